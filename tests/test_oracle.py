@@ -1,0 +1,221 @@
+"""Pins the CPU oracle (oracle/zk_oracle.c) before anything trusts it.
+
+The reference holds no golden vectors ("parity unpinned"), so the oracle is
+pinned by (1) oracle/pyref.py -- first-principles Python big ints, (2) the hand-derived
+README-circuit fixture tests/golden/readme_circuit.json, (3) the reference's own algebraic
+self-tests restated here (curve.ml:224-239, polynomial.ml:94-97,135-139,180-209,232-246;
+FFT.ml:88-108), (4) `verify = true` through a pairing (src/lib/test/test.ml:178).
+"""
+import json
+import os
+import random
+
+import pytest
+
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import r1cs as RC
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_circuit.json")
+rnd = random.Random(20261003)
+
+
+def frb(x):
+    return P.fr_to_bytes(x)
+
+
+def frs(xs):
+    return b"".join(P.fr_to_bytes(x) for x in xs)
+
+
+def csrs(cs):
+    return [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+
+
+def test_constants_and_generators():
+    d = json.load(open(GOLDEN))
+    assert O.fr_omega() == frb(int(d["omega_2_32"], 16))
+    assert O.g1_compress(O.g1_generator()).hex() == d["g1_generator_compressed"]
+    assert O.g2_compress(O.g2_generator()).hex() == d["g2_generator_compressed"]
+    assert d["g1_generator_compressed"].startswith("97f1d3a7")
+    assert d["g2_generator_compressed"].startswith("93e02b60")
+    assert P.on_curve(P.G1, P.B1) and P.on_curve(P.G2, P.B2)
+    assert P.pt_mul(P.G1, P.R) is None and P.pt_mul(P.G2, P.R) is None
+    assert pow(P.OMEGA, 1 << 32, P.R) == 1 and pow(P.OMEGA, 1 << 31, P.R) != 1
+
+
+def test_field_vs_bigint():
+    for _ in range(50):
+        a, b = rnd.randrange(P.R), rnd.randrange(P.R)
+        assert O.fr_mul(frb(a), frb(b)) == frb(a * b % P.R)
+    for a in (1, 2, P.R - 1, rnd.randrange(P.R)):
+        assert O.fr_inv(frb(a)) == frb(P.fr_inv(a))
+
+
+def test_group_vs_bigint():
+    g1, g2 = O.g1_generator(), O.g2_generator()
+    for k in (0, 1, 2, P.R - 1, rnd.randrange(P.R), rnd.randrange(P.R)):
+        p1, p2 = P.pt_mul(P.G1, k), P.pt_mul(P.G2, k)
+        assert O.g1_mul(g1, frb(k)) == P.g1_to_bytes(p1)
+        assert O.g2_mul(g2, frb(k)) == P.g2_to_bytes(p2)
+        assert O.g1_compress(P.g1_to_bytes(p1)) == P.g1_compress(p1)
+        assert O.g2_compress(P.g2_to_bytes(p2)) == P.g2_compress(p2)
+    p = P.pt_mul(P.G1, 12345)
+    q = P.pt_mul(P.G1, 999)
+    pb, qb = P.g1_to_bytes(p), P.g1_to_bytes(q)
+    assert O.g1_add(pb, qb) == P.g1_to_bytes(P.pt_add(p, q))
+    assert O.g1_add(pb, pb) == P.g1_to_bytes(P.pt_add(p, p))                 # P + P
+    assert O.g1_add(pb, P.g1_to_bytes(P.pt_neg(p))) == P.g1_to_bytes(None)   # P + (-P)
+    assert O.g1_add(pb, P.g1_to_bytes(None)) == pb                            # P + O
+    p2 = P.pt_mul(P.G2, 777)
+    assert O.g2_add(P.g2_to_bytes(p2), P.g2_to_bytes(p2)) == P.g2_to_bytes(P.pt_add(p2, p2))
+
+
+def test_curve_ml_homomorphism_selftest():
+    """curve.ml:224-239: g*a = of_Fr a ; g*(ab+cd) = g*ab + g*cd for random ints < 10000."""
+    a, b, c, d = (rnd.randrange(10000) for _ in range(4))
+    g = O.g1_generator()
+    lhs = O.g1_mul(g, frb(a * b + c * d))
+    rhs = O.g1_add(O.g1_mul(g, frb(a * b)), O.g1_mul(g, frb(c * d)))
+    assert lhs == rhs
+
+
+def test_ntt_vs_definition():
+    """FFT.ml:29-67: out[k] = sum_j a_j w_N^(jk), natural order; inverse divides by N."""
+    for lg in range(0, 7):
+        a = [rnd.randrange(P.R) for _ in range(1 << lg)]
+        assert O.fr_ntt(frs(a), lg, False) == frs(P.ntt(a))
+        assert O.fr_ntt(frs(a), lg, True) == frs(P.ntt(a, True))
+    a = [rnd.randrange(P.R) for _ in range(1 << 10)]
+    assert O.fr_ntt(O.fr_ntt(frs(a), 10, False), 10, True) == frs(a)   # FFT.ml:88-96 test_fft
+
+
+def test_ntt_polynomial_mul_equals_naive():
+    """FFT.ml:98-108 polynomial_mul == Polynomial.mul."""
+    p1 = [rnd.randrange(P.R) for _ in range(13)]
+    p2 = [rnd.randrange(P.R) for _ in range(20)]
+    lg = 6
+    f1 = RC.fr_ints(O.fr_ntt(frs(p1 + [0] * (64 - 13)), lg, False))
+    f2 = RC.fr_ints(O.fr_ntt(frs(p2 + [0] * (64 - 20)), lg, False))
+    prod = RC.fr_ints(O.fr_ntt(frs([x * y % P.R for x, y in zip(f1, f2)]), lg, True))
+    assert P.poly_normalize(prod) == P.poly_mul(p1, p2)
+    assert RC.fr_ints(O.poly_mul(frs(p1), frs(p2))) == P.poly_mul(p1, p2)
+
+
+def test_polynomial_ml_kats():
+    """polynomial.ml:94-97 apply KAT, :135-139 mul KAT, :180-209 div_rem identity, over Fr."""
+    one = [1, 1, 1]
+    assert RC.fr_ints(O.poly_mul(frs(one), frs([1, 1, 1, 1]))) == [1, 2, 3, 3, 2, 1]
+    assert P.poly_eval([1, 2, 3, 4], 2) == 49
+    for _ in range(50):
+        a = [rnd.randrange(P.R) for _ in range(rnd.randrange(1, 20))]
+        b = [rnd.randrange(P.R) for _ in range(rnd.randrange(1, 20))]
+        q, r = O.poly_divrem(frs(a), frs(b))
+        qi, ri = RC.fr_ints(q), RC.fr_ints(r)
+        assert len(ri) < len(b)
+        assert P.poly_add(P.poly_mul(qi, b), ri) == P.poly_normalize(a)
+        pq, pr = P.poly_divrem(a, b)
+        assert P.poly_normalize(qi) == pq and ri == pr
+
+
+def test_readme_circuit_fixture():
+    d = json.load(open(GOLDEN))
+    for case in d["cases"]:
+        cs, w = RC.readme_circuit(case["x"])
+        assert [hex(x) for x in w] == case["witness"]
+        assert cs.check(w)
+        q = O.QAP(cs.n, cs.m, *csrs(cs))
+        assert [hex(x) for x in RC.fr_ints(q.poly(3))] == d["z"]
+        rc, p, h = q.eval(frs(w))
+        assert rc == 0
+        assert [hex(x) for x in RC.fr_ints(h)] == case["h"]
+        assert [hex(x) for x in RC.fr_ints(p)] == case["p"]
+        v, ww, y = q.eval_vwy(frs(w))
+        assert [hex(x) for x in P.poly_normalize(RC.fr_ints(v))] == case["v"]
+        assert [hex(x) for x in P.poly_normalize(RC.fr_ints(ww))] == case["w"]
+        assert [hex(x) for x in P.poly_normalize(RC.fr_ints(y))] == case["y"]
+    # x = 3: h = -15 - 9 X
+    assert [int(c, 16) for c in d["cases"][0]["h"]] == [P.R - 15, P.R - 9]
+    # unsatisfied witness -> non-zero remainder (QAP.ml:134 assert)
+    cs, w = RC.readme_circuit(3)
+    w[4] += 1
+    q = O.QAP(cs.n, cs.m, *csrs(cs))
+    assert q.eval(frs(w))[0] == -3
+
+
+def test_qap_build_interpolates():
+    """QAP.ml:81-86: every variable polynomial takes the gate coefficient at X = gate id."""
+    cs, w = RC.iterated_cubic(8, 5)
+    q = O.QAP(cs.n, cs.m, *csrs(cs))
+    for which, M in ((0, cs.L), (1, cs.R), (2, cs.O)):
+        dense = [[0] * cs.n for _ in range(cs.m)]
+        for g in range(cs.n):
+            for e in range(M.ptr[g], M.ptr[g + 1]):
+                dense[M.col[e]][g] = int.from_bytes(bytes(M.val[32 * e:32 * e + 32]), "little")
+        for k in range(cs.m):
+            poly = RC.fr_ints(q.poly(which, k))
+            assert [P.poly_eval(poly, g) for g in range(cs.n)] == dense[k]
+            assert poly == P.interpolate_int_domain(dense[k])
+
+
+def _groth16_verify(cs, w, pk1, pk2, vk1, vk2, a, b, c):
+    """groth16.ml:163-173: e(A,B) = e(alpha,beta) + e(sum_io w_k L_k/gamma, gamma) + e(C, delta)."""
+    A, B, Cc = P.g1_from_bytes(a), P.g2_from_bytes(b), P.g1_from_bytes(c)
+    alpha1, beta2 = P.g1_from_bytes(pk1[:96]), P.g2_from_bytes(pk2[:192])
+    gm, dl = P.g2_from_bytes(vk2[192:384]), P.g2_from_bytes(vk2[384:576])
+    io = [k for k in range(cs.m) if not cs.mid[k]]
+    acc = None
+    for j, k in enumerate(io):
+        acc = P.pt_add(acc, P.pt_mul(P.g1_from_bytes(vk1[96 * (1 + j):96 * (2 + j)]), w[k]))
+    return P.pairing_product_is_one([(A, B), (P.pt_neg(alpha1), beta2), (P.pt_neg(acc), gm), (P.pt_neg(Cc), dl)])
+
+
+@pytest.mark.parametrize("maker", [lambda: RC.readme_circuit(3), lambda: RC.iterated_cubic(8, 0x1234567)])
+def test_groth16_literal_equals_msm_form_equals_trapdoor_and_verifies(maker):
+    cs, w = maker()
+    assert cs.check(w)
+    L, R_, Oo = csrs(cs)
+    q = O.QAP(cs.n, cs.m, L, R_, Oo)
+    st = P.fr_stream(0x5EED0002)
+    tox = [next(st) for _ in range(7)]
+    toxic, r, s = frs(tox[:5]), frb(tox[5]), frb(tox[6])
+    pk1, pk2, vk1, vk2 = q.groth16_setup(toxic, cs.mid)
+    sol = frs(w)
+    rc1, a1, b1, c1 = q.groth16_prove(pk1, pk2, cs.mid, sol, r, s, 1)   # literal groth16.ml:116-161
+    rc0, a0, b0, c0 = q.groth16_prove(pk1, pk2, cs.mid, sol, r, s, 0)
+    a2, b2, c2 = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, sol, toxic, r, s)
+    assert rc1 == 0 and rc0 == 0
+    assert a1 == a0 == a2 and b1 == b0 == b2 and c1 == c0 == c2
+    assert _groth16_verify(cs, w, pk1, pk2, vk1, vk2, a1, b1, c1)
+    # a tampered proof must not verify
+    assert not _groth16_verify(cs, w, pk1, pk2, vk1, vk2, O.g1_add(a1, O.g1_generator()), b1, c1)
+    # setup exponents reproduce the key
+    e1, e2, eio = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, toxic)
+    g1, g2 = O.g1_generator(), O.g2_generator()
+    for i in range(len(e1) // 32):
+        assert O.g1_mul(g1, e1[32 * i:32 * i + 32]) == pk1[96 * i:96 * i + 96]
+    for i in range(len(e2) // 32):
+        assert O.g2_mul(g2, e2[32 * i:32 * i + 32]) == pk2[192 * i:192 * i + 192]
+    for i in range(len(eio) // 32):
+        assert O.g1_mul(g1, eio[32 * i:32 * i + 32]) == vk1[96 * (1 + i):96 * (2 + i)]
+
+
+def test_msm_naive_matches_bigint_and_apply_powers_errors():
+    n = 6
+    ks = [rnd.randrange(P.R) for _ in range(n)]
+    ss = [rnd.randrange(P.R) for _ in range(n)]
+    bases1 = b"".join(O.g1_mul(O.g1_generator(), frb(k)) for k in ks)
+    bases2 = b"".join(O.g2_mul(O.g2_generator(), frb(k)) for k in ks)
+    rc, out = O.g1_msm_naive(bases1, frs(ss))
+    exp = sum(k * s for k, s in zip(ks, ss)) % P.R
+    assert rc == 0 and out == O.g1_mul(O.g1_generator(), frb(exp))
+    assert out == P.g1_to_bytes(P.msm([P.g1_from_bytes(bases1[96 * i:96 * i + 96]) for i in range(n)], ss))
+    rc, out = O.g2_msm_naive(bases2, frs(ss))
+    assert rc == 0 and out == O.g2_mul(O.g2_generator(), frb(exp))
+    assert O.fr_dot(frs(ks), frs(ss)) == frb(exp)
+    # curve.ml:116 invalid_arg "apply_powers": fewer points than coefficients
+    assert O.g1_msm_naive(bases1[:96 * 3], frs(ss))[0] == -2
+    # curve.ml:115: coefficients may run out first
+    rc, out = O.g1_msm_naive(bases1, frs(ss[:3]))
+    assert rc == 0 and out == O.g1_mul(O.g1_generator(), frb(sum(k * s for k, s in zip(ks[:3], ss[:3])) % P.R))
+    assert O.g1_msm_naive(b"", b"")[1] == P.g1_to_bytes(None)
