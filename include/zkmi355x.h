@@ -1,0 +1,148 @@
+/* libzkmi355x -- C-ABI of the MI355X-native Groth16 / Pinocchio prove path for zukelang.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Every entry
+ * point names the reference interface it replaces (paths relative to the zukelang tree).  The
+ * OCaml ctypes stubs a maintainer would add are shown in INTEGRATION.md.
+ *
+ * Byte formats (what the OCaml side already holds):
+ *   Fr      32 B little-endian canonical integer < r            (Bls12_381.Fr.to_bytes)
+ *   G1      96 B uncompressed ZCash big-endian x || y           (G1.to_bytes, curve.ml:161)
+ *   G2     192 B uncompressed x1 || x0 || y1 || y0              (G2.to_bytes)
+ *   infinity: first byte 0x40, rest zero.
+ *   Compressed outputs (48 B / 96 B) carry the 0x80 / 0x40 / 0x20 flag bits of
+ *   to_compressed_bytes (curve.ml:199,208) -- the JSON form of proofs (groth16.ml:110-114).
+ *
+ * Ownership: all buffers are caller-owned; the library copies host->device and retains no host
+ * pointer after return.  Long-lived device state sits behind uint64_t handles with explicit free.
+ * Threading: calls are synchronous and blocking (the reference is single-threaded OCaml); one
+ * process drives one GPU.
+ * Errors: 0 = ok, negative = the codes below (the reference raises exceptions; the shim maps
+ * ZK_ERR_APPLY_POWERS -> Invalid_argument "apply_powers", ZK_ERR_REMAINDER / ZK_ERR_DOMAIN ->
+ * Assert_failure, the rest -> Failure (zk_strerror)).
+ */
+#ifndef ZKMI355X_H
+#define ZKMI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define ZK_OK 0
+#define ZK_ERR_ARG (-1)            /* bad length / null pointer / unsupported size */
+#define ZK_ERR_NOT_ON_CURVE (-2)   /* a base point fails y^2 = x^3 + b */
+#define ZK_ERR_SCALAR_RANGE (-3)   /* an Fr input is >= r */
+#define ZK_ERR_REMAINDER (-4)      /* p mod Z != 0: `assert (Polynomial.is_zero rem)`, src/lib/zk/QAP.ml:134 */
+#define ZK_ERR_HIP (-5)            /* HIP runtime error (no GPU, OOM, launch failure) */
+#define ZK_ERR_APPLY_POWERS (-6)   /* fewer points than coefficients: invalid_arg "apply_powers", src/lib/zk/curve.ml:116 */
+#define ZK_ERR_HANDLE (-7)         /* unknown or freed handle */
+#define ZK_ERR_DOMAIN (-8)         /* key sets differ: `assert false` in G.dot, src/lib/zk/curve.ml:96-100 */
+
+const char* zk_strerror(int code);
+const char* zk_last_error(void);       /* detail of the most recent failure in this process */
+int zk_device_count(void);             /* number of visible HIP devices (0 without a GPU) */
+int zk_init(int device);               /* bind this process to one GPU; idempotent */
+int zk_shutdown(void);
+
+/* ---- Fr stage ---------------------------------------------------------------------------
+ * FFT.Make(F).fft / ifft over Bls12_381.Fr -- src/lib/zk/FFT.ml:29-86,222-233:
+ * out[k] = sum_j a_j w_N^(jk), w_N = w^(2^32/N), w = 5^((r-1)/2^32); natural order in and out;
+ * inverse uses w^-1 and divides by N.  inout: 2^log_n Fr elements. */
+int zk_fr_ntt(uint8_t* inout, uint32_t log_n, int inverse);
+
+/* FFT.Make(F).polynomial_mul -- src/lib/zk/FFT.ml:98-105 (== Polynomial.mul, polynomial.ml:124-131):
+ * out receives na+nb-1 coefficients (low -> high), *nout the normalized length. */
+int zk_fr_poly_mul(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, uint8_t* out, size_t* nout);
+
+/* ---- curve plugin seam (Curve.S.G, src/lib/zk/curve.mli:3-31) ------------------------------
+ * G.apply_powers cs xis / G.dot m c -- src/lib/zk/curve.ml:94-118: sum_i scalars[i] * bases[i]
+ * over the first nscalars bases.  nscalars > nbases -> ZK_ERR_APPLY_POWERS.  window_bits 0 = auto. */
+int zk_msm_g1(const uint8_t* bases, size_t nbases, const uint8_t* scalars, size_t nscalars,
+              uint32_t window_bits, uint8_t out[96]);
+int zk_msm_g2(const uint8_t* bases, size_t nbases, const uint8_t* scalars, size_t nscalars,
+              uint32_t window_bits, uint8_t out[192]);
+
+/* G.of_Fr mapped over a vector (G1.one * s_i) -- src/lib/zk/curve.ml:180; the engine of
+ * G.powers (curve.ml:106-109) and of keygen (groth16.ml:70-90, pinocchio.ml:104-156). */
+int zk_g1_of_fr(const uint8_t* scalars, size_t n, uint8_t* out /* n*96 */);
+int zk_g2_of_fr(const uint8_t* scalars, size_t n, uint8_t* out /* n*192 */);
+/* G.powers d s = [ g^(s^i) | i = 0..d ] -- src/lib/zk/curve.ml:106-109 (d+1 points). */
+int zk_g1_powers(uint32_t d, const uint8_t s[32], uint8_t* out /* (d+1)*96 */);
+int zk_g2_powers(uint32_t d, const uint8_t s[32], uint8_t* out /* (d+1)*192 */);
+
+/* to_compressed_bytes (curve.ml:199,208) of one uncompressed point. */
+int zk_g1_compress(const uint8_t in[96], uint8_t out[48]);
+int zk_g2_compress(const uint8_t in[192], uint8_t out[96]);
+
+/* ---- protocol seam: Groth16.Make(C).prove (src/groth16/groth16.ml:235-237) -------------------
+ * The circuit enters as sparse R1CS rows instead of the dense QAP.t (which is 3*m*n field
+ * elements, QAP.ml:11-16): three CSR matrices L (`v`, left operand), R (`w`, right operand),
+ * O (`y`, the gate's lhs) with n rows = gates in Gate.Set order (QAP.ml:22) and m columns =
+ * variables in Var.compare order; `lhs = l * r` (src/lib/zk/circuit.ml:73-75). */
+typedef struct {
+    const uint32_t* row_ptr;   /* n + 1 */
+    const uint32_t* col;       /* nnz   */
+    const uint8_t* val;        /* nnz * 32, Fr */
+} zk_csr;
+
+/* Proving key of groth16.ml:24-34, fields in declaration order, plus the circuit.
+ *   g1: a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid[n_mid]   (ltd_mid in Var.Map key order)
+ *   g2: b2 | d2 | ti2[n+2]
+ *   mid[k] != 0  <=>  variable k is in Dom(ltd_mid) (= circuit.mids, groth16.ml:74-79).
+ * Uploads once, precomputes the per-n tables of the Fr stage, returns a handle. */
+int zk_groth16_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
+                         const uint8_t* mid /* m */, const uint8_t* pk_g1, size_t pk_g1_points,
+                         const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
+int zk_groth16_pk_free(uint64_t handle);
+
+/* Groth16.prove rng qap pkey sol with r, s supplied by the caller in the order the reference
+ * draws them (groth16.ml:124-125; Fr.gen is an external function).
+ * sol: m Fr values in Var.compare order (the witness incl. ONE).
+ * proof: a (G1 96 B) | b (G2 192 B) | c (G1 96 B) uncompressed; zk_g*_compress gives the JSON form.
+ * Returns ZK_ERR_REMAINDER when the witness does not satisfy the gates (QAP.ml:134). */
+int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
+                     uint8_t proof[384]);
+
+/* QAP.eval (src/lib/zk/QAP.ml:120-135) on the uploaded circuit: coefficient vectors of
+ * v = sum_k sol_k v_k, w, and h = (v*w - y)/Z, each padded with zeros to n (h: n-1). Any out
+ * pointer may be NULL. */
+int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out);
+
+/* ---- point-sharded multi-GPU prove --------------------------------------------
+ * Rank `rank` of `world` uploads the same key but keeps only its contiguous slice of every base
+ * vector; zk_groth16_prove_partial returns that rank's five partial sums (A, B1, H, L in G1 and
+ * B in G2) as raw XYZZ Montgomery limbs (4*48 B each for G1, 4*96 B for G2 = 1152 B total) for the
+ * host to all-gather; zk_groth16_combine adds `world` partial blocks and finishes the proof. */
+#define ZK_GROTH16_PARTIAL_BYTES 1152
+int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
+                                 const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
+                                 const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world,
+                                 uint64_t* handle);
+int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]);
+int zk_groth16_combine(uint64_t handle, const uint8_t* partials, uint32_t world, const uint8_t r[32],
+                       const uint8_t s[32], uint8_t proof[384]);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------------
+ * With profiling on, kernel families are bracketed by HIP events on the stream they run on;
+ * zk_profile_get returns the summed milliseconds and launch count since the last reset. */
+int zk_profile_enable(int on);
+int zk_profile_reset(void);
+int zk_profile_get(const char* family, double* total_ms, uint64_t* launches);
+int zk_profile_names(char* buf, size_t buflen);   /* comma-separated family names */
+int zk_sync(void);                                 /* hipStreamSynchronize on the library's streams */
+/* Throughput of the register-resident Montgomery multiplier (kind 0 = Fr, 1 = Fp): ALU ceiling. */
+int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif

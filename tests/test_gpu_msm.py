@@ -1,0 +1,101 @@
+"""GPU parity: Pippenger MSM (HIP) == the oracle's left fold of scalar multiplications
+(curve.ml:91-118), bit-exact on the uncompressed encodings; G.of_Fr / G.powers likewise."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import r1cs as RC
+from zukelang_amd.curve import G1, G2
+
+pytestmark = pytest.mark.gpu
+
+
+def frb(x):
+    return P.fr_to_bytes(x)
+
+
+@pytest.mark.parametrize("G,gen,mul", [(G1, O.g1_generator, O.g1_mul), (G2, O.g2_generator, O.g2_mul)])
+def test_of_fr_and_powers_match_oracle(G, gen, mul):
+    ks = [0, 1, 2, P.R - 1, 0x1234567890ABCDEF, P.R // 3] + [int.from_bytes(bytes(RC.random_fr_bytes(1, 40 + i)), "little") for i in range(10)]
+    got = bytes(G.of_Fr(b"".join(frb(k) for k in ks)))
+    B = G.POINT_BYTES
+    for i, k in enumerate(ks):
+        assert got[B * i:B * (i + 1)] == mul(gen(), frb(k)), i
+    s = 0x0BADC0FFEE0DDF00D
+    pw = bytes(G.powers(9, frb(s)))
+    ref = (O.g1_powers if G is G1 else O.g2_powers)(9, frb(s))
+    assert pw == ref
+
+
+@pytest.mark.parametrize("n,c", [(1, 0), (2, 4), (7, 3), (33, 5), (100, 8), (257, 0), (600, 11)])
+def test_msm_g1_matches_naive_oracle(n, c):
+    ks = RC.random_fr_bytes(n, 1000 + n)
+    bases = G1.of_Fr(ks)
+    scalars = RC.random_fr_bytes(n, 2000 + n)
+    rc, ref = O.g1_msm_naive(bytes(bases), bytes(scalars))
+    assert rc == 0
+    assert bytes(G1.apply_powers(scalars, bases, c)) == ref
+
+
+@pytest.mark.parametrize("n,c", [(1, 0), (5, 3), (64, 6), (300, 0)])
+def test_msm_g2_matches_naive_oracle(n, c):
+    ks = RC.random_fr_bytes(n, 3000 + n)
+    bases = G2.of_Fr(ks)
+    scalars = RC.random_fr_bytes(n, 4000 + n)
+    rc, ref = O.g2_msm_naive(bytes(bases), bytes(scalars))
+    assert rc == 0
+    assert bytes(G2.apply_powers(scalars, bases, c)) == ref
+
+
+def test_msm_edge_cases():
+    """Adversarial inputs for the bucket sums: duplicates (P+P), negations (P+(-P)), zero and
+    boundary scalars, infinity among the bases (SURVEY 7.2 hard part 5)."""
+    g = O.g1_generator()
+    p = O.g1_mul(g, frb(5))
+    inf = bytes([0x40]) + bytes(95)
+    bases = p * 6 + inf + g
+    scalars = [7, 7, P.R - 7, 0, 1, P.R - 1, 12345, 0x8000]      # same digit -> same bucket: doubling path
+    rc, ref = O.g1_msm_naive(bases, b"".join(frb(s) for s in scalars))
+    for c in (2, 3, 4, 8, 13, 16):
+        assert bytes(G1.apply_powers(b"".join(frb(s) for s in scalars), bases, c)) == ref, c
+    # everything cancels -> infinity
+    sc = [3, P.R - 3]
+    assert bytes(G1.apply_powers(b"".join(frb(s) for s in sc), p * 2, 0)) == inf
+    # curve.ml:116 invalid_arg "apply_powers"
+    with pytest.raises(ValueError):
+        G1.apply_powers(frb(1) * 3, p * 2)
+    # curve.ml:115: fewer coefficients than points is fine
+    assert bytes(G1.apply_powers(frb(2), p * 2)) == O.g1_mul(p, frb(2))
+    assert bytes(G1.apply_powers(b"", b"")) == inf
+    # dot over different key sets: curve.ml:96-100 assert false
+    with pytest.raises(AssertionError):
+        G1.dot({1: p, 2: p}, {1: frb(1), 3: frb(1)})
+    assert bytes(G1.dot({1: p, 2: g}, {2: frb(3), 1: frb(4)})) == O.g1_add(O.g1_mul(p, frb(4)), O.g1_mul(g, frb(3)))
+
+
+def test_msm_rejects_bad_inputs():
+    from zukelang_amd._lib import ZkError
+    g = bytearray(O.g1_generator())
+    g[95] ^= 1
+    with pytest.raises(ZkError) as e:
+        G1.apply_powers(frb(1), bytes(g))
+    assert e.value.code == -2
+    with pytest.raises(ZkError) as e:
+        G1.apply_powers((P.R).to_bytes(32, "little"), O.g1_generator())
+    assert e.value.code == -3
+
+
+@pytest.mark.parametrize("G,mul,gen,logn", [(G1, O.g1_mul, O.g1_generator, 16), (G2, O.g2_mul, O.g2_generator, 14), (G1, O.g1_mul, O.g1_generator, 20)])
+def test_msm_large_trapdoor(G, mul, gen, logn):
+    """Full-size exact check: bases k_i*G with known k_i, so MSM = (sum s_i k_i) * G."""
+    n = 1 << logn
+    ks = RC.random_fr_bytes(n, 77)
+    scalars = RC.random_fr_bytes(n, 78)
+    bases = G.of_Fr(ks)
+    # spot-check the fixed-base kernel against the oracle
+    B = G.POINT_BYTES
+    for i in (0, 1, n // 2, n - 1):
+        assert bytes(bases[B * i:B * (i + 1)]) == mul(gen(), bytes(ks[32 * i:32 * i + 32]))
+    expect = mul(gen(), O.fr_dot(bytes(ks), bytes(scalars)))
+    assert bytes(G.apply_powers(scalars, bases, 0)) == expect

@@ -1,0 +1,64 @@
+"""ctypes loader of libzkmi355x.so -- the HIP product library (include/zkmi355x.h).
+
+There is no CPU fallback: if the shared object is missing, or no MI355X is visible when a
+compute entry point is called, the error is raised to the caller.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkmi355x.so")
+
+# every symbol include/zkmi355x.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTS = [
+    "zk_strerror", "zk_last_error", "zk_device_count", "zk_init", "zk_shutdown",
+    "zk_fr_ntt", "zk_fr_poly_mul", "zk_msm_g1", "zk_msm_g2", "zk_g1_of_fr", "zk_g2_of_fr",
+    "zk_g1_powers", "zk_g2_powers", "zk_g1_compress", "zk_g2_compress",
+    "zk_groth16_pk_upload", "zk_groth16_pk_free", "zk_groth16_prove", "zk_groth16_qap_eval",
+    "zk_groth16_pk_upload_sharded", "zk_groth16_prove_partial", "zk_groth16_combine",
+    "zk_profile_enable", "zk_profile_reset", "zk_profile_get", "zk_profile_names", "zk_sync",
+    "zk_bench_field_mul",
+]
+
+
+class ZkError(RuntimeError):
+    def __init__(self, code, detail):
+        self.code = code
+        super().__init__("libzkmi355x error %d: %s" % (code, detail))
+
+
+class CSR(C.Structure):
+    _fields_ = [("row_ptr", C.POINTER(C.c_uint32)), ("col", C.POINTER(C.c_uint32)), ("val", C.POINTER(C.c_uint8))]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.zk_strerror.restype = C.c_char_p
+        _lib.zk_last_error.restype = C.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        L = lib()
+        raise ZkError(rc, "%s -- %s" % (L.zk_strerror(rc).decode(), L.zk_last_error().decode()))
+    return rc
+
+
+def u8(buf):
+    """numpy uint8 array / bytes -> (pointer, keepalive)."""
+    import numpy as np
+    if isinstance(buf, (bytes, bytearray)):
+        arr = np.frombuffer(bytes(buf), dtype=np.uint8)
+    else:
+        arr = np.ascontiguousarray(buf, dtype=np.uint8)
+    return arr.ctypes.data_as(C.POINTER(C.c_uint8)), arr

@@ -1,0 +1,197 @@
+// BLS12-381 G1 / G2 group law for gfx950, generic over the coordinate field (Fp or Fp2).
+//
+// Accumulators use extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2):
+// the mixed addition XYZZ += affine costs 8M + 2S with no inversion, which is what the Pippenger
+// bucket loop executes n * windows times.  Every special case the bucket sums hit (identity
+// operands, P + P, P + (-P)) is branched explicitly -- bit-exact results depend on it
+// (SURVEY.md 7.2 hard part 5).  ZZ = 0 encodes the identity, so zero-filled memory is a valid
+// array of identities.  Affine (0, 0) encodes the identity (not on either curve since b != 0).
+//
+// Computes the same group elements as the reference's G.add / G.mul / G.negate
+// (src/lib/zk/curve.ml:159-191, delegated to opam bls12-381).
+#pragma once
+#include "ff.cuh"
+
+namespace zk {
+
+template <class F> struct FieldOps;
+template <> struct FieldOps<Fp> {
+    static FF_INLINE Fp zero() { return fe_zero<FpParams>(); }
+    static FF_INLINE Fp one() { return fe_one<FpParams>(); }
+    static FF_INLINE Fp curve_b() { Fp o = one(); return fe_dbl(fe_dbl(o)); }   // 4
+    static constexpr int WORDS = 12;
+};
+template <> struct FieldOps<Fp2> {
+    static FF_INLINE Fp2 zero() { return fp2_zero(); }
+    static FF_INLINE Fp2 one() { return fp2_one(); }
+    static FF_INLINE Fp2 curve_b() { Fp f = fe_dbl(fe_dbl(fe_one<FpParams>())); return {f, f}; }  // 4 + 4u
+    static constexpr int WORDS = 24;
+};
+
+template <class F> struct Aff {
+    F x, y;
+};
+template <class F> struct Xyzz {
+    F x, y, zz, zzz;
+};
+using G1Aff = Aff<Fp>;
+using G2Aff = Aff<Fp2>;
+using G1Xyzz = Xyzz<Fp>;
+using G2Xyzz = Xyzz<Fp2>;
+
+template <class F> FF_INLINE bool aff_is_inf(const Aff<F>& p) { return fe_is_zero(p.x) && fe_is_zero(p.y); }
+template <class F> FF_INLINE Aff<F> aff_inf() { return {FieldOps<F>::zero(), FieldOps<F>::zero()}; }
+template <class F> FF_INLINE bool xyzz_is_inf(const Xyzz<F>& p) { return fe_is_zero(p.zz); }
+template <class F> FF_INLINE Xyzz<F> xyzz_inf() {
+    F z = FieldOps<F>::zero();
+    return {z, z, z, z};
+}
+template <class F> FF_INLINE Xyzz<F> xyzz_from_aff(const Aff<F>& p) {
+    if (aff_is_inf(p)) return xyzz_inf<F>();
+    return {p.x, p.y, FieldOps<F>::one(), FieldOps<F>::one()};
+}
+template <class F> FF_INLINE Xyzz<F> xyzz_neg(const Xyzz<F>& p) { return {p.x, fe_neg(p.y), p.zz, p.zzz}; }
+template <class F> FF_INLINE Aff<F> aff_neg(const Aff<F>& p) { return {p.x, fe_neg(p.y)}; }
+
+// y^2 == x^3 + b
+template <class F> FF_INLINE bool aff_on_curve(const Aff<F>& p) {
+    if (aff_is_inf(p)) return true;
+    F l = fe_sqr(p.y);
+    F r = fe_add(fe_mul(fe_sqr(p.x), p.x), FieldOps<F>::curve_b());
+    return fe_eq(l, r);
+}
+
+// dbl-2008-s-1 (a = 0)
+template <class F> FF_INLINE Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+    if (xyzz_is_inf(p) || fe_is_zero(p.y)) return xyzz_inf<F>();
+    F U = fe_dbl(p.y);
+    F V = fe_sqr(U);
+    F W = fe_mul(U, V);
+    F S = fe_mul(p.x, V);
+    F X2 = fe_sqr(p.x);
+    F M = fe_add(fe_dbl(X2), X2);
+    F X3 = fe_sub(fe_sqr(M), fe_dbl(S));
+    F Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
+    return {X3, Y3, fe_mul(V, p.zz), fe_mul(W, p.zzz)};
+}
+// mdbl-2008-s-1: doubling of an affine point
+template <class F> FF_INLINE Xyzz<F> xyzz_dbl_aff(const Aff<F>& p) {
+    if (aff_is_inf(p) || fe_is_zero(p.y)) return xyzz_inf<F>();
+    F U = fe_dbl(p.y);
+    F V = fe_sqr(U);
+    F W = fe_mul(U, V);
+    F S = fe_mul(p.x, V);
+    F X2 = fe_sqr(p.x);
+    F M = fe_add(fe_dbl(X2), X2);
+    F X3 = fe_sub(fe_sqr(M), fe_dbl(S));
+    F Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
+    return {X3, Y3, V, W};
+}
+// madd-2008-s: acc += q (q affine)
+template <class F> FF_INLINE void xyzz_madd(Xyzz<F>& acc, const Aff<F>& q) {
+    if (aff_is_inf(q)) return;
+    if (xyzz_is_inf(acc)) {
+        acc = {q.x, q.y, FieldOps<F>::one(), FieldOps<F>::one()};
+        return;
+    }
+    F U2 = fe_mul(q.x, acc.zz);
+    F S2 = fe_mul(q.y, acc.zzz);
+    F P = fe_sub(U2, acc.x);
+    F R = fe_sub(S2, acc.y);
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R)) acc = xyzz_dbl_aff(q);
+        else acc = xyzz_inf<F>();
+        return;
+    }
+    F PP = fe_sqr(P);
+    F PPP = fe_mul(P, PP);
+    F Q = fe_mul(acc.x, PP);
+    F X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    F Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(acc.y, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = fe_mul(acc.zz, PP);
+    acc.zzz = fe_mul(acc.zzz, PPP);
+}
+// add-2008-s: acc += q (both XYZZ)
+template <class F> FF_INLINE void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
+    if (xyzz_is_inf(q)) return;
+    if (xyzz_is_inf(acc)) {
+        acc = q;
+        return;
+    }
+    F U1 = fe_mul(acc.x, q.zz);
+    F U2 = fe_mul(q.x, acc.zz);
+    F S1 = fe_mul(acc.y, q.zzz);
+    F S2 = fe_mul(q.y, acc.zzz);
+    F P = fe_sub(U2, U1);
+    F R = fe_sub(S2, S1);
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R)) acc = xyzz_dbl(acc);
+        else acc = xyzz_inf<F>();
+        return;
+    }
+    F PP = fe_sqr(P);
+    F PPP = fe_mul(P, PP);
+    F Q = fe_mul(U1, PP);
+    F X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    F Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(S1, PPP));
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = fe_mul(fe_mul(acc.zz, q.zz), PP);
+    acc.zzz = fe_mul(fe_mul(acc.zzz, q.zzz), PPP);
+}
+// one inversion: 1/(ZZ*ZZZ)
+template <class F> FF_INLINE Aff<F> xyzz_to_aff(const Xyzz<F>& p) {
+    if (xyzz_is_inf(p)) return aff_inf<F>();
+    F i = fe_inv(fe_mul(p.zz, p.zzz));
+    F izz = fe_mul(i, p.zzz);
+    F izzz = fe_mul(i, p.zz);
+    return {fe_mul(p.x, izz), fe_mul(p.y, izzz)};
+}
+// k * p for a small non-negative k (bucket index weights), double-and-add from the top bit
+template <class F> FF_INLINE Xyzz<F> xyzz_mul_u32(const Xyzz<F>& p, uint32_t k) {
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (int b = 31 - __builtin_clz(k | 1); b >= 0; b--) {
+        acc = xyzz_dbl(acc);
+        if ((k >> b) & 1) xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+// ---- memory layout: affine points are stored as consecutive Montgomery coordinates
+//      (G1: x | y = 96 B; G2: x.c0 | x.c1 | y.c0 | y.c1 = 192 B), XYZZ as x | y | zz | zzz.
+FF_INLINE Fp load_f(const Fp*, const void* p) { return fe_load<FpParams>(p); }
+FF_INLINE Fp2 load_f(const Fp2*, const void* p) {
+    return {fe_load<FpParams>(p), fe_load<FpParams>((const char*)p + 48)};
+}
+FF_INLINE void store_f(void* p, const Fp& a) { fe_store<FpParams>(p, a); }
+FF_INLINE void store_f(void* p, const Fp2& a) {
+    fe_store<FpParams>(p, a.c0);
+    fe_store<FpParams>((char*)p + 48, a.c1);
+}
+template <class F> FF_INLINE Aff<F> aff_load(const void* p) {
+    constexpr int B = FieldOps<F>::WORDS * 4;
+    return {load_f((const F*)nullptr, p), load_f((const F*)nullptr, (const char*)p + B)};
+}
+template <class F> FF_INLINE void aff_store(void* p, const Aff<F>& a) {
+    constexpr int B = FieldOps<F>::WORDS * 4;
+    store_f(p, a.x);
+    store_f((char*)p + B, a.y);
+}
+template <class F> FF_INLINE Xyzz<F> xyzz_load(const void* p) {
+    constexpr int B = FieldOps<F>::WORDS * 4;
+    const char* c = (const char*)p;
+    return {load_f((const F*)nullptr, c), load_f((const F*)nullptr, c + B), load_f((const F*)nullptr, c + 2 * B),
+            load_f((const F*)nullptr, c + 3 * B)};
+}
+template <class F> FF_INLINE void xyzz_store(void* p, const Xyzz<F>& a) {
+    constexpr int B = FieldOps<F>::WORDS * 4;
+    char* c = (char*)p;
+    store_f(c, a.x);
+    store_f(c + B, a.y);
+    store_f(c + 2 * B, a.zz);
+    store_f(c + 3 * B, a.zzz);
+}
+
+}  // namespace zk

@@ -1,0 +1,285 @@
+// BLS12-381 field arithmetic for gfx950 (CDNA4): Montgomery form on 32-bit limbs held in VGPRs.
+//
+// CDNA4 has no 64x64 multiplier; the widest integer multiply-add is v_mad_u64_u32
+// (32x32 + 64 -> 64), so elements are N x u32 (Fr: N = 8, R = 2^256; Fp: N = 12, R = 2^384)
+// and every product row is a chain of v_mad_u64_u32 with the running 32-bit carry folded into
+// the 64-bit addend.  Everything is fully unrolled so limbs never leave registers.
+//
+// Replaces, for the prove path, the Fr / Fq arithmetic the reference obtains from opam
+// bls12-381 (src/lib/zk/curve.ml:121-140 Fr ops; G1/G2 coordinates curve.ml:159-191).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FF_INLINE __device__ __forceinline__
+
+namespace zk {
+
+struct FrParams {
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xffffffffu;  // -r^-1 mod 2^32
+};
+struct FpParams {
+    static constexpr int N = 12;
+    static constexpr uint32_t INV = 0xfffcfffdu;  // -p^-1 mod 2^32
+};
+
+// Constants live in const device arrays; with full unrolling clang folds them to literals.
+__device__ static const uint32_t FR_MOD[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
+                                              0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+__device__ static const uint32_t FR_R1[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                                             0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+__device__ static const uint32_t FR_R2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                                             0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+__device__ static const uint32_t FP_MOD[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu,
+                                               0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u,
+                                               0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+__device__ static const uint32_t FP_R1[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu,
+                                              0x53c758bau, 0x5f489857u, 0x70525745u, 0x77ce5853u,
+                                              0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+__device__ static const uint32_t FP_R2[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u,
+                                              0x4c95b6d5u, 0x8de5476cu, 0x939d83c0u, 0x67eb88a9u,
+                                              0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+
+template <class P> struct Consts;
+template <> struct Consts<FrParams> {
+    static FF_INLINE uint32_t mod(int i) { return FR_MOD[i]; }
+    static FF_INLINE uint32_t r1(int i) { return FR_R1[i]; }
+    static FF_INLINE uint32_t r2(int i) { return FR_R2[i]; }
+};
+template <> struct Consts<FpParams> {
+    static FF_INLINE uint32_t mod(int i) { return FP_MOD[i]; }
+    static FF_INLINE uint32_t r1(int i) { return FP_R1[i]; }
+    static FF_INLINE uint32_t r2(int i) { return FP_R2[i]; }
+};
+
+template <class P> struct Fe {
+    static constexpr int N = P::N;
+    uint32_t v[P::N];
+};
+using Fr = Fe<FrParams>;
+using Fp = Fe<FpParams>;
+
+template <class P> FF_INLINE Fe<P> fe_zero() {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.v[i] = 0;
+    return r;
+}
+template <class P> FF_INLINE Fe<P> fe_one() {
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r.v[i] = Consts<P>::r1(i);
+    return r;
+}
+template <class P> FF_INLINE bool fe_is_zero(const Fe<P>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) o |= a.v[i];
+    return o == 0;
+}
+template <class P> FF_INLINE bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+
+// r = a - mod if a >= mod (a < 2*mod)
+template <class P> FF_INLINE void fe_cond_sub(Fe<P>& a) {
+    uint32_t t[P::N];
+    uint64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        uint64_t d = (uint64_t)a.v[i] - Consts<P>::mod(i) - bw;
+        t[i] = (uint32_t)d;
+        bw = (d >> 32) & 1;
+    }
+    if (!bw) {
+#pragma unroll
+        for (int i = 0; i < P::N; i++) a.v[i] = t[i];
+    }
+}
+template <class P> FF_INLINE Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    // moduli are < 2^(32N-1): no carry out of the top limb
+    fe_cond_sub(r);
+    return r;
+}
+template <class P> FF_INLINE Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    uint64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        uint64_t d = (uint64_t)a.v[i] - b.v[i] - bw;
+        r.v[i] = (uint32_t)d;
+        bw = (d >> 32) & 1;
+    }
+    uint32_t mask = (uint32_t)0 - (uint32_t)bw;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        c += (uint64_t)r.v[i] + (Consts<P>::mod(i) & mask);
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+template <class P> FF_INLINE Fe<P> fe_neg(const Fe<P>& a) {
+    if (fe_is_zero(a)) return a;
+    Fe<P> r;
+    uint64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        uint64_t d = (uint64_t)Consts<P>::mod(i) - a.v[i] - bw;
+        r.v[i] = (uint32_t)d;
+        bw = (d >> 32) & 1;
+    }
+    return r;
+}
+template <class P> FF_INLINE Fe<P> fe_dbl(const Fe<P>& a) { return fe_add(a, a); }
+
+// Montgomery product a*b*R^-1 mod p, CIOS, fully reduced.
+template <class P> FF_INLINE Fe<P> fe_mul_inline(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int N = P::N;
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            c = (uint64_t)a.v[j] * b.v[i] + t[j] + c;   // < 2^64: (2^32-1)^2 + 2(2^32-1)
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        uint32_t tn = t[N] + (uint32_t)c;   // fits: the running value stays < 2p*2^32
+        uint32_t m = t[0] * P::INV;
+        c = (uint64_t)m * Consts<P>::mod(0) + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            c = (uint64_t)m * Consts<P>::mod(j) + t[j] + c;
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += tn;
+        t[N - 1] = (uint32_t)c;
+        t[N] = (uint32_t)(c >> 32);
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    fe_cond_sub(r);
+    return r;
+}
+// The 12-limb product is ~1.3k instructions: as a real function (operands and result travel in
+// VGPRs under the AMDGPU calling convention) every kernel shares one copy -- the hot loops stay
+// inside the instruction cache and the library compiles in minutes instead of an hour.
+__device__ __noinline__ static Fe<FpParams> fp_mul_call(Fe<FpParams> a, Fe<FpParams> b) { return fe_mul_inline(a, b); }
+template <class P> FF_INLINE Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    if constexpr (P::N == 12) return fp_mul_call(a, b);
+    else return fe_mul_inline(a, b);
+}
+template <class P> FF_INLINE Fe<P> fe_sqr(const Fe<P>& a) { return fe_mul(a, a); }
+
+template <class P> FF_INLINE Fe<P> fe_to_mont(const Fe<P>& a) {
+    Fe<P> r2;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) r2.v[i] = Consts<P>::r2(i);
+    return fe_mul(a, r2);
+}
+template <class P> FF_INLINE Fe<P> fe_from_mont(const Fe<P>& a) {
+    Fe<P> one = fe_zero<P>();
+    one.v[0] = 1;
+    return fe_mul(a, one);
+}
+// canonical a < mod ?
+template <class P> FF_INLINE bool fe_is_canonical(const Fe<P>& a) {
+    uint64_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        uint64_t d = (uint64_t)a.v[i] - Consts<P>::mod(i) - bw;
+        bw = (d >> 32) & 1;
+    }
+    return bw != 0;
+}
+// a^(mod-2) by square-and-multiply over the constant exponent (not unrolled: code size).
+template <class P> __device__ __noinline__ Fe<P> fe_inv(const Fe<P>& a) {
+    Fe<P> acc = fe_one<P>();
+    Fe<P> base = a;
+    uint32_t borrow = 2;   // exponent = mod - 2, limb by limb
+    for (int l = 0; l < P::N; l++) {
+        uint32_t m = Consts<P>::mod(l);
+        uint32_t w = m - borrow;
+        borrow = (m < borrow) ? 1u : 0u;
+        for (int i = 0; i < 32; i++) {
+            if ((w >> i) & 1) acc = fe_mul(acc, base);
+            base = fe_sqr(base);
+        }
+    }
+    return acc;
+}
+template <class P> FF_INLINE Fe<P> fe_from_u32(uint32_t x) {
+    Fe<P> r = fe_zero<P>();
+    r.v[0] = x;
+    return fe_to_mont(r);
+}
+
+// 128-bit vector loads / stores of whole elements (32 B Fr = 2 x dwordx4, 48 B Fp = 3 x dwordx4).
+template <class P> FF_INLINE Fe<P> fe_load(const void* p) {
+    Fe<P> r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < P::N / 4; i++) {
+        uint4 x = q[i];
+        r.v[4 * i] = x.x; r.v[4 * i + 1] = x.y; r.v[4 * i + 2] = x.z; r.v[4 * i + 3] = x.w;
+    }
+    return r;
+}
+template <class P> FF_INLINE void fe_store(void* p, const Fe<P>& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < P::N / 4; i++) q[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+}
+
+// ------------------------------------------------------------------ Fp2 = Fp[u]/(u^2 + 1)
+struct Fp2 {
+    Fp c0, c1;
+};
+FF_INLINE Fp2 fp2_zero() { return {fe_zero<FpParams>(), fe_zero<FpParams>()}; }
+FF_INLINE Fp2 fp2_one() { return {fe_one<FpParams>(), fe_zero<FpParams>()}; }
+FF_INLINE bool fe_is_zero(const Fp2& a) { return fe_is_zero(a.c0) && fe_is_zero(a.c1); }
+FF_INLINE bool fe_eq(const Fp2& a, const Fp2& b) { return fe_eq(a.c0, b.c0) && fe_eq(a.c1, b.c1); }
+FF_INLINE Fp2 fe_add(const Fp2& a, const Fp2& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
+FF_INLINE Fp2 fe_sub(const Fp2& a, const Fp2& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
+FF_INLINE Fp2 fe_neg(const Fp2& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+FF_INLINE Fp2 fe_dbl(const Fp2& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
+// Karatsuba: 3 base multiplications
+FF_INLINE Fp2 fe_mul(const Fp2& a, const Fp2& b) {
+    Fp t0 = fe_mul(a.c0, b.c0);
+    Fp t1 = fe_mul(a.c1, b.c1);
+    Fp s = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
+    return {fe_sub(t0, t1), fe_sub(fe_sub(s, t0), t1)};
+}
+// (a0 + a1 u)^2 = (a0+a1)(a0-a1) + 2 a0 a1 u : 2 base multiplications
+FF_INLINE Fp2 fe_sqr(const Fp2& a) {
+    Fp p = fe_mul(fe_add(a.c0, a.c1), fe_sub(a.c0, a.c1));
+    Fp q = fe_mul(a.c0, a.c1);
+    return {p, fe_dbl(q)};
+}
+__device__ __noinline__ inline Fp2 fe_inv(const Fp2& a) {
+    Fp n = fe_add(fe_sqr(a.c0), fe_sqr(a.c1));
+    Fp d = fe_inv(n);
+    return {fe_mul(a.c0, d), fe_neg(fe_mul(a.c1, d))};
+}
+
+}  // namespace zk

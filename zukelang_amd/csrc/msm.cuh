@@ -1,0 +1,52 @@
+// Pippenger multi-scalar multiplication for BLS12-381 G1 / G2 on gfx950 -- internal interface.
+#pragma once
+#include "zk_common.h"
+
+namespace zk {
+
+enum Curve { CURVE_G1 = 0, CURVE_G2 = 1 };
+
+static inline size_t aff_bytes(Curve c) { return c == CURVE_G1 ? 96 : 192; }
+static inline size_t xyzz_bytes(Curve c) { return c == CURVE_G1 ? 192 : 384; }
+
+// Signed-digit window layout: nw = floor(255 / c) + 1 windows of c bits (the top window absorbs
+// the last carry: scalars are < r < 2^255), digits in [-2^(c-1), 2^(c-1)], buckets 1..2^(c-1).
+static inline uint32_t msm_windows(uint32_t c) { return 255 / c + 1; }
+
+struct MsmBases {
+    Curve curve = CURVE_G1;
+    uint64_t n = 0;          // points
+    uint32_t c = 0;          // window bits
+    uint32_t nw = 0;         // windows
+    bool precomp = false;    // table holds 2^(c*j) * P_i for j < nw at [j*n + i]; one bucket set
+    DevBuf table;            // affine Montgomery points
+};
+
+struct MsmWorkspace {
+    DevBuf counts, offsets, cursor, sorted, buckets, head, tail, red, wsum;
+    uint64_t cap_points = 0;
+    uint32_t c = 0, nw = 0;
+    bool precomp = false;
+    Curve curve = CURVE_G1;
+    uint32_t nbuckets = 0;      // total bucket slots (windows * 2^(c-1) in classic mode)
+    uint32_t chunk = 0;         // sorted entries per accumulate thread
+    uint64_t nthreads = 0;
+};
+
+uint32_t msm_auto_window(uint64_t n, bool precomp);
+int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
+int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
+int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b);
+// d_scalars: n canonical (non-Montgomery) Fr, 32 B each, on device.  d_result: one XYZZ point.
+int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_result_xyzz, hipStream_t s);
+// XYZZ (device) -> uncompressed bytes (host); count points
+int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s);
+// bytes (device copy of host encoding) -> affine Montgomery; *d_flag |= 1 not on curve, |= 2 bad encoding
+int points_bytes_to_affine(Curve curve, void* d_affine, const void* d_bytes, uint64_t n, int* d_flag, hipStream_t s);
+int points_affine_to_bytes(Curve curve, void* d_bytes, const void* d_affine, uint64_t n, hipStream_t s);
+// out[i] = scalars[i] * G (affine Montgomery on device); scalars canonical on device
+int fixed_base_mul(Curve curve, void* d_affine_out, const void* d_scalars, uint64_t n, hipStream_t s);
+// acc[i] = sum_j parts[j*stride + i] over j < count   (XYZZ, tiny: cross-GPU partial reduction)
+int xyzz_sum_columns(Curve curve, void* d_out, const void* d_parts, uint32_t count, uint32_t npoints, hipStream_t s);
+
+}  // namespace zk

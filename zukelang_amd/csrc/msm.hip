@@ -1,0 +1,666 @@
+// Pippenger multi-scalar multiplication over BLS12-381 G1 / G2 for gfx950.
+//
+// Computes the same group element as the reference's left folds of single scalar
+// multiplications: G.apply_powers (src/lib/zk/curve.ml:112-118), G.dot / sum_map (:91-103).
+//
+// MI355X-first pipeline (all integer work; no MFMA):
+//   1 count    scalars (32 B, coalesced) -> signed c-bit digits -> histogram of bucket ids
+//   2 scan     exclusive prefix sum of the histogram (bucket -> start of its run)
+//   3 scatter  point references (index | sign) written bucket-contiguously: a counting sort
+//   4 accumulate  the sorted run is cut into equal chunks, one per lane: every lane does the same
+//              number of mixed additions XYZZ += affine regardless of the digit distribution
+//              (no per-bucket load imbalance); runs inside a chunk go straight to their bucket,
+//              runs cut by a chunk border go to per-lane head / tail slots
+//   5 fixup    one lane per bucket adds the few border partials of its run
+//   6 reduce   sum_b (b+1) * B_b by per-lane running sums over 2^k-bucket slices + one small
+//              scalar multiple per slice, then a wave-shuffle-free LDS tree per window
+//   7 final    Horner over the windows (classic mode) -> one XYZZ point
+// With `precomp` the base table holds 2^(c*j) * P_i for every window j (HBM is 288 GB: a 2^22
+// Groth16 key costs 32 GB), all windows share ONE bucket set and step 7's 255 serial doublings
+// disappear; this is the mode the resident proving key uses.
+#include "ec.cuh"
+#include "msm.cuh"
+
+#include <string.h>
+
+namespace zk {
+
+// ------------------------------------------------------------------ byte <-> Montgomery conversions
+// 48 B big-endian -> 12 little-endian u32 limbs
+FF_INLINE Fp fp_from_be(const uint8_t* p) {
+    Fp r;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v[i] = __builtin_bswap32(w[11 - i]);
+    return r;
+}
+FF_INLINE void fp_to_be(uint8_t* p, const Fp& a) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[11 - i] = __builtin_bswap32(a.v[i]);
+}
+FF_INLINE bool fp_canonical(const Fp& a) { return fe_is_canonical(a); }
+
+// G1: x | y ; G2: x1 | x0 | y1 | y0  (ZCash uncompressed)
+FF_INLINE int aff_decode(Aff<Fp>& out, const uint8_t* p) {
+    uint8_t flags = p[0];
+    if (flags & 0x80) return 2;                       // compressed encodings are not accepted here
+    if (flags & 0x40) { out = aff_inf<Fp>(); return 0; }
+    Fp x = fp_from_be(p), y = fp_from_be(p + 48);
+    if (!fp_canonical(x) || !fp_canonical(y)) return 2;
+    out = {fe_to_mont(x), fe_to_mont(y)};
+    return 0;
+}
+FF_INLINE int aff_decode(Aff<Fp2>& out, const uint8_t* p) {
+    uint8_t flags = p[0];
+    if (flags & 0x80) return 2;
+    if (flags & 0x40) { out = aff_inf<Fp2>(); return 0; }
+    Fp x1 = fp_from_be(p), x0 = fp_from_be(p + 48), y1 = fp_from_be(p + 96), y0 = fp_from_be(p + 144);
+    if (!fp_canonical(x0) || !fp_canonical(x1) || !fp_canonical(y0) || !fp_canonical(y1)) return 2;
+    out = {{fe_to_mont(x0), fe_to_mont(x1)}, {fe_to_mont(y0), fe_to_mont(y1)}};
+    return 0;
+}
+FF_INLINE void aff_encode(uint8_t* p, const Aff<Fp>& a) {
+    if (aff_is_inf(a)) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(p);
+        for (int i = 0; i < 24; i++) w[i] = 0;
+        p[0] = 0x40;
+        return;
+    }
+    fp_to_be(p, fe_from_mont(a.x));
+    fp_to_be(p + 48, fe_from_mont(a.y));
+}
+FF_INLINE void aff_encode(uint8_t* p, const Aff<Fp2>& a) {
+    if (aff_is_inf(a)) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(p);
+        for (int i = 0; i < 48; i++) w[i] = 0;
+        p[0] = 0x40;
+        return;
+    }
+    fp_to_be(p, fe_from_mont(a.x.c1));
+    fp_to_be(p + 48, fe_from_mont(a.x.c0));
+    fp_to_be(p + 96, fe_from_mont(a.y.c1));
+    fp_to_be(p + 144, fe_from_mont(a.y.c0));
+}
+
+template <class F> __global__ void k_bytes_to_affine(uint8_t* dst, const uint8_t* src, uint64_t n, int* flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int B = FieldOps<F>::WORDS * 8;
+    Aff<F> a;
+    int rc = aff_decode(a, src + B * i);
+    if (rc) { atomicOr(flag, 2); a = aff_inf<F>(); }
+    else if (!aff_on_curve(a)) { atomicOr(flag, 1); a = aff_inf<F>(); }
+    aff_store<F>(dst + B * i, a);
+}
+template <class F> __global__ void k_affine_to_bytes(uint8_t* dst, const uint8_t* src, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int B = FieldOps<F>::WORDS * 8;
+    aff_encode(dst + B * i, aff_load<F>(src + B * i));
+}
+template <class F> __global__ void k_xyzz_to_bytes(uint8_t* dst, const uint8_t* src, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int B = FieldOps<F>::WORDS * 8;
+    aff_encode(dst + B * i, xyzz_to_aff(xyzz_load<F>(src + 2 * B * i)));
+}
+
+// ------------------------------------------------------------------ precomputation: table[j*n + i] = 2^(c*j) * P_i
+template <class F> __global__ void k_precompute(uint8_t* table, uint64_t n, uint32_t c, uint32_t nw) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int B = FieldOps<F>::WORDS * 8;
+    Aff<F> p = aff_load<F>(table + B * i);
+    for (uint32_t j = 1; j < nw; j++) {
+        Xyzz<F> q = xyzz_dbl_aff(p);
+        for (uint32_t k = 1; k < c; k++) q = xyzz_dbl(q);
+        p = xyzz_to_aff(q);
+        aff_store<F>(table + B * ((uint64_t)j * n + i), p);
+    }
+}
+
+// ------------------------------------------------------------------ digits
+struct DigitArgs {
+    uint64_t n;
+    uint32_t c, nw, precomp, nb_per_window;
+};
+// Calls f(key, val) for every non-zero signed digit of scalar i.
+template <class Fn> FF_INLINE void for_each_digit(const uint32_t* __restrict__ scalars, uint64_t i, const DigitArgs& a, Fn f) {
+    const uint32_t* sp = scalars + 8 * i;
+    uint32_t s[8];
+    uint4 lo = reinterpret_cast<const uint4*>(sp)[0], hi = reinterpret_cast<const uint4*>(sp)[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
+    if ((s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) == 0) return;
+    const uint32_t mask = (1u << a.c) - 1, half = 1u << (a.c - 1);
+    uint32_t carry = 0;
+    for (uint32_t j = 0; j < a.nw; j++) {
+        uint32_t off = j * a.c, w = off >> 5, b = off & 31;
+        uint32_t x0 = 0, x1 = 0;
+        // static indexing keeps the scalar in registers
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((int)w == k) x0 = s[k];
+            if ((int)w + 1 == k) x1 = s[k];
+        }
+        uint64_t x = ((uint64_t)x1 << 32) | x0;
+        uint32_t d = (w < 8 ? (uint32_t)(x >> b) & mask : 0u) + carry;
+        uint32_t neg = 0;
+        carry = 0;
+        if (d > half) { d = (1u << a.c) - d; neg = 1; carry = 1; }
+        if (d) {
+            uint32_t key = (a.precomp ? 0u : j * a.nb_per_window) + (d - 1);
+            uint32_t val = (uint32_t)(a.precomp ? (uint64_t)j * a.n + i : i) | (neg << 31);
+            f(key, val);
+        }
+    }
+}
+__global__ void k_msm_count(const uint32_t* __restrict__ scalars, DigitArgs a, uint32_t* __restrict__ counts) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    for_each_digit(scalars, i, a, [&](uint32_t key, uint32_t) { atomicAdd(&counts[key], 1u); });
+}
+__global__ void k_msm_scatter(const uint32_t* __restrict__ scalars, DigitArgs a, uint32_t* __restrict__ cursor,
+                              uint32_t* __restrict__ sorted) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    for_each_digit(scalars, i, a, [&](uint32_t key, uint32_t val) { sorted[atomicAdd(&cursor[key], 1u)] = val; });
+}
+// single workgroup: offsets[k] = sum_{q<k} counts[q], offsets[nb] = total; cursor = offsets
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                               uint32_t* __restrict__ cursor, uint32_t nb) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t lo = t * per, hi = min(lo + per, nb);
+    uint32_t s = 0;
+    for (uint32_t k = lo; k < hi; k++) s += counts[k];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (uint32_t k = lo; k < hi; k++) {
+        offsets[k] = run;
+        cursor[k] = run;
+        run += counts[k];
+    }
+    if (t == 1023) offsets[nb] = part[1023];
+}
+
+// ------------------------------------------------------------------ accumulate
+template <class F>
+__global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restrict__ table, const uint32_t* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ sorted, uint32_t nb, uint32_t chunk,
+                                                        uint8_t* __restrict__ buckets, uint8_t* __restrict__ head,
+                                                        uint8_t* __restrict__ tail) {
+    constexpr int AB = FieldOps<F>::WORDS * 8, XB = FieldOps<F>::WORDS * 16;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t N = offsets[nb];
+    uint64_t start64 = t * chunk;
+    if (start64 >= N) return;
+    uint32_t pos = (uint32_t)start64;
+    const uint32_t end = min(pos + chunk, N);
+    // largest kb with offsets[kb] <= pos (then offsets[kb+1] > pos, so the bucket is non-empty)
+    uint32_t lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= pos) lo = mid; else hi = mid;
+    }
+    uint32_t kb = lo;
+    bool first = true;
+    while (pos < end) {
+        uint32_t bstart = offsets[kb], bend = offsets[kb + 1];
+        if (bend <= pos) { kb++; continue; }           // empty bucket
+        uint32_t seg_end = min(bend, end);
+        Xyzz<F> acc = xyzz_inf<F>();
+        bool complete = (pos == bstart) && (seg_end == bend);
+        for (uint32_t e = pos; e < seg_end; e++) {
+            uint32_t v = sorted[e];
+            Aff<F> p = aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
+            if (v >> 31) p.y = fe_neg(p.y);
+            xyzz_madd(acc, p);
+        }
+        uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
+        xyzz_store<F>(dst, acc);
+        first = false;
+        pos = seg_end;
+        if (pos == bend) kb++;
+    }
+}
+template <class F>
+__global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t chunk,
+                                                   uint8_t* __restrict__ buckets, const uint8_t* __restrict__ head,
+                                                   const uint8_t* __restrict__ tail) {
+    constexpr int XB = FieldOps<F>::WORDS * 16;
+    const uint32_t kb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kb >= nb) return;
+    const uint32_t s = offsets[kb], e = offsets[kb + 1];
+    if (e == s) return;                                 // empty: the bucket array was zero-filled = identity
+    const uint32_t t0 = s / chunk, t1 = (e - 1) / chunk;
+    if (t0 == t1) return;                               // whole run inside one chunk: written directly
+    Xyzz<F> acc = xyzz_load<F>((s == t0 * chunk ? head : tail) + (uint64_t)XB * t0);
+    for (uint32_t t = t0 + 1; t <= t1; t++) {
+        Xyzz<F> q = xyzz_load<F>(head + (uint64_t)XB * t);
+        xyzz_add(acc, q);
+    }
+    xyzz_store<F>(buckets + (uint64_t)XB * kb, acc);
+}
+
+// ------------------------------------------------------------------ bucket reduction: sum_b (b+1) * B_b per window
+// lane: slice of `per` consecutive buckets, running sums from the top, + lo * (slice sum)
+template <class F>
+__global__ __launch_bounds__(128) void k_msm_reduce_slices(const uint8_t* __restrict__ buckets, uint32_t nb_per_window,
+                                                           uint32_t per, uint32_t slices_per_window, uint32_t total_slices,
+                                                           uint8_t* __restrict__ red) {
+    constexpr int XB = FieldOps<F>::WORDS * 16;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_slices) return;
+    const uint32_t w = g / slices_per_window, sl = g % slices_per_window;
+    const uint32_t lo = sl * per, hi = min(lo + per, nb_per_window);
+    const uint8_t* bw = buckets + (uint64_t)XB * w * nb_per_window;
+    Xyzz<F> acc = xyzz_inf<F>(), sum = xyzz_inf<F>();
+    for (uint32_t b = hi; b-- > lo;) {
+        Xyzz<F> q = xyzz_load<F>(bw + (uint64_t)XB * b);
+        xyzz_add(acc, q);
+        xyzz_add(sum, acc);
+    }
+    if (lo) {
+        Xyzz<F> m = xyzz_mul_u32(acc, lo);
+        xyzz_add(sum, m);
+    }
+    xyzz_store<F>(red + (uint64_t)XB * g, sum);
+}
+// one workgroup per window: tree-sum the slice results through LDS
+template <class F>
+__global__ __launch_bounds__(256) void k_msm_window_sum(const uint8_t* __restrict__ red, uint32_t slices_per_window,
+                                                        uint8_t* __restrict__ wsum) {
+    constexpr int XB = FieldOps<F>::WORDS * 16;
+    constexpr int XW = FieldOps<F>::WORDS * 4;
+    __shared__ uint32_t lds[XW][256];                  // limb-major: conflict-free column access
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (uint32_t sl = t; sl < slices_per_window; sl += 256) {
+        Xyzz<F> q = xyzz_load<F>(red + (uint64_t)XB * ((uint64_t)w * slices_per_window + sl));
+        xyzz_add(acc, q);
+    }
+    __attribute__((aligned(16))) uint32_t tmp[XW];
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        __syncthreads();
+        if (t >= d && t < 2 * d) {
+            xyzz_store<F>(tmp, acc);
+#pragma unroll
+            for (int l = 0; l < XW; l++) lds[l][t] = tmp[l];
+        }
+        __syncthreads();
+        if (t < d) {
+#pragma unroll
+            for (int l = 0; l < XW; l++) tmp[l] = lds[l][t + d];
+            Xyzz<F> q = xyzz_load<F>(tmp);
+            xyzz_add(acc, q);
+        }
+    }
+    if (t == 0) xyzz_store<F>(wsum + (uint64_t)XB * w, acc);
+}
+// classic mode: result = sum_j 2^(c*j) * W_j by Horner from the top window (one lane)
+template <class F> __global__ void k_msm_final(const uint8_t* __restrict__ wsum, uint32_t nw, uint32_t c, uint8_t* __restrict__ out) {
+    constexpr int XB = FieldOps<F>::WORDS * 16;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Xyzz<F> acc = xyzz_load<F>(wsum + (uint64_t)XB * (nw - 1));
+    for (uint32_t j = nw - 1; j-- > 0;) {
+        for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
+        Xyzz<F> q = xyzz_load<F>(wsum + (uint64_t)XB * j);
+        xyzz_add(acc, q);
+    }
+    xyzz_store<F>(out, acc);
+}
+template <class F> __global__ void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
+    constexpr int XB = FieldOps<F>::WORDS * 16;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoints) return;
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (uint32_t j = 0; j < count; j++) {
+        Xyzz<F> q = xyzz_load<F>(parts + (uint64_t)XB * ((uint64_t)j * npoints + i));
+        xyzz_add(acc, q);
+    }
+    xyzz_store<F>(out + (uint64_t)XB * i, acc);
+}
+
+// ------------------------------------------------------------------ fixed-base: out[i] = s_i * G
+// pow2[k] = 2^k * G (affine), 256 entries per curve, built once by 256 lanes.
+template <class F> FF_INLINE Aff<F> generator();
+template <> FF_INLINE Aff<Fp> generator<Fp>() {
+    // canonical generator coordinates as little-endian limbs, converted to Montgomery
+    Fp x = {{0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+             0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u}};
+    Fp y = {{0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+             0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u}};
+    return {fe_to_mont(x), fe_to_mont(y)};
+}
+template <> FF_INLINE Aff<Fp2> generator<Fp2>() {
+    Fp x0 = {{0xc121bdb8u, 0xd48056c8u, 0xa805bbefu, 0x0bac0326u, 0x7ae3d177u, 0xb4510b64u,
+              0xfa403b02u, 0xc6e47ad4u, 0x2dc51051u, 0x26080527u, 0xf08f0a91u, 0x024aa2b2u}};
+    Fp x1 = {{0x5d042b7eu, 0xe5ac7d05u, 0x13945d57u, 0x334cf112u, 0xdc7f5049u, 0xb5da61bbu,
+              0x9920b61au, 0x596bd0d0u, 0x88274f65u, 0x7dacd3a0u, 0x52719f60u, 0x13e02b60u}};
+    Fp y0 = {{0x08b82801u, 0xe1935486u, 0x3baca289u, 0x923ac9ccu, 0x5160d12cu, 0x6d429a69u,
+              0x8cbdd3a7u, 0xadfd9baau, 0xda2e351au, 0x8cc9cdc6u, 0x727d6e11u, 0x0ce5d527u}};
+    Fp y1 = {{0xf05f79beu, 0xaaa9075fu, 0x5cec1da1u, 0x3f370d27u, 0x572e99abu, 0x267492abu,
+              0x85a763afu, 0xcb3e287eu, 0x2bc28b99u, 0x32acd2b0u, 0x2ea734ccu, 0x0606c4a0u}};
+    return {{fe_to_mont(x0), fe_to_mont(x1)}, {fe_to_mont(y0), fe_to_mont(y1)}};
+}
+template <class F> __global__ void k_gen_pow2_table(uint8_t* table) {
+    constexpr int AB = FieldOps<F>::WORDS * 8;
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 256) return;
+    Aff<F> g = generator<F>();
+    Xyzz<F> q = xyzz_from_aff(g);
+    for (uint32_t i = 0; i < k; i++) q = xyzz_dbl(q);
+    aff_store<F>(table + AB * k, xyzz_to_aff(q));
+}
+template <class F>
+__global__ __launch_bounds__(128) void k_fixed_base_mul(uint8_t* __restrict__ out, const uint32_t* __restrict__ scalars,
+                                                        uint64_t n, const uint8_t* __restrict__ pow2) {
+    constexpr int AB = FieldOps<F>::WORDS * 8;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (uint32_t w = 0; w < 8; w++) {
+        uint32_t bits = scalars[8 * i + w];
+        while (bits) {
+            uint32_t b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            Aff<F> p = aff_load<F>(pow2 + AB * (32 * w + b));
+            xyzz_madd(acc, p);
+        }
+    }
+    aff_store<F>(out + AB * i, xyzz_to_aff(acc));
+}
+
+// ================================================================== host side
+static inline dim3 grid_for(uint64_t n, unsigned threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
+// buckets per reduce lane: 32 for big windows, fewer when the window is small (keeps >= 256 lanes busy)
+static inline uint32_t reduce_per(uint32_t nbw) {
+    if (nbw >= 32 * 256) return 32;
+    uint32_t per = nbw / 256;
+    return per ? per : 1;
+}
+
+uint32_t msm_auto_window(uint64_t n, bool precomp) {
+    // work ~ nw * n additions + buckets * (2 reduce additions); pick the c minimizing it, capped so the
+    // accumulate pass still has >= ~128k lanes of work
+    double best = 1e300;
+    uint32_t bc = 8;
+    for (uint32_t c = 6; c <= 20; c++) {
+        double nw = msm_windows(c);
+        double buckets = (precomp ? 1.0 : nw) * (double)(1u << (c - 1));
+        double cost = nw * (double)n + 3.0 * buckets;
+        if (cost < best) { best = cost; bc = c; }
+    }
+    return bc;
+}
+
+template <class F> static int bases_finish(MsmBases& b, hipStream_t s) {
+    if (b.precomp && b.nw > 1) {
+        ScopedTimer t("msm_precompute", s);
+        hipLaunchKernelGGL(k_precompute<F>, grid_for(b.n, 64), dim3(64), 0, s, b.table.as<uint8_t>(), b.n, b.c, b.nw);
+        HIPCHK(hipGetLastError());
+    }
+    return ZK_OK;
+}
+static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool precomp) {
+    if (n == 0) ZK_FAIL(ZK_ERR_ARG, "msm: empty base set");
+    if (c == 0) c = msm_auto_window(n, precomp);
+    if (c < 2 || c > 22) ZK_FAIL(ZK_ERR_ARG, "msm: window_bits must be in [2, 22]");
+    b.curve = curve; b.n = n; b.c = c; b.nw = msm_windows(c); b.precomp = precomp;
+    if ((precomp ? (uint64_t)b.nw : 1) * n >= ((uint64_t)1 << 31)) ZK_FAIL(ZK_ERR_ARG, "msm: too many points for 31-bit references");
+    return b.table.alloc(aff_bytes(curve) * n * (precomp ? b.nw : 1));
+}
+int points_bytes_to_affine(Curve curve, void* d_aff, const void* d_bytes, uint64_t n, int* d_flag, hipStream_t s) {
+    if (!n) return ZK_OK;
+    if (curve == CURVE_G1) hipLaunchKernelGGL(k_bytes_to_affine<Fp>, grid_for(n, 128), dim3(128), 0, s, (uint8_t*)d_aff, (const uint8_t*)d_bytes, n, d_flag);
+    else hipLaunchKernelGGL(k_bytes_to_affine<Fp2>, grid_for(n, 128), dim3(128), 0, s, (uint8_t*)d_aff, (const uint8_t*)d_bytes, n, d_flag);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int points_affine_to_bytes(Curve curve, void* d_bytes, const void* d_aff, uint64_t n, hipStream_t s) {
+    if (!n) return ZK_OK;
+    if (curve == CURVE_G1) hipLaunchKernelGGL(k_affine_to_bytes<Fp>, grid_for(n, 128), dim3(128), 0, s, (uint8_t*)d_bytes, (const uint8_t*)d_aff, n);
+    else hipLaunchKernelGGL(k_affine_to_bytes<Fp2>, grid_for(n, 128), dim3(128), 0, s, (uint8_t*)d_bytes, (const uint8_t*)d_aff, n);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s) {
+    DevBuf tmp;
+    ZKCHK(tmp.alloc(aff_bytes(curve) * count));
+    if (curve == CURVE_G1) hipLaunchKernelGGL(k_xyzz_to_bytes<Fp>, grid_for(count, 64), dim3(64), 0, s, tmp.as<uint8_t>(), (const uint8_t*)d_xyzz, count);
+    else hipLaunchKernelGGL(k_xyzz_to_bytes<Fp2>, grid_for(count, 64), dim3(64), 0, s, tmp.as<uint8_t>(), (const uint8_t*)d_xyzz, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_out, tmp.p, aff_bytes(curve) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ZK_OK;
+}
+int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s) {
+    ZKCHK(bases_setup(b, curve, n, c, precomp));
+    HIPCHK(hipMemcpyAsync(b.table.p, d_affine, aff_bytes(curve) * n, hipMemcpyDeviceToDevice, s));
+    return curve == CURVE_G1 ? bases_finish<Fp>(b, s) : bases_finish<Fp2>(b, s);
+}
+int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s) {
+    ZKCHK(bases_setup(b, curve, n, c, precomp));
+    DevBuf raw, flag;
+    ZKCHK(raw.alloc(aff_bytes(curve) * n));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
+    HIPCHK(hipMemcpyAsync(raw.p, host_bytes, aff_bytes(curve) * n, hipMemcpyHostToDevice, s));
+    ZKCHK(points_bytes_to_affine(curve, b.table.p, raw.p, n, flag.as<int>(), s));
+    int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h & 2) ZK_FAIL(ZK_ERR_ARG, "point encoding: compressed flag set or coordinate >= p");
+    if (h & 1) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "a base point is not on the curve");
+    return curve == CURVE_G1 ? bases_finish<Fp>(b, s) : bases_finish<Fp2>(b, s);
+}
+
+int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
+    w.curve = b.curve; w.c = b.c; w.nw = b.nw; w.precomp = b.precomp; w.cap_points = b.n;
+    const uint32_t nbw = 1u << (b.c - 1);
+    w.nbuckets = (b.precomp ? 1 : b.nw) * nbw;
+    const uint64_t maxN = b.n * b.nw;
+    // >= 2 waves per SIMD when there is enough work; chunks of at least 8 entries
+    uint64_t target_threads = 256 * 1024;
+    uint32_t chunk = (uint32_t)((maxN + target_threads - 1) / target_threads);
+    if (chunk < 8) chunk = 8;
+    w.chunk = chunk;
+    w.nthreads = (maxN + chunk - 1) / chunk;
+    const size_t XB = xyzz_bytes(b.curve);
+    ZKCHK(w.counts.alloc(4 * (size_t)(w.nbuckets + 1)));
+    ZKCHK(w.offsets.alloc(4 * (size_t)(w.nbuckets + 1)));
+    ZKCHK(w.cursor.alloc(4 * (size_t)(w.nbuckets + 1)));
+    ZKCHK(w.sorted.alloc(4 * (size_t)maxN));
+    ZKCHK(w.buckets.alloc(XB * w.nbuckets));
+    ZKCHK(w.head.alloc(XB * w.nthreads));
+    ZKCHK(w.tail.alloc(XB * w.nthreads));
+    const uint32_t per = reduce_per(nbw);
+    const uint32_t spw = (nbw + per - 1) / per;
+    ZKCHK(w.red.alloc(XB * (size_t)spw * (b.precomp ? 1 : b.nw)));
+    ZKCHK(w.wsum.alloc(XB * (b.precomp ? 1 : b.nw)));
+    return ZK_OK;
+}
+
+template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
+    const uint32_t nbw = 1u << (b.c - 1);
+    const uint32_t nwin = b.precomp ? 1 : b.nw;
+    DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw};
+    const size_t XB = xyzz_bytes(b.curve);
+    {
+        ScopedTimer t("msm_sort", s);
+        HIPCHK(hipMemsetAsync(w.counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
+        hipLaunchKernelGGL(k_msm_count, grid_for(b.n, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.counts.as<uint32_t>());
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
+        hipLaunchKernelGGL(k_msm_scatter, grid_for(b.n, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.cursor.as<uint32_t>(), w.sorted.as<uint32_t>());
+        HIPCHK(hipMemsetAsync(w.buckets.p, 0, XB * w.nbuckets, s));
+    }
+    {
+        ScopedTimer t(b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2", s);
+        hipLaunchKernelGGL(k_msm_accumulate<F>, grid_for(w.nthreads, 128), dim3(128), 0, s, b.table.as<uint8_t>(), w.offsets.as<uint32_t>(),
+                           w.sorted.as<uint32_t>(), w.nbuckets, w.chunk, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
+    }
+    {
+        ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
+        hipLaunchKernelGGL(k_msm_fixup<F>, grid_for(w.nbuckets, 128), dim3(128), 0, s, w.offsets.as<uint32_t>(), w.nbuckets, w.chunk,
+                           w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
+        const uint32_t per = reduce_per(nbw);
+        const uint32_t spw = (nbw + per - 1) / per;
+        hipLaunchKernelGGL(k_msm_reduce_slices<F>, grid_for((uint64_t)spw * nwin, 128), dim3(128), 0, s, w.buckets.as<uint8_t>(), nbw, per, spw,
+                           spw * nwin, w.red.as<uint8_t>());
+        hipLaunchKernelGGL(k_msm_window_sum<F>, dim3(nwin), dim3(256), 0, s, w.red.as<uint8_t>(), spw, w.wsum.as<uint8_t>());
+        if (nwin > 1) hipLaunchKernelGGL(k_msm_final<F>, dim3(1), dim3(64), 0, s, w.wsum.as<uint8_t>(), nwin, b.c, (uint8_t*)d_out);
+        else HIPCHK(hipMemcpyAsync(d_out, w.wsum.p, XB, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
+    if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.cap_points < b.n) ZK_FAIL(ZK_ERR_ARG, "msm: workspace does not match bases");
+    return b.curve == CURVE_G1 ? msm_run_t<Fp>(b, w, d_scalars, d_out, s) : msm_run_t<Fp2>(b, w, d_scalars, d_out, s);
+}
+int xyzz_sum_columns(Curve curve, void* d_out, const void* d_parts, uint32_t count, uint32_t npoints, hipStream_t s) {
+    if (curve == CURVE_G1) hipLaunchKernelGGL(k_xyzz_sum_columns<Fp>, grid_for(npoints, 64), dim3(64), 0, s, (uint8_t*)d_out, (const uint8_t*)d_parts, count, npoints);
+    else hipLaunchKernelGGL(k_xyzz_sum_columns<Fp2>, grid_for(npoints, 64), dim3(64), 0, s, (uint8_t*)d_out, (const uint8_t*)d_parts, count, npoints);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
+static DevBuf g_pow2[2];
+static void msm_release() { g_pow2[0].release(); g_pow2[1].release(); }
+static CleanupRegistrar g_msm_cleanup(msm_release);
+
+int fixed_base_mul(Curve curve, void* d_out, const void* d_scalars, uint64_t n, hipStream_t s) {
+    DevBuf& tab = g_pow2[curve];
+    if (!tab.p) {
+        ZKCHK(tab.alloc(aff_bytes(curve) * 256));
+        if (curve == CURVE_G1) hipLaunchKernelGGL(k_gen_pow2_table<Fp>, dim3(4), dim3(64), 0, s, tab.as<uint8_t>());
+        else hipLaunchKernelGGL(k_gen_pow2_table<Fp2>, dim3(4), dim3(64), 0, s, tab.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+    }
+    if (!n) return ZK_OK;
+    ScopedTimer t("fixed_base_mul", s);
+    if (curve == CURVE_G1) hipLaunchKernelGGL(k_fixed_base_mul<Fp>, grid_for(n, 128), dim3(128), 0, s, (uint8_t*)d_out, (const uint32_t*)d_scalars, n, tab.as<uint8_t>());
+    else hipLaunchKernelGGL(k_fixed_base_mul<Fp2>, grid_for(n, 128), dim3(128), 0, s, (uint8_t*)d_out, (const uint32_t*)d_scalars, n, tab.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
+// Fr canonical check on device scalars
+__global__ void k_check_scalars(const uint32_t* s, uint64_t n, int* flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr a = fe_load<FrParams>(s + 8 * i);
+    if (!fe_is_canonical(a)) *flag = 1;
+}
+// powers: out[i] = s^i (canonical), sequential products split over lanes by fast exponentiation
+__global__ void k_fr_powers(uint32_t* out, const uint32_t* s_canon, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr base = fe_to_mont(fe_load<FrParams>(s_canon)), acc = fe_one<FrParams>();
+    for (uint64_t e = i; e; e >>= 1) {
+        if (e & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+    }
+    fe_store<FrParams>(out + 8 * i, fe_from_mont(acc));
+}
+
+static int msm_api(Curve curve, const uint8_t* bases, size_t nbases, const uint8_t* scalars, size_t nscalars, uint32_t window_bits, uint8_t* out) {
+    if (!out) ZK_FAIL(ZK_ERR_ARG, "msm: null output");
+    if (nscalars > nbases) ZK_FAIL(ZK_ERR_APPLY_POWERS, "apply_powers");        // curve.ml:116
+    ZKCHK(ensure_init());
+    Ctx& c = ctx();
+    if (nscalars == 0) {                                                        // curve.ml:115: zero
+        memset(out, 0, aff_bytes(curve));
+        out[0] = 0x40;
+        return ZK_OK;
+    }
+    if (!bases || !scalars) ZK_FAIL(ZK_ERR_ARG, "msm: null input");
+    MsmBases b;
+    MsmWorkspace w;
+    ZKCHK(msm_bases_from_bytes(b, curve, bases, nscalars, window_bits, false, c.stream));
+    ZKCHK(msm_workspace_alloc(w, b));
+    DevBuf sc, res, flag;
+    ZKCHK(sc.alloc(32 * nscalars));
+    ZKCHK(res.alloc(xyzz_bytes(curve)));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
+    HIPCHK(hipMemcpyAsync(sc.p, scalars, 32 * nscalars, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(k_check_scalars, grid_for(nscalars, 256), dim3(256), 0, c.stream, sc.as<uint32_t>(), (uint64_t)nscalars, flag.as<int>());
+    ZKCHK(msm_run(b, w, sc.p, res.p, c.stream));
+    int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (h) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "msm: scalar >= r");
+    return points_xyzz_to_bytes(curve, res.p, 1, out, c.stream);
+}
+static int of_fr_api(Curve curve, const uint8_t* scalars, size_t n, uint8_t* out) {
+    if (n && (!scalars || !out)) ZK_FAIL(ZK_ERR_ARG, "of_Fr: null");
+    ZKCHK(ensure_init());
+    if (!n) return ZK_OK;
+    Ctx& c = ctx();
+    DevBuf sc, aff, bytes, flag;
+    ZKCHK(sc.alloc(32 * n));
+    ZKCHK(aff.alloc(aff_bytes(curve) * n));
+    ZKCHK(bytes.alloc(aff_bytes(curve) * n));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
+    HIPCHK(hipMemcpyAsync(sc.p, scalars, 32 * n, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(k_check_scalars, grid_for(n, 256), dim3(256), 0, c.stream, sc.as<uint32_t>(), (uint64_t)n, flag.as<int>());
+    ZKCHK(fixed_base_mul(curve, aff.p, sc.p, n, c.stream));
+    ZKCHK(points_affine_to_bytes(curve, bytes.p, aff.p, n, c.stream));
+    int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(out, bytes.p, aff_bytes(curve) * n, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (h) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "of_Fr: scalar >= r");
+    return ZK_OK;
+}
+static int powers_api(Curve curve, uint32_t d, const uint8_t* s32, uint8_t* out) {
+    if (!s32 || !out) ZK_FAIL(ZK_ERR_ARG, "powers: null");
+    ZKCHK(ensure_init());
+    Ctx& c = ctx();
+    uint64_t n = (uint64_t)d + 1;
+    DevBuf s, sc, aff, bytes, flag;
+    ZKCHK(s.alloc(32));
+    ZKCHK(sc.alloc(32 * n));
+    ZKCHK(aff.alloc(aff_bytes(curve) * n));
+    ZKCHK(bytes.alloc(aff_bytes(curve) * n));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
+    HIPCHK(hipMemcpyAsync(s.p, s32, 32, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(k_check_scalars, dim3(1), dim3(64), 0, c.stream, s.as<uint32_t>(), (uint64_t)1, flag.as<int>());
+    hipLaunchKernelGGL(k_fr_powers, grid_for(n, 256), dim3(256), 0, c.stream, sc.as<uint32_t>(), s.as<uint32_t>(), n);
+    ZKCHK(fixed_base_mul(curve, aff.p, sc.p, n, c.stream));
+    ZKCHK(points_affine_to_bytes(curve, bytes.p, aff.p, n, c.stream));
+    int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(out, bytes.p, aff_bytes(curve) * n, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (h) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "powers: scalar >= r");
+    return ZK_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+extern "C" {
+int zk_msm_g1(const uint8_t* bases, size_t nbases, const uint8_t* scalars, size_t nscalars, uint32_t window_bits, uint8_t out[96]) {
+    return msm_api(CURVE_G1, bases, nbases, scalars, nscalars, window_bits, out);
+}
+int zk_msm_g2(const uint8_t* bases, size_t nbases, const uint8_t* scalars, size_t nscalars, uint32_t window_bits, uint8_t out[192]) {
+    return msm_api(CURVE_G2, bases, nbases, scalars, nscalars, window_bits, out);
+}
+int zk_g1_of_fr(const uint8_t* scalars, size_t n, uint8_t* out) { return of_fr_api(CURVE_G1, scalars, n, out); }
+int zk_g2_of_fr(const uint8_t* scalars, size_t n, uint8_t* out) { return of_fr_api(CURVE_G2, scalars, n, out); }
+int zk_g1_powers(uint32_t d, const uint8_t s[32], uint8_t* out) { return powers_api(CURVE_G1, d, s, out); }
+int zk_g2_powers(uint32_t d, const uint8_t s[32], uint8_t* out) { return powers_api(CURVE_G2, d, s, out); }
+}

@@ -1,0 +1,295 @@
+// Radix-2 NTT over BLS12-381 Fr for gfx950.
+//
+// Value-identical to the reference's FFT.Make(F).gen_fft (src/lib/zk/FFT.ml:29-67) with
+// zeta_N = w^(2^32/N), w = 5^((r-1)/2^32) (FFT.ml:208-232): out[k] = sum_j a_j zeta_N^(jk).
+//
+// MI355X design: the log N butterfly stages are grouped into passes; each pass pulls tiles of
+// 1024 elements (32 KiB) into LDS in limb-major (SoA) layout -- lanes walk consecutive dwords, so
+// ds_read_b32 / ds_write_b32 are conflict-free for every butterfly distance >= 32 and 2-way at
+// worst below -- runs up to 10 stages there, and writes back, so HBM sees ceil(log N / 8..10)
+// round trips instead of log N.  Strided passes fetch rows of C >= 4 consecutive elements
+// (>= 128 contiguous bytes).  Forward = DIF (natural -> bit-reversed), inverse = DIT
+// (bit-reversed -> natural): convolutions never pay a permutation; only the public zk_fr_ntt
+// (natural in/out like FFT.ml) adds one.  Twiddles come from per-level tables (level k holds
+// zeta_{2^k}^j contiguously), which the late, small-stride stages hit in L2.
+#include "ff.cuh"
+#include "zk_common.h"
+
+namespace zk {
+
+static constexpr int NTT_LOG_T = 10;
+static constexpr int NTT_T = 1 << NTT_LOG_T;
+static constexpr int NTT_THREADS = 256;
+
+__device__ static const uint32_t OMEGA_MONT[8] = {0x0c17f47cu, 0x9cab6d5cu, 0xfd4b71e5u, 0x1ce1e93du,
+                                                  0x471dd505u, 0x0d6db230u, 0x743a3b6au, 0x3f0ee990u};
+__device__ static const uint32_t OMEGA_INV_MONT[8] = {0xb3082d19u, 0x55a9e082u, 0xc7dc4a13u, 0x082f90b2u,
+                                                      0xc76b052cu, 0x76ce3accu, 0x6e54185du, 0x15c39d95u};
+
+// tw[2^(k-1) + j] = w_{2^k}^(+-j), j < 2^(k-1), k = 1..K.  Entry 0 unused.
+__global__ void k_gen_twiddles(uint32_t* tw, uint32_t log_k, int inverse) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = (uint64_t)1 << log_k;
+    if (i >= total || i == 0) return;
+    uint32_t k = 64 - __builtin_clzll(i);          // level: 2^(k-1) <= i < 2^k
+    uint32_t j = (uint32_t)(i - ((uint64_t)1 << (k - 1)));
+    // exponent of the 2^32-th root: j * 2^(32-k) < 2^31
+    uint32_t e = j << (32 - k);
+    Fr base, acc = fe_one<FrParams>();
+#pragma unroll
+    for (int l = 0; l < 8; l++) base.v[l] = inverse ? OMEGA_INV_MONT[l] : OMEGA_MONT[l];
+    for (int b = 0; b < 32; b++) {
+        if ((e >> b) & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+    }
+    fe_store<FrParams>(tw + 8 * i, acc);
+}
+
+struct PassArgs {
+    uint32_t log_hi;     // log2 of the largest butterfly span (2 * half) handled by this pass
+    uint32_t s;          // stages in this pass
+    uint32_t log_T;      // log2 tile elements
+    uint32_t log_RS;     // log2 of the LDS distance of one row step
+    uint32_t strided;    // rows come from stride-L global addresses
+};
+
+template <bool INVERSE>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw,
+                                                         PassArgs a, const uint32_t* __restrict__ scale) {
+    __shared__ uint32_t lds[8][NTT_T];
+    const uint32_t T = 1u << a.log_T;
+    const uint32_t log_L = a.log_hi - a.s;
+    const uint32_t RSm = (1u << a.log_RS) - 1;
+    const uint64_t tile = blockIdx.x;
+    uint64_t base;      // global index of tile element 0
+    uint32_t c0 = 0;
+    if (a.strided) {
+        uint32_t log_tiles_per_span = log_L - a.log_RS;                 // L / C
+        uint64_t q = tile >> log_tiles_per_span;
+        c0 = (uint32_t)(tile & ((1u << log_tiles_per_span) - 1)) << a.log_RS;
+        base = (q << a.log_hi) + c0;
+    } else {
+        base = tile << a.log_T;
+    }
+    auto gidx = [&](uint32_t e) -> uint64_t {
+        return a.strided ? base + ((uint64_t)(e >> a.log_RS) << log_L) + (e & RSm) : base + e;
+    };
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x = fe_load<FrParams>(data + 8 * gidx(e));
+#pragma unroll
+        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+    }
+    __syncthreads();
+    for (uint32_t st = 0; st < a.s; st++) {
+        const uint32_t log_hl = INVERSE ? st : a.s - 1 - st;            // local half = 2^log_hl rows
+        const uint32_t log_hs = log_hl + a.log_RS;
+        const uint32_t hs = 1u << log_hs;
+        const uint32_t hlm = (1u << log_hl) - 1;
+        const uint64_t h = (uint64_t)1 << (log_hl + log_L);              // global half-distance
+        for (uint32_t b = threadIdx.x; b < T / 2; b += NTT_THREADS) {
+            uint32_t e = ((b >> log_hs) << (log_hs + 1)) | (b & (hs - 1));
+            uint32_t rho = (e >> a.log_RS) & hlm;
+            uint32_t c = a.strided ? c0 + (e & RSm) : (e & RSm) & ((1u << log_L) - 1);
+            uint64_t j = ((uint64_t)rho << log_L) + c;
+            Fr w = fe_load<FrParams>(tw + 8 * (h + j));
+            Fr u, v;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { u.v[l] = lds[l][e]; v.v[l] = lds[l][e + hs]; }
+            Fr x, y;
+            if (INVERSE) {
+                v = fe_mul(v, w);
+                x = fe_add(u, v);
+                y = fe_sub(u, v);
+            } else {
+                x = fe_add(u, v);
+                y = fe_mul(fe_sub(u, v), w);
+            }
+#pragma unroll
+            for (int l = 0; l < 8; l++) { lds[l][e] = x.v[l]; lds[l][e + hs] = y.v[l]; }
+        }
+        __syncthreads();
+    }
+    Fr sc;
+    if (scale) sc = fe_load<FrParams>(scale);
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
+        if (scale) x = fe_mul(x, sc);
+        fe_store<FrParams>(data + 8 * gidx(e), x);
+    }
+}
+
+__global__ void k_fr_bitrev(uint32_t* data, uint64_t total, uint32_t log_len) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || log_len == 0) return;
+    uint64_t seg = i >> log_len, k = i & (((uint64_t)1 << log_len) - 1);
+    uint64_t r = __brevll(k) >> (64 - log_len);
+    if (k < r) {
+        uint32_t* p = data + 8 * i;
+        uint32_t* q = data + 8 * ((seg << log_len) + r);
+        Fr a = fe_load<FrParams>(p), b = fe_load<FrParams>(q);
+        fe_store<FrParams>(p, b);
+        fe_store<FrParams>(q, a);
+    }
+}
+__global__ void k_fr_to_mont(uint32_t* dst, const uint32_t* src, uint64_t n, int* flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr a = fe_load<FrParams>(src + 8 * i);
+    if (flag && !fe_is_canonical(a)) *flag = 1;
+    fe_store<FrParams>(dst + 8 * i, fe_to_mont(a));
+}
+__global__ void k_fr_from_mont(uint32_t* dst, const uint32_t* src, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store<FrParams>(dst + 8 * i, fe_from_mont(fe_load<FrParams>(src + 8 * i)));
+}
+__global__ void k_fr_pointwise_mul(uint32_t* out, const uint32_t* a, const uint32_t* b, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store<FrParams>(out + 8 * i, fe_mul(fe_load<FrParams>(a + 8 * i), fe_load<FrParams>(b + 8 * i)));
+}
+// 2^-k in Montgomery form for k = 0..32, filled once
+__global__ void k_gen_inv_pow2(uint32_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Fr half = fe_inv(fe_from_u32<FrParams>(2));
+    Fr acc = fe_one<FrParams>();
+    for (int k = 0; k <= 32; k++) {
+        fe_store<FrParams>(out + 8 * k, acc);
+        acc = fe_mul(acc, half);
+    }
+}
+
+static DevBuf g_tw_fwd, g_tw_inv, g_inv_pow2;
+
+int ntt_ensure_twiddles(uint32_t log_n) {
+    Ctx& c = ctx();
+    if (log_n > 30) ZK_FAIL(ZK_ERR_ARG, "NTT size above 2^30 is not supported");
+    if (!g_inv_pow2.p) {
+        ZKCHK(g_inv_pow2.alloc(33 * 32));
+        hipLaunchKernelGGL(k_gen_inv_pow2, dim3(1), dim3(64), 0, c.stream, g_inv_pow2.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+    }
+    if (c.tw_log >= log_n && c.tw_fwd) return ZK_OK;
+    uint32_t k = log_n < 12 ? 12 : log_n;
+    HIPCHK(hipStreamSynchronize(c.stream));
+    ZKCHK(g_tw_fwd.alloc(((size_t)32) << k));
+    ZKCHK(g_tw_inv.alloc(((size_t)32) << k));
+    uint64_t total = (uint64_t)1 << k;
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipLaunchKernelGGL(k_gen_twiddles, grid, dim3(256), 0, c.stream, g_tw_fwd.as<uint32_t>(), k, 0);
+    hipLaunchKernelGGL(k_gen_twiddles, grid, dim3(256), 0, c.stream, g_tw_inv.as<uint32_t>(), k, 1);
+    HIPCHK(hipGetLastError());
+    c.tw_fwd = g_tw_fwd.p;
+    c.tw_inv = g_tw_inv.p;
+    c.tw_log = k;
+    return ZK_OK;
+}
+static void ntt_release() {
+    g_tw_fwd.release(); g_tw_inv.release(); g_inv_pow2.release();
+    ctx().tw_fwd = ctx().tw_inv = nullptr; ctx().tw_log = 0;
+}
+static CleanupRegistrar g_ntt_cleanup(ntt_release);
+
+// Pass plan: the contiguous pass takes the s_last smallest strides, strided passes the rest.
+static void plan(uint32_t log_len, uint32_t log_T, std::vector<PassArgs>& strided, PassArgs& last) {
+    uint32_t s_last = log_len < log_T ? log_len : log_T;
+    last = PassArgs{s_last, s_last, log_T, 0, 0};
+    uint32_t rem = log_len - s_last;
+    if (rem == 0) return;
+    const uint32_t smax = log_T - 2;                 // rows of C >= 4 elements
+    uint32_t np = (rem + smax - 1) / smax;
+    uint32_t hi = log_len;
+    for (uint32_t p = 0; p < np; p++) {
+        uint32_t s = (rem + (np - p) - 1) / (np - p);
+        strided.push_back(PassArgs{hi, s, log_T, log_T - s, 1});
+        hi -= s;
+        rem -= s;
+    }
+}
+
+static int run_ntt(void* d, uint64_t total, uint32_t log_len, bool inverse, bool scale, hipStream_t s) {
+    if (log_len == 0) return ZK_OK;
+    if (total == 0 || (total & (total - 1)) || ((uint64_t)1 << log_len) > total) ZK_FAIL(ZK_ERR_ARG, "ntt: bad sizes");
+    ZKCHK(ntt_ensure_twiddles(log_len));
+    Ctx& c = ctx();
+    uint32_t log_total = ceil_log2(total);
+    uint32_t log_T = log_total < (uint32_t)NTT_LOG_T ? log_total : NTT_LOG_T;
+    std::vector<PassArgs> st;
+    PassArgs last;
+    plan(log_len, log_T, st, last);
+    dim3 grid((unsigned)(total >> log_T));
+    const uint32_t* sc = scale ? g_inv_pow2.as<uint32_t>() + 8 * log_len : nullptr;
+    ScopedTimer t(inverse ? "ntt_inverse" : "ntt_forward", s);
+    if (!inverse) {
+        for (auto& p : st)
+            hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_fwd, p, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_fwd, last, (const uint32_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_inv, last, st.empty() ? sc : (const uint32_t*)nullptr);
+        for (size_t i = st.size(); i-- > 0;)
+            hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_inv, st[i], i == 0 ? sc : (const uint32_t*)nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int ntt_forward(void* d, uint64_t total, uint32_t log_len, hipStream_t s) { return run_ntt(d, total, log_len, false, false, s); }
+int ntt_inverse(void* d, uint64_t total, uint32_t log_len, bool scale, hipStream_t s) { return run_ntt(d, total, log_len, true, scale, s); }
+
+static inline dim3 grid1d(uint64_t n) { return dim3((unsigned)((n + 255) / 256)); }
+int fr_bitrev_permute(void* d, uint64_t total, uint32_t log_len, hipStream_t s) {
+    hipLaunchKernelGGL(k_fr_bitrev, grid1d(total), dim3(256), 0, s, (uint32_t*)d, total, log_len);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int fr_to_mont(void* dst, const void* src, uint64_t n, int* flag, hipStream_t s) {
+    if (!n) return ZK_OK;
+    hipLaunchKernelGGL(k_fr_to_mont, grid1d(n), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n, flag);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int fr_from_mont(void* dst, const void* src, uint64_t n, hipStream_t s) {
+    if (!n) return ZK_OK;
+    hipLaunchKernelGGL(k_fr_from_mont, grid1d(n), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int fr_pointwise_mul(void* out, const void* a, const void* b, uint64_t n, hipStream_t s) {
+    if (!n) return ZK_OK;
+    hipLaunchKernelGGL(k_fr_pointwise_mul, grid1d(n), dim3(256), 0, s, (uint32_t*)out, (const uint32_t*)a, (const uint32_t*)b, n);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" int zk_fr_ntt(uint8_t* inout, uint32_t log_n, int inverse) {
+    if (!inout) ZK_FAIL(ZK_ERR_ARG, "zk_fr_ntt: null buffer");
+    if (log_n > 28) ZK_FAIL(ZK_ERR_ARG, "zk_fr_ntt: log_n > 28");   // FFT.ml:230 raises above 2^32
+    ZKCHK(ensure_init());
+    Ctx& c = ctx();
+    uint64_t n = (uint64_t)1 << log_n;
+    DevBuf d, flag;
+    ZKCHK(d.alloc(n * 32));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
+    HIPCHK(hipMemcpyAsync(d.p, inout, n * 32, hipMemcpyHostToDevice, c.stream));
+    ZKCHK(fr_to_mont(d.p, d.p, n, flag.as<int>(), c.stream));
+    if (!inverse) {
+        ZKCHK(ntt_forward(d.p, n, log_n, c.stream));
+        ZKCHK(fr_bitrev_permute(d.p, n, log_n, c.stream));
+    } else {
+        ZKCHK(fr_bitrev_permute(d.p, n, log_n, c.stream));
+        ZKCHK(ntt_inverse(d.p, n, log_n, true, c.stream));
+    }
+    ZKCHK(fr_from_mont(d.p, d.p, n, c.stream));
+    int h_flag = 0;
+    HIPCHK(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (h_flag) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "zk_fr_ntt: input element >= r");
+    HIPCHK(hipMemcpy(inout, d.p, n * 32, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}

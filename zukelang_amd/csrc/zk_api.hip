@@ -1,0 +1,236 @@
+// Context, errors, profiling hooks and byte-level helpers of libzkmi355x.so.
+#include "ff.cuh"
+#include "zk_common.h"
+
+#include <string.h>
+
+namespace zk {
+
+Ctx& ctx() {
+    static Ctx c;
+    return c;
+}
+int set_error(int code, const char* what, const char* file, int line) {
+    char buf[512];
+    const char* base = strrchr(file, '/');
+    snprintf(buf, sizeof buf, "%s (%s:%d)", what ? what : "", base ? base + 1 : file, line);
+    ctx().last_error = buf;
+    return code;
+}
+std::vector<void (*)()>& cleanup_hooks() {
+    static std::vector<void (*)()> h;
+    return h;
+}
+int ensure_init() {
+    if (ctx().inited) return ZK_OK;
+    return zk_init(0);
+}
+
+ScopedTimer::ScopedTimer(const char* name, hipStream_t stream) : s(stream) {
+    Ctx& c = ctx();
+    if (!c.profiling) return;
+    for (size_t i = 0; i < c.timers.size(); i++)
+        if (c.timers[i].name == name) idx = (int)i;
+    if (idx < 0) {
+        c.timers.push_back(KernelTimer{name, {}});
+        idx = (int)c.timers.size() - 1;
+    }
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+}
+ScopedTimer::~ScopedTimer() {
+    if (idx < 0) return;
+    (void)hipEventRecord(b, s);
+    ctx().timers[idx].spans.push_back({a, b});
+}
+
+// one multiplication chain per lane; all 256 CUs x 8 waves/SIMD busy
+template <class P> __global__ void k_bench_mul(uint32_t* out, uint32_t iters) {
+    Fe<P> x, y;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) {
+        x.v[i] = Consts<P>::r1(i) ^ (threadIdx.x * 2654435761u >> (i & 7));
+        y.v[i] = Consts<P>::r2(i) + blockIdx.x;
+    }
+    x.v[P::N - 1] &= 0x0fffffffu;
+    y.v[P::N - 1] &= 0x0fffffffu;
+    for (uint32_t i = 0; i < iters; i++) {
+        x = fe_mul_inline(x, y);
+        y = fe_mul_inline(y, x);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < P::N; i++) acc ^= x.v[i] ^ y.v[i];
+    if (acc == 0x12345678u) out[0] = acc;   // keep the chain live
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+const char* zk_strerror(int code) {
+    switch (code) {
+        case ZK_OK: return "ok";
+        case ZK_ERR_ARG: return "invalid argument";
+        case ZK_ERR_NOT_ON_CURVE: return "point not on curve";
+        case ZK_ERR_SCALAR_RANGE: return "field element not canonical (>= modulus)";
+        case ZK_ERR_REMAINDER: return "witness does not satisfy the circuit: p mod Z != 0 (QAP.ml:134)";
+        case ZK_ERR_HIP: return "HIP runtime error";
+        case ZK_ERR_APPLY_POWERS: return "apply_powers: fewer points than coefficients (curve.ml:116)";
+        case ZK_ERR_HANDLE: return "unknown handle";
+        case ZK_ERR_DOMAIN: return "domain mismatch (curve.ml:96-100)";
+        default: return "unknown error";
+    }
+}
+const char* zk_last_error(void) { return ctx().last_error.c_str(); }
+
+int zk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int zk_init(int device) {
+    Ctx& c = ctx();
+    if (c.inited) {
+        if (c.device == device) return ZK_OK;
+        ZK_FAIL(ZK_ERR_ARG, "zk_init: already bound to another device (one process drives one GPU)");
+    }
+    int n = zk_device_count();
+    if (n <= 0) ZK_FAIL(ZK_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback");
+    if (device < 0 || device >= n) ZK_FAIL(ZK_ERR_ARG, "zk_init: device index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+    c.device = device;
+    c.inited = true;
+    return ZK_OK;
+}
+
+int zk_shutdown(void) {
+    Ctx& c = ctx();
+    if (!c.inited) return ZK_OK;
+    (void)hipDeviceSynchronize();
+    for (auto f : zk::cleanup_hooks()) f();
+    zk_profile_reset();
+    (void)hipEventDestroy(c.ev_fork);
+    (void)hipEventDestroy(c.ev_join);
+    (void)hipStreamDestroy(c.stream);
+    (void)hipStreamDestroy(c.stream2);
+    c.inited = false;
+    c.device = -1;
+    return ZK_OK;
+}
+
+int zk_sync(void) {
+    Ctx& c = ctx();
+    if (!c.inited) return ZK_OK;
+    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream2));
+    return ZK_OK;
+}
+
+int zk_profile_enable(int on) {
+    ctx().profiling = on != 0;
+    return ZK_OK;
+}
+int zk_profile_reset(void) {
+    Ctx& c = ctx();
+    for (auto& t : c.timers)
+        for (auto& sp : t.spans) {
+            (void)hipEventDestroy(sp.first);
+            (void)hipEventDestroy(sp.second);
+        }
+    c.timers.clear();
+    return ZK_OK;
+}
+int zk_profile_get(const char* family, double* total_ms, uint64_t* launches) {
+    Ctx& c = ctx();
+    ZKCHK(zk_sync());
+    double tot = 0;
+    uint64_t cnt = 0;
+    for (auto& t : c.timers) {
+        if (t.name != family) continue;
+        for (auto& sp : t.spans) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, sp.first, sp.second));
+            tot += ms;
+            cnt++;
+        }
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = cnt;
+    return ZK_OK;
+}
+int zk_profile_names(char* buf, size_t buflen) {
+    std::string s;
+    for (auto& t : ctx().timers) {
+        if (!s.empty()) s += ",";
+        s += t.name;
+    }
+    if (!buf || buflen <= s.size()) ZK_FAIL(ZK_ERR_ARG, "zk_profile_names: buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return ZK_OK;
+}
+
+int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s) {
+    ZKCHK(ensure_init());
+    Ctx& c = ctx();
+    DevBuf out;
+    ZKCHK(out.alloc(64));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    const unsigned blocks = 256 * 8, threads = 256;
+    for (int rep = 0; rep < 2; rep++) {
+        HIPCHK(hipEventRecord(a, c.stream));
+        if (kind == 0) hipLaunchKernelGGL(k_bench_mul<FrParams>, dim3(blocks), dim3(threads), 0, c.stream, out.as<uint32_t>(), iters);
+        else hipLaunchKernelGGL(k_bench_mul<FpParams>, dim3(blocks), dim3(threads), 0, c.stream, out.as<uint32_t>(), iters);
+        HIPCHK(hipEventRecord(b, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    }
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (gmul_per_s) *gmul_per_s = 2.0 * iters * blocks * threads / (ms * 1e-3) / 1e9;
+    return ZK_OK;
+}
+
+// ---- to_compressed_bytes (curve.ml:199,208) from the uncompressed canonical encoding: pure byte logic
+static const uint8_t P_MINUS1_HALF_BE[48] = {
+    0x0d, 0x00, 0x88, 0xf5, 0x1c, 0xbf, 0xf3, 0x4d, 0x25, 0x8d, 0xd3, 0xdb, 0x21, 0xa5, 0xd6, 0x6b,
+    0xb2, 0x3b, 0xa5, 0xc2, 0x79, 0xc2, 0x89, 0x5f, 0xb3, 0x98, 0x69, 0x50, 0x7b, 0x58, 0x7b, 0x12,
+    0x0f, 0x55, 0xff, 0xff, 0x58, 0xa9, 0xff, 0xff, 0xdc, 0xff, 0x7f, 0xff, 0xff, 0xff, 0xd5, 0x55};
+static int be48_gt_half(const uint8_t* y) { return memcmp(y, P_MINUS1_HALF_BE, 48) > 0; }
+static int be48_is_zero(const uint8_t* y) {
+    uint8_t o = 0;
+    for (int i = 0; i < 48; i++) o |= y[i];
+    return o == 0;
+}
+int zk_g1_compress(const uint8_t in[96], uint8_t out[48]) {
+    if (!in || !out) ZK_FAIL(ZK_ERR_ARG, "zk_g1_compress: null");
+    if (in[0] & 0x40) { memset(out, 0, 48); out[0] = 0xC0; return ZK_OK; }
+    memcpy(out, in, 48);
+    out[0] |= 0x80;
+    if (be48_gt_half(in + 48)) out[0] |= 0x20;
+    return ZK_OK;
+}
+int zk_g2_compress(const uint8_t in[192], uint8_t out[96]) {
+    if (!in || !out) ZK_FAIL(ZK_ERR_ARG, "zk_g2_compress: null");
+    if (in[0] & 0x40) { memset(out, 0, 96); out[0] = 0xC0; return ZK_OK; }
+    memcpy(out, in, 96);
+    out[0] |= 0x80;
+    const uint8_t* y1 = in + 96;
+    const uint8_t* y0 = in + 144;
+    int larger = be48_is_zero(y1) ? be48_gt_half(y0) : be48_gt_half(y1);
+    if (larger) out[0] |= 0x20;
+    return ZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// Host-side plumbing shared by the translation units of libzkmi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/zkmi355x.h"
+
+namespace zk {
+
+struct KernelTimer {      // HIP-event timing of one named kernel family, live inside the library
+    std::string name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+};
+
+struct Ctx {
+    bool inited = false;
+    int device = -1;
+    hipStream_t stream = nullptr;      // main stream (G1 work, Fr stage)
+    hipStream_t stream2 = nullptr;     // second stream (G2 MSM overlaps the G1 MSMs)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // twiddles: heap layout, level k (NTT size 2^k) at offset 2^(k-1); fwd = w^j, inv = w^-j
+    void* tw_fwd = nullptr;
+    void* tw_inv = nullptr;
+    uint32_t tw_log = 0;
+    bool profiling = false;
+    std::vector<KernelTimer> timers;
+    std::string last_error;
+};
+Ctx& ctx();
+int set_error(int code, const char* what, const char* file, int line);
+int ensure_init();
+std::vector<void (*)()>& cleanup_hooks();   // run by zk_shutdown before the streams die
+struct CleanupRegistrar { explicit CleanupRegistrar(void (*f)()) { cleanup_hooks().push_back(f); } };
+
+#define ZK_FAIL(code, what) return ::zk::set_error((code), (what), __FILE__, __LINE__)
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) return ::zk::set_error(ZK_ERR_HIP, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define ZKCHK(expr)                 \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != ZK_OK) return _rc; \
+    } while (0)
+
+// RAII device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; return set_error(ZK_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
+        bytes = n;
+        return ZK_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Scoped kernel-family timer (no-op unless profiling is on)
+struct ScopedTimer {
+    int idx = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    ScopedTimer(const char* name, hipStream_t stream);
+    ~ScopedTimer();
+};
+
+static inline uint32_t ceil_log2(uint64_t x) {
+    uint32_t l = 0;
+    while (((uint64_t)1 << l) < x) l++;
+    return l;
+}
+
+// ---- ntt.hip
+int ntt_ensure_twiddles(uint32_t log_n);
+// In-place radix-2 stages over `total` Montgomery Fr elements viewed as independent contiguous
+// segments of 2^log_len: forward = DIF (natural -> bit-reversed), inverse = DIT (bit-reversed ->
+// natural), inverse scaled by 2^-log_len when `scale` is set.
+int ntt_forward(void* d_data, uint64_t total, uint32_t log_len, hipStream_t s);
+int ntt_inverse(void* d_data, uint64_t total, uint32_t log_len, bool scale, hipStream_t s);
+int fr_bitrev_permute(void* d_data, uint64_t total, uint32_t log_len, hipStream_t s);
+int fr_to_mont(void* d_dst, const void* d_src, uint64_t n, int* d_flag_noncanonical, hipStream_t s);
+int fr_from_mont(void* d_dst, const void* d_src, uint64_t n, hipStream_t s);
+int fr_pointwise_mul(void* d_out, const void* d_a, const void* d_b, uint64_t n, hipStream_t s);
+
+}  // namespace zk
