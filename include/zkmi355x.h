@@ -114,18 +114,21 @@ int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], c
 int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out);
 
 /* ---- point-sharded multi-GPU prove --------------------------------------------
- * Rank `rank` of `world` uploads the same key but keeps only its contiguous slice of every base
- * vector; zk_groth16_prove_partial returns that rank's five partial sums (A, B1, H, L in G1 and
- * B in G2) as raw XYZZ Montgomery limbs (4*48 B each for G1, 4*96 B for G2 = 1152 B total) for the
- * host to all-gather; zk_groth16_combine adds `world` partial blocks and finishes the proof. */
-#define ZK_GROTH16_PARTIAL_BYTES 1152
+ * One process per GPU.  Rank `rank` of `world` uploads the same key but keeps only its contiguous
+ * slice of the two base pools (g1: a | d1 | b1 | ti1 | tiztd | ltd_mid, g2: b2 | d2 | ti2); the Fr
+ * stage is replicated.  zk_groth16_prove_partial returns the rank's partial sums of the three
+ * multi-scalar products as raw XYZZ Montgomery limbs: A | C (G1, 4*48 B each) | B (G2, 4*96 B).
+ * EC addition is not a reduction operator of RCCL, so the host all-gathers the `world` blocks as
+ * bytes (torch.distributed / ncclAllGather over xGMI) and zk_groth16_combine adds them on the
+ * GPU and emits the proof.  The sum is exact: the proof bytes do not depend on `world`. */
+#define ZK_GROTH16_PARTIAL_BYTES 768
 int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                                  const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
                                  const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world,
                                  uint64_t* handle);
-int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]);
-int zk_groth16_combine(uint64_t handle, const uint8_t* partials, uint32_t world, const uint8_t r[32],
-                       const uint8_t s[32], uint8_t proof[384]);
+int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
+                             uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]);
+int zk_groth16_combine(const uint8_t* partials /* world * 768 */, uint32_t world, uint8_t proof[384]);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------
  * With profiling on, kernel families are bracketed by HIP events on the stream they run on;

@@ -182,7 +182,7 @@ class QAP:
 
     def groth16_setup(self, toxic, mid):
         n, m = self.n, self.m
-        nmid = int(sum(mid)); nio = m - nmid
+        nmid = int(np.asarray(mid, dtype=np.int64).sum()); nio = m - nmid
         pk1 = _buf(96 * (3 + (n + 2) + max(n - 1, 0) + nmid)); pk2 = _buf(192 * (2 + n + 2))
         vk1 = _buf(96 * (1 + nio)); vk2 = _buf(192 * 3)
         lib.orc_groth16_setup(self.h, _b(toxic), _b(bytes(mid)), pk1, pk2, vk1, vk2)
@@ -201,7 +201,7 @@ def groth16_prove_trapdoor(n, m, L, R, O, mid, sol, toxic, r, s):
 
 
 def groth16_setup_exponents(n, m, L, R, O, mid, toxic, want_io=True):
-    nmid = int(sum(mid)); nio = m - nmid
+    nmid = int(np.asarray(mid, dtype=np.int64).sum()); nio = m - nmid
     e1 = _buf(32 * (3 + (n + 2) + max(n - 1, 0) + nmid)); e2 = _buf(32 * (2 + n + 2))
     eio = _buf(32 * max(nio, 1))
     lib.orc_groth16_setup_exponents(n, m, *L.args(), *R.args(), *O.args(), _b(bytes(mid)), _b(toxic), e1, e2, eio if want_io else None)

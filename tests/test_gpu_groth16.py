@@ -1,0 +1,144 @@
+"""GPU parity: Groth16.prove on the MI355X == the oracle's restatement of groth16.ml:116-161 /
+QAP.ml:120-135 (bit-exact on the uncompressed proof encodings), plus `verify = true` via the
+oracle pairing (the reference's own acceptance test, src/lib/test/test.ml:178)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import r1cs as RC
+from zukelang_amd.curve import G1, G2
+from zukelang_amd.groth16 import Groth16, PKey
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_circuit.json")
+
+
+def frs(xs):
+    return b"".join(P.fr_to_bytes(x) for x in xs)
+
+
+def csrs(cs):
+    return [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+
+
+def seeded_rng(seed):
+    st = P.fr_stream(seed)
+    return lambda: next(st)
+
+
+def pairing_verify(cs, w, pk, vk, proof):
+    """groth16.ml:163-173 with the oracle's pairing."""
+    A, B, Cc = P.g1_from_bytes(proof.a), P.g2_from_bytes(proof.b), P.g1_from_bytes(proof.c)
+    alpha1, beta2 = P.g1_from_bytes(bytes(pk.g1[:96])), P.g2_from_bytes(bytes(pk.g2[:192]))
+    gm, dl = P.g2_from_bytes(vk.gm), P.g2_from_bytes(vk.d)
+    io = [k for k in range(cs.m) if not cs.mid[k]]
+    acc = None
+    for j, k in enumerate(io):
+        acc = P.pt_add(acc, P.pt_mul(P.g1_from_bytes(bytes(vk.ltgm_io[96 * j:96 * j + 96])), w[k]))
+    return P.pairing_product_is_one([(A, B), (P.pt_neg(alpha1), beta2), (P.pt_neg(acc), gm), (P.pt_neg(Cc), dl)])
+
+
+def test_readme_circuit_matches_literal_reference_algorithm():
+    d = json.load(open(GOLDEN))
+    for case in d["cases"]:
+        cs, w = RC.readme_circuit(case["x"])
+        q = O.QAP(cs.n, cs.m, *csrs(cs))
+        rng = seeded_rng(0x5EED0002)
+        toxic = [rng() for _ in range(5)]
+        r, s = rng(), rng()
+        opk1, opk2, ovk1, ovk2 = q.groth16_setup(frs(toxic), cs.mid)
+        # keygen on the GPU reproduces the oracle's setup byte for byte
+        it = iter(toxic)
+        pk, vk = Groth16.keygen(lambda: next(it), cs)
+        assert bytes(pk.g1) == opk1 and bytes(pk.g2) == opk2
+        assert vk.one1 + bytes(vk.ltgm_io) == ovk1 and vk.one2 + vk.gm + vk.d == ovk2
+        prover = Groth16(cs, pk)
+        v, ww, h = prover.qap_eval(w)
+        assert [hex(x) for x in P.poly_normalize(RC.fr_ints(h))] == case["h"]
+        assert [hex(x) for x in P.poly_normalize(RC.fr_ints(v))] == case["v"]
+        assert [hex(x) for x in P.poly_normalize(RC.fr_ints(ww))] == case["w"]
+        proof = prover.prove_rs(w, r, s)
+        rc, a, b, c = q.groth16_prove(opk1, opk2, cs.mid, frs(w), P.fr_to_bytes(r), P.fr_to_bytes(s), 1)   # literal
+        assert rc == 0
+        assert (proof.a, proof.b, proof.c) == (a, b, c)
+        assert proof.to_compressed() == O.g1_compress(a) + O.g2_compress(b) + O.g1_compress(c)
+        assert pairing_verify(cs, w, pk, vk, proof)
+        prover.close()
+
+
+@pytest.mark.parametrize("n", [2, 4, 6, 10, 16, 30, 64, 100, 256, 1000, 1024, 2048])
+def test_iterated_cubic_matches_oracle(n):
+    cs, w = RC.iterated_cubic(n, 0xC0FFEE + n)
+    q = O.QAP(cs.n, cs.m, *csrs(cs))
+    rng = seeded_rng(0x5EED0002 + n)
+    toxic = [rng() for _ in range(5)]
+    r, s = rng(), rng()
+    it = iter(toxic)
+    pk, vk = Groth16.keygen(lambda: next(it), cs)
+    prover = Groth16(cs, pk)
+    # Fr stage: v, w, h equal QAP.eval's coefficient lists
+    rc, p_ref, h_ref = q.eval(frs(w))
+    assert rc == 0
+    v_ref, w_ref, _ = q.eval_vwy(frs(w))
+    v, ww, h = prover.qap_eval(w)
+    assert bytes(v) == v_ref and bytes(ww) == w_ref
+    assert bytes(h)[:len(h_ref)] == h_ref and not any(bytes(h)[len(h_ref):])
+    proof = prover.prove_rs(w, r, s)
+    ta, tb, tc = O.groth16_prove_trapdoor(cs.n, cs.m, *csrs(cs), cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    assert (proof.a, proof.b, proof.c) == (ta, tb, tc)
+    if n <= 64:
+        opk1, opk2, _, _ = q.groth16_setup(frs(toxic), cs.mid)
+        assert bytes(pk.g1) == opk1 and bytes(pk.g2) == opk2
+        rc, a, b, c = q.groth16_prove(opk1, opk2, cs.mid, frs(w), P.fr_to_bytes(r), P.fr_to_bytes(s), 1 if n <= 16 else 0)
+        assert rc == 0 and (proof.a, proof.b, proof.c) == (a, b, c)
+    if n in (2, 6, 100):
+        assert pairing_verify(cs, w, pk, vk, proof)
+    # the same key proves a second witness (no state leaks between proofs)
+    cs2, w2 = RC.iterated_cubic(n, 12345)
+    proof2 = prover.prove_rs(w2, s, r)
+    t2 = O.groth16_prove_trapdoor(cs.n, cs.m, *csrs(cs), cs.mid, frs(w2), frs(toxic), P.fr_to_bytes(s), P.fr_to_bytes(r))
+    assert (proof2.a, proof2.b, proof2.c) == t2
+    prover.close()
+
+
+def test_unsatisfied_witness_raises_like_the_reference():
+    cs, w = RC.iterated_cubic(16, 99)
+    rng = seeded_rng(5)
+    pk, _ = Groth16.keygen(rng, cs)
+    prover = Groth16(cs, pk)
+    w[7] = (w[7] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        prover.prove(rng, w)                       # QAP.ml:134
+    with pytest.raises(AssertionError):
+        prover.prove(rng, w[:-1])                  # missing variable: var.ml:75-77
+    prover.close()
+
+
+@pytest.mark.parametrize("log_n", [16, 18])
+def test_full_size_trapdoor_and_verify(log_n):
+    """BASELINE configs 2 (2^16) and up: expected proof bytes from the trapdoor evaluation (exact at
+    any n), and the pairing check."""
+    n = 1 << log_n
+    cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0001)))
+    rng = seeded_rng(0x5EED0002)
+    toxic = [rng() for _ in range(5)]
+    r, s = rng(), rng()
+    L, R_, Oo = csrs(cs)
+    e1, e2, eio = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
+    pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
+    # spot-check key points against the oracle's scalar multiplication
+    for i in (0, 3, n // 2, len(e1) // 32 - 1):
+        assert bytes(pk.g1[96 * i:96 * i + 96]) == O.g1_mul(O.g1_generator(), e1[32 * i:32 * i + 32])
+    prover = Groth16(cs, pk)
+    proof = prover.prove_rs(w, r, s)
+    ta, tb, tc = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    assert (proof.a, proof.b, proof.c) == (ta, tb, tc)
+    from zukelang_amd.groth16 import VKey
+    vk = VKey(O.g1_generator(), G1.of_Fr(eio), O.g2_generator(), O.g2_mul(O.g2_generator(), P.fr_to_bytes(toxic[2])),
+              O.g2_mul(O.g2_generator(), P.fr_to_bytes(toxic[3])))
+    assert pairing_verify(cs, w, pk, vk, proof)
+    prover.close()

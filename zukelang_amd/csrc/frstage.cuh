@@ -1,0 +1,35 @@
+// Fr stage of the prover: QAP.eval (src/lib/zk/QAP.ml:120-135) for sparse R1CS on the GPU.
+#pragma once
+#include "zk_common.h"
+
+namespace zk {
+
+struct CsrDev {
+    DevBuf ptr, col, val;   // val in Montgomery form
+    uint64_t nnz = 0;
+};
+
+struct FrStage {
+    uint32_t n = 0, m = 0;
+    uint32_t n2 = 0, log_n2 = 0;     // next power of two >= n : size of the basis-conversion tree
+    uint32_t S = 0, log_S = 0;       // 2 * n2 : NTT size of the convolutions
+    CsrDev L, R, O;
+    DevBuf invfact;                   // 1/i!, i < n2
+    DevBuf e_ntt;                     // NTT_S of (-1)^j / j!, bit-reversed order
+    DevBuf pntt;                      // log_n2 levels x n2: NTT_len(P_{s,len/2}) / len per node
+    DevBuf iz_ntt;                    // NTT_S of (rev Z)^-1 mod x^(n-1)
+    DevBuf z;                         // Z coefficients, n + 1 (Montgomery)
+    // per-proof scratch
+    DevBuf wit, abc, d, tmp, bufA, bufB, h, flag;
+};
+
+int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, hipStream_t s);
+// witness: m canonical Fr on device.  Leaves v = f.d[0..n), w = f.d[n2..n2+n), h = f.h[0..n-1) in
+// Montgomery form; *f.flag |= 1 when some gate is violated (QAP.ml:134), |= 2 when a witness
+// value is not canonical.
+int frstage_eval(FrStage& f, const void* d_witness_canonical, hipStream_t s);
+
+// a*b via NTT on device (Montgomery in/out); out must hold na+nb-1 elements
+int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, void* d_out, hipStream_t s);
+
+}  // namespace zk

@@ -1,0 +1,478 @@
+// Fr stage of the prover on gfx950: the GPU counterpart of QAP.eval (src/lib/zk/QAP.ml:120-135)
+// for circuits given as sparse R1CS rows.
+//
+// The reference interpolates over the INTEGER points X = 0..n-1 (QAP.ml:84,92), so the
+// coefficient vectors it feeds to apply_powers are those of the unique polynomials with
+//   v(i) = (L w)_i,  w(i) = (R w)_i,  y(i) = (O w)_i,   h = (v*w - y) / Z,  Z = prod (X - i).
+// An NTT over roots of unity is not the interpolation map of that domain; here it is only the
+// multiplication engine (as in the reference's own FFT.polynomial_mul, FFT.ml:98-105):
+//   1 spmv      a = L w, b = R w, c = O w; remainder = 0 <=> a_i*b_i = c_i for all i (deg rem < n)
+//   2 newton    values -> Newton (falling-factorial) coefficients by ONE convolution:
+//               d_k = sum_{i<=k} (y_i / i!) * ((-1)^(k-i) / (k-i)!)
+//   3 tree      Newton -> monomial, bottom-up over the subproduct tree of prod (X - i):
+//               F(node) = F(left) + P_left(X) * F(right); P_left is precomputed per n in the NTT
+//               domain, so a level is {pad, NTT, pointwise, iNTT, add} -- fused into one LDS-resident
+//               kernel for node sizes <= 1024
+//   4 product   top half of v*w (y has degree < n: it never reaches h)
+//   5 divide    rev(h) = rev(v*w) * (rev Z)^-1 mod X^(n-1); the power-series inverse is per-n
+// All exact arithmetic in Fr: the resulting v, w, h equal the reference's coefficient lists.
+#include "frstage.cuh"
+#include "ntt_lds.cuh"
+
+namespace zk {
+
+static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
+#define FRP(buf) ((buf).template as<uint32_t>())
+
+// ------------------------------------------------------------------ kernels
+__global__ void k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ val,
+                       const uint32_t* __restrict__ w, uint32_t* __restrict__ out, uint32_t n) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    Fr acc = fe_zero<FrParams>();
+    for (uint32_t e = ptr[g]; e < ptr[g + 1]; e++)
+        acc = fe_add(acc, fe_mul(fe_load<FrParams>(val + 8 * (uint64_t)e), fe_load<FrParams>(w + 8 * (uint64_t)col[e])));
+    fe_store<FrParams>(out + 8 * (uint64_t)g, acc);
+}
+__global__ void k_check_r1cs(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t n, int* flag) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    Fr p = fe_mul(fe_load<FrParams>(a + 8 * (uint64_t)g), fe_load<FrParams>(b + 8 * (uint64_t)g));
+    if (!fe_eq(p, fe_load<FrParams>(c + 8 * (uint64_t)g))) atomicOr(flag, 1);
+}
+// witness -> Montgomery; bit 1 of *flag reports a value >= r
+__global__ void k_fr_to_mont_flag2(uint32_t* dst, const uint32_t* src, uint64_t n, int* flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr a = fe_load<FrParams>(src + 8 * i);
+    if (!fe_is_canonical(a)) atomicOr(flag, 2);
+    fe_store<FrParams>(dst + 8 * i, fe_to_mont(a));
+}
+// out[i] = i < n_in ? in[i] * (tab ? tab[i] : 1) : 0      for i < total
+__global__ void k_scale_pad(uint32_t* out, const uint32_t* in, const uint32_t* tab, uint64_t n_in, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    Fr x = fe_zero<FrParams>();
+    if (i < n_in) {
+        x = fe_load<FrParams>(in + 8 * i);
+        if (tab) x = fe_mul(x, fe_load<FrParams>(tab + 8 * i));
+    }
+    fe_store<FrParams>(out + 8 * i, x);
+}
+// data[i] *= tab[i & mask]
+__global__ void k_mul_tab(uint32_t* data, const uint32_t* tab, uint64_t total, uint64_t mask) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    fe_store<FrParams>(data + 8 * i, fe_mul(fe_load<FrParams>(data + 8 * i), fe_load<FrParams>(tab + 8 * (i & mask))));
+}
+// tree level, unfused form: scratch = hi half of every node, zero padded to the node length
+__global__ void k_tree_prep(uint32_t* scratch, const uint32_t* d, uint32_t log_len, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint64_t half = (uint64_t)1 << (log_len - 1), j = i & ((half << 1) - 1);
+    Fr x = fe_zero<FrParams>();
+    if (j < half) x = fe_load<FrParams>(d + 8 * (i + half));
+    fe_store<FrParams>(scratch + 8 * i, x);
+}
+__global__ void k_tree_combine(uint32_t* d, const uint32_t* scratch, uint32_t log_len, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint64_t half = (uint64_t)1 << (log_len - 1), j = i & ((half << 1) - 1);
+    Fr x = fe_load<FrParams>(scratch + 8 * i);
+    if (j < half) x = fe_add(x, fe_load<FrParams>(d + 8 * i));
+    fe_store<FrParams>(d + 8 * i, x);
+}
+// tree level fused in LDS (node length 2^log_len <= tile): d[node] <- lo + P_left * hi
+__global__ __launch_bounds__(NTT_THREADS) void k_tree_level_fused(uint32_t* __restrict__ d, const uint32_t* __restrict__ pntt,
+                                                                 const uint32_t* __restrict__ tw_fwd, const uint32_t* __restrict__ tw_inv,
+                                                                 uint32_t log_len, uint32_t log_T, uint64_t tab_mask) {
+    __shared__ uint32_t lds[8][NTT_T];
+    const uint32_t T = 1u << log_T;
+    const uint64_t base = (uint64_t)blockIdx.x << log_T;
+    const uint32_t half = 1u << (log_len - 1), lm = (half << 1) - 1;
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x = fe_zero<FrParams>();
+        if ((e & lm) < half) x = fe_load<FrParams>(d + 8 * (base + e + half));
+#pragma unroll
+        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+    }
+    __syncthreads();
+    lds_ntt_stages<false>(lds, tw_fwd, T, log_len, 0, 0, 0, false);
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
+        x = fe_mul(x, fe_load<FrParams>(pntt + 8 * ((base + e) & tab_mask)));
+#pragma unroll
+        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+    }
+    __syncthreads();
+    lds_ntt_stages<true>(lds, tw_inv, T, log_len, 0, 0, 0, false);
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
+        if ((e & lm) < half) x = fe_add(x, fe_load<FrParams>(d + 8 * (base + e)));
+        fe_store<FrParams>(d + 8 * (base + e), x);
+    }
+}
+// out[k] = k < cnt ? in[top - k] : 0    (reversal of a coefficient window, zero padded)
+__global__ void k_reverse_pad(uint32_t* out, const uint32_t* in, uint64_t top, uint64_t cnt, uint64_t total) {
+    uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    Fr x = fe_zero<FrParams>();
+    if (k < cnt) x = fe_load<FrParams>(in + 8 * (top - k));
+    fe_store<FrParams>(out + 8 * k, x);
+}
+
+// ---- per-n tables
+// chunk products for the factorial scan: prod[c] = product of max(i,1) over chunk c
+static constexpr uint32_t FCH = 256;
+__global__ void k_fact_chunk_prod(uint32_t* prod, uint32_t n2) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * FCH >= n2) return;
+    Fr acc = fe_one<FrParams>();
+    for (uint32_t i = c * FCH; i < min((c + 1) * FCH, n2); i++)
+        if (i) acc = fe_mul(acc, fe_from_u32<FrParams>(i));
+    fe_store<FrParams>(prod + 8 * c, acc);
+}
+__global__ void k_fact_chunk_scan(uint32_t* prod, uint32_t nchunks) {   // exclusive prefix products, one lane
+    if (blockIdx.x || threadIdx.x) return;
+    Fr run = fe_one<FrParams>();
+    for (uint32_t c = 0; c < nchunks; c++) {
+        Fr p = fe_load<FrParams>(prod + 8 * c);
+        fe_store<FrParams>(prod + 8 * c, run);
+        run = fe_mul(run, p);
+    }
+}
+// invfact[i] = 1/i!; alt[i] = (-1)^i / i!
+__global__ void k_invfact(uint32_t* invfact, uint32_t* alt, const uint32_t* prefix, uint32_t n2) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * FCH >= n2) return;
+    uint32_t lo = c * FCH, hi = min((c + 1) * FCH, n2);
+    Fr f = fe_load<FrParams>(prefix + 8 * c);             // (lo-1)!  (1 for c = 0)
+    for (uint32_t i = lo; i < hi; i++)
+        if (i) f = fe_mul(f, fe_from_u32<FrParams>(i));
+    Fr inv = fe_inv(f);                                    // 1/(hi-1)!
+    for (uint32_t i = hi; i-- > lo;) {
+        fe_store<FrParams>(invfact + 8 * i, inv);
+        fe_store<FrParams>(alt + 8 * i, (i & 1) ? fe_neg(inv) : inv);
+        if (i) inv = fe_mul(inv, fe_from_u32<FrParams>(i));
+    }
+}
+// leaves of the subproduct tree: q0[s] = -s   (Q_{0,s} = X - s, leading 1 implicit)
+__global__ void k_tree_leaves(uint32_t* q, uint32_t n2) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n2) return;
+    fe_store<FrParams>(q + 8 * s, fe_neg(fe_from_u32<FrParams>(s)));
+}
+// scratch[node*2len + j] = j < len ? q[node*len + j] : (j == len ? 1 : 0)    (monic, padded to 2 len)
+__global__ void k_tree_expand(uint32_t* scratch, const uint32_t* q, uint32_t log_len, uint64_t total2) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total2) return;
+    uint64_t len = (uint64_t)1 << log_len, node = i >> (log_len + 1), j = i & ((len << 1) - 1);
+    Fr x = fe_zero<FrParams>();
+    if (j < len) x = fe_load<FrParams>(q + 8 * (node * len + j));
+    else if (j == len) x = fe_one<FrParams>();
+    fe_store<FrParams>(scratch + 8 * i, x);
+}
+// from N = NTT_{2len}(Q nodes): pntt_next[parent*2len + j] = N[left][j] * scale;  prod[parent*2len + j] = N[left][j]*N[right][j]
+__global__ void k_tree_pair(uint32_t* pntt_next, uint32_t* prod, const uint32_t* N, const uint32_t* scale, uint32_t log_len2, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint64_t len2 = (uint64_t)1 << log_len2, parent = i >> log_len2, j = i & (len2 - 1);
+    Fr l = fe_load<FrParams>(N + 8 * ((2 * parent) * len2 + j));
+    Fr r = fe_load<FrParams>(N + 8 * ((2 * parent + 1) * len2 + j));
+    fe_store<FrParams>(pntt_next + 8 * i, fe_mul(l, fe_load<FrParams>(scale)));
+    fe_store<FrParams>(prod + 8 * i, fe_mul(l, r));
+}
+// cyclic wrap of the monic leading term: q[parent*len2 + 0] -= 1
+__global__ void k_tree_unwrap(uint32_t* q, uint32_t log_len2, uint64_t nodes) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nodes) return;
+    uint32_t* a = q + 8 * (p << log_len2);
+    fe_store<FrParams>(a, fe_sub(fe_load<FrParams>(a), fe_one<FrParams>()));
+}
+__global__ void k_set_one(uint32_t* p) {
+    if (blockIdx.x || threadIdx.x) return;
+    fe_store<FrParams>(p, fe_one<FrParams>());
+}
+// t = 2 - t  (power-series Newton step), first cnt entries
+__global__ void k_two_minus(uint32_t* t, uint64_t cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    Fr x = fe_neg(fe_load<FrParams>(t + 8 * i));
+    if (i == 0) x = fe_add(x, fe_from_u32<FrParams>(2));
+    fe_store<FrParams>(t + 8 * i, x);
+}
+__global__ void k_inv_pow2_of(uint32_t* out, uint32_t k) {   // 2^-k
+    if (blockIdx.x || threadIdx.x) return;
+    Fr half = fe_inv(fe_from_u32<FrParams>(2)), acc = fe_one<FrParams>();
+    for (uint32_t i = 0; i < k; i++) acc = fe_mul(acc, half);
+    fe_store<FrParams>(out, acc);
+}
+
+// ------------------------------------------------------------------ host helpers
+int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, void* d_out, hipStream_t s) {
+    if (!na || !nb) return ZK_OK;
+    uint64_t nout = na + nb - 1;
+    uint32_t lg = ceil_log2(nout);
+    uint64_t S = (uint64_t)1 << lg;
+    DevBuf A, B;
+    ZKCHK(A.alloc(32 * S));
+    ZKCHK(B.alloc(32 * S));
+    hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(A), (const uint32_t*)d_a, (const uint32_t*)nullptr, na, S);
+    hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(B), (const uint32_t*)d_b, (const uint32_t*)nullptr, nb, S);
+    ZKCHK(ntt_forward(A.p, S, lg, s));
+    ZKCHK(ntt_forward(B.p, S, lg, s));
+    ZKCHK(fr_pointwise_mul(A.p, A.p, B.p, S, s));
+    ZKCHK(ntt_inverse(A.p, S, lg, true, s));
+    HIPCHK(hipMemcpyAsync(d_out, A.p, 32 * nout, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // A, B are freed on return
+    return ZK_OK;
+}
+
+static int upload_csr(CsrDev& d, const zk_csr* h, uint32_t n, uint32_t m, hipStream_t s) {
+    if (!h || !h->row_ptr) ZK_FAIL(ZK_ERR_ARG, "R1CS matrix: null row_ptr");
+    uint64_t nnz = h->row_ptr[n];
+    for (uint32_t g = 0; g < n; g++)
+        if (h->row_ptr[g] > h->row_ptr[g + 1]) ZK_FAIL(ZK_ERR_ARG, "R1CS matrix: row_ptr not monotone");
+    if (nnz && (!h->col || !h->val)) ZK_FAIL(ZK_ERR_ARG, "R1CS matrix: null col/val");
+    for (uint64_t e = 0; e < nnz; e++)
+        if (h->col[e] >= m) ZK_FAIL(ZK_ERR_ARG, "R1CS matrix: column index out of range");
+    d.nnz = nnz;
+    ZKCHK(d.ptr.alloc(4 * (size_t)(n + 1)));
+    ZKCHK(d.col.alloc(4 * (size_t)(nnz ? nnz : 1)));
+    ZKCHK(d.val.alloc(32 * (size_t)(nnz ? nnz : 1)));
+    HIPCHK(hipMemcpyAsync(d.ptr.p, h->row_ptr, 4 * (size_t)(n + 1), hipMemcpyHostToDevice, s));
+    if (nnz) {
+        HIPCHK(hipMemcpyAsync(d.col.p, h->col, 4 * nnz, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d.val.p, h->val, 32 * nnz, hipMemcpyHostToDevice, s));
+        DevBuf flag;
+        ZKCHK(flag.alloc(4));
+        HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
+        ZKCHK(fr_to_mont(d.val.p, d.val.p, nnz, flag.as<int>(), s));
+        int hf = 0;
+        HIPCHK(hipMemcpyAsync(&hf, flag.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (hf) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "R1CS coefficient >= r");
+    }
+    return ZK_OK;
+}
+
+// Newton -> monomial for `batch` vectors of n2 coefficients stored back to back in d (in place).
+static int tree_convert(FrStage& f, void* d, uint32_t batch, uint32_t levels, void* tmp, hipStream_t s) {
+    Ctx& c = ctx();
+    const uint64_t total = (uint64_t)batch * f.n2;
+    const uint32_t log_total = ceil_log2(total);
+    const uint32_t log_T = log_total < (uint32_t)NTT_LOG_T ? log_total : NTT_LOG_T;
+    ZKCHK(ntt_ensure_twiddles(levels));
+    ScopedTimer t("fr_tree", s);
+    for (uint32_t l = 1; l <= levels; l++) {
+        const uint32_t* tab = FRP(f.pntt) + 8 * (uint64_t)(l - 1) * f.n2;
+        if (l <= log_T) {
+            hipLaunchKernelGGL(k_tree_level_fused, dim3((unsigned)(total >> log_T)), dim3(NTT_THREADS), 0, s, (uint32_t*)d, tab,
+                               (const uint32_t*)c.tw_fwd, (const uint32_t*)c.tw_inv, l, log_T, (uint64_t)f.n2 - 1);
+        } else {
+            hipLaunchKernelGGL(k_tree_prep, g1d(total), dim3(256), 0, s, (uint32_t*)tmp, (const uint32_t*)d, l, total);
+            ZKCHK(ntt_forward(tmp, total, l, s));
+            hipLaunchKernelGGL(k_mul_tab, g1d(total), dim3(256), 0, s, (uint32_t*)tmp, tab, total, (uint64_t)f.n2 - 1);
+            ZKCHK(ntt_inverse(tmp, total, l, false, s));
+            hipLaunchKernelGGL(k_tree_combine, g1d(total), dim3(256), 0, s, (uint32_t*)d, (const uint32_t*)tmp, l, total);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
+int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, hipStream_t s) {
+    if (n < 2 || n > (1u << 24)) ZK_FAIL(ZK_ERR_ARG, "constraint count must be in [2, 2^24]");
+    if (m == 0) ZK_FAIL(ZK_ERR_ARG, "no variables");
+    f.n = n; f.m = m;
+    f.log_n2 = ceil_log2(n); f.n2 = 1u << f.log_n2;
+    f.log_S = f.log_n2 + 1; f.S = 1u << f.log_S;
+    ZKCHK(upload_csr(f.L, L, n, m, s));
+    ZKCHK(upload_csr(f.R, R, n, m, s));
+    ZKCHK(upload_csr(f.O, O, n, m, s));
+    ZKCHK(ntt_ensure_twiddles(f.log_S));
+    const uint32_t n2 = f.n2, S = f.S;
+    ZKCHK(f.invfact.alloc(32 * (size_t)n2));
+    ZKCHK(f.e_ntt.alloc(32 * (size_t)S));
+    ZKCHK(f.pntt.alloc(32 * (size_t)n2 * (f.log_n2 ? f.log_n2 : 1)));
+    ZKCHK(f.iz_ntt.alloc(32 * (size_t)S));
+    ZKCHK(f.z.alloc(32 * (size_t)(n + 1)));
+    ZKCHK(f.wit.alloc(32 * (size_t)m));
+    ZKCHK(f.abc.alloc(32 * (size_t)3 * n));
+    ZKCHK(f.d.alloc(32 * (size_t)2 * n2));
+    ZKCHK(f.tmp.alloc(32 * (size_t)2 * n2));
+    ZKCHK(f.bufA.alloc(32 * (size_t)S));
+    ZKCHK(f.bufB.alloc(32 * (size_t)S));
+    ZKCHK(f.h.alloc(32 * (size_t)n));
+    ZKCHK(f.flag.alloc(4));
+
+    // ---- 1/i! and the alternating kernel of the Newton convolution
+    {
+        uint32_t nch = (n2 + FCH - 1) / FCH;
+        DevBuf prod, alt;
+        ZKCHK(prod.alloc(32 * (size_t)nch));
+        ZKCHK(alt.alloc(32 * (size_t)n2));
+        hipLaunchKernelGGL(k_fact_chunk_prod, g1d(nch, 64), dim3(64), 0, s, FRP(prod), n2);
+        hipLaunchKernelGGL(k_fact_chunk_scan, dim3(1), dim3(64), 0, s, FRP(prod), nch);
+        hipLaunchKernelGGL(k_invfact, g1d(nch, 64), dim3(64), 0, s, FRP(f.invfact), FRP(alt), (const uint32_t*)FRP(prod), n2);
+        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.e_ntt), (const uint32_t*)FRP(alt), (const uint32_t*)nullptr, (uint64_t)n2, (uint64_t)S);
+        ZKCHK(ntt_forward(f.e_ntt.p, S, f.log_S, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    // ---- subproduct tree, bottom-up.  q holds Q_{l,node} (low 2^l coefficients, monic), n2 entries per level.
+    {
+        DevBuf q, N, prod, scale;
+        ZKCHK(q.alloc(32 * (size_t)n2));
+        ZKCHK(N.alloc(32 * (size_t)2 * n2));
+        ZKCHK(prod.alloc(32 * (size_t)n2));
+        ZKCHK(scale.alloc(32));
+        hipLaunchKernelGGL(k_tree_leaves, g1d(n2), dim3(256), 0, s, FRP(q), n2);
+        for (uint32_t l = 0; l < f.log_n2; l++) {
+            // N = NTT_{2^(l+1)} of every level-l node (monic, padded): 2*n2 entries
+            hipLaunchKernelGGL(k_tree_expand, g1d(2 * (uint64_t)n2), dim3(256), 0, s, FRP(N), (const uint32_t*)FRP(q), l, 2 * (uint64_t)n2);
+            ZKCHK(ntt_forward(N.p, 2 * (uint64_t)n2, l + 1, s));
+            hipLaunchKernelGGL(k_inv_pow2_of, dim3(1), dim3(64), 0, s, FRP(scale), l + 1);
+            hipLaunchKernelGGL(k_tree_pair, g1d(n2), dim3(256), 0, s, FRP(f.pntt) + 8 * (uint64_t)l * n2, FRP(prod), (const uint32_t*)FRP(N),
+                               (const uint32_t*)FRP(scale), l + 1, (uint64_t)n2);
+            ZKCHK(ntt_inverse(prod.p, n2, l + 1, true, s));
+            hipLaunchKernelGGL(k_tree_unwrap, g1d(n2 >> (l + 1)), dim3(256), 0, s, FRP(prod), l + 1, (uint64_t)(n2 >> (l + 1)));
+            HIPCHK(hipMemcpyAsync(q.p, prod.p, 32 * (size_t)n2, hipMemcpyDeviceToDevice, s));
+        }
+        // ---- Z = prod_{i<n} (X - i)
+        if (n == n2) {
+            HIPCHK(hipMemcpyAsync(f.z.p, q.p, 32 * (size_t)n, hipMemcpyDeviceToDevice, s));   // root product, monic
+            hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, FRP(f.z) + 8 * (uint64_t)n);
+        } else {
+            // Z = X^(n falling) : Newton coordinates e_n, converted through the tree (n < n2)
+            HIPCHK(hipMemsetAsync(f.d.p, 0, 32 * (size_t)n2, s));
+            hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, FRP(f.d) + 8 * (uint64_t)n);
+            ZKCHK(tree_convert(f, f.d.p, 1, f.log_n2, f.tmp.p, s));
+            HIPCHK(hipMemcpyAsync(f.z.p, f.d.p, 32 * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    // ---- (rev Z)^-1 mod X^(n-1) by Newton iteration g <- g (2 - f g), then its NTT_S
+    {
+        const uint64_t need = n - 1;
+        DevBuf fz, g, t1, t2;
+        ZKCHK(fz.alloc(32 * (size_t)(n + 1)));
+        ZKCHK(g.alloc(32 * (size_t)(2 * need + 2)));
+        ZKCHK(t1.alloc(32 * (size_t)(4 * need + 4)));
+        ZKCHK(t2.alloc(32 * (size_t)(4 * need + 4)));
+        hipLaunchKernelGGL(k_reverse_pad, g1d(n + 1), dim3(256), 0, s, FRP(fz), (const uint32_t*)FRP(f.z), (uint64_t)n, (uint64_t)n + 1, (uint64_t)n + 1);
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, FRP(g));   // rev Z has constant term 1
+        uint64_t prec = 1;
+        while (prec < need) {
+            uint64_t p2 = prec * 2 < need ? prec * 2 : need;
+            uint64_t fl = p2 < (uint64_t)n + 1 ? p2 : (uint64_t)n + 1;
+            ZKCHK(dev_poly_mul(fz.p, fl, g.p, prec, t1.p, s));                 // f*g, keep p2 terms
+            uint64_t got = fl + prec - 1;
+            if (got < p2) HIPCHK(hipMemsetAsync((char*)t1.p + 32 * got, 0, 32 * (p2 - got), s));
+            hipLaunchKernelGGL(k_two_minus, g1d(p2), dim3(256), 0, s, FRP(t1), p2);
+            ZKCHK(dev_poly_mul(g.p, prec, t1.p, p2, t2.p, s));                 // g*(2 - f g) mod X^p2
+            HIPCHK(hipMemcpyAsync(g.p, t2.p, 32 * p2, hipMemcpyDeviceToDevice, s));
+            prec = p2;
+        }
+        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.iz_ntt), (const uint32_t*)FRP(g), (const uint32_t*)nullptr, need, (uint64_t)S);
+        ZKCHK(ntt_forward(f.iz_ntt.p, S, f.log_S, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
+int frstage_eval(FrStage& f, const void* d_wit_canon, hipStream_t s) {
+    const uint32_t n = f.n, n2 = f.n2, S = f.S;
+    uint32_t* a = FRP(f.abc);
+    uint32_t* b = a + 8 * (uint64_t)n;
+    uint32_t* cc = b + 8 * (uint64_t)n;
+    HIPCHK(hipMemsetAsync(f.flag.p, 0, 4, s));
+    {
+        ScopedTimer t("fr_spmv", s);
+        // witness -> Montgomery; a non-canonical value sets bit 0 of a scratch flag which we fold into bit 1
+        DevBuf& w = f.wit;
+        hipLaunchKernelGGL(k_fr_to_mont_flag2, g1d(f.m), dim3(256), 0, s, FRP(w), (const uint32_t*)d_wit_canon, (uint64_t)f.m, f.flag.as<int>());
+        hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.L.ptr), (const uint32_t*)FRP(f.L.col), (const uint32_t*)FRP(f.L.val), (const uint32_t*)FRP(w), a, n);
+        hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.R.ptr), (const uint32_t*)FRP(f.R.col), (const uint32_t*)FRP(f.R.val), (const uint32_t*)FRP(w), b, n);
+        hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.O.ptr), (const uint32_t*)FRP(f.O.col), (const uint32_t*)FRP(f.O.val), (const uint32_t*)FRP(w), cc, n);
+        hipLaunchKernelGGL(k_check_r1cs, g1d(n), dim3(256), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)cc, n, f.flag.as<int>());
+    }
+    // ---- values -> Newton coefficients (both vectors), into d[0..n2) and d[n2..2 n2)
+    {
+        ScopedTimer t("fr_newton", s);
+        for (int k = 0; k < 2; k++) {
+            const uint32_t* src = k == 0 ? a : b;
+            hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.bufA), src, (const uint32_t*)FRP(f.invfact), (uint64_t)n, (uint64_t)S);
+            ZKCHK(ntt_forward(f.bufA.p, S, f.log_S, s));
+            ZKCHK(fr_pointwise_mul(f.bufA.p, f.bufA.p, f.e_ntt.p, S, s));
+            ZKCHK(ntt_inverse(f.bufA.p, S, f.log_S, true, s));
+            hipLaunchKernelGGL(k_scale_pad, g1d(n2), dim3(256), 0, s, FRP(f.d) + 8 * (uint64_t)k * n2, (const uint32_t*)FRP(f.bufA), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)n2);
+        }
+    }
+    // ---- Newton -> monomial
+    ZKCHK(tree_convert(f, f.d.p, 2, f.log_n2, f.tmp.p, s));
+    // ---- h
+    {
+        ScopedTimer t("fr_quotient", s);
+        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.bufA), (const uint32_t*)FRP(f.d), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
+        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.bufB), (const uint32_t*)(FRP(f.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
+        ZKCHK(ntt_forward(f.bufA.p, S, f.log_S, s));
+        ZKCHK(ntt_forward(f.bufB.p, S, f.log_S, s));
+        ZKCHK(fr_pointwise_mul(f.bufA.p, f.bufA.p, f.bufB.p, S, s));
+        ZKCHK(ntt_inverse(f.bufA.p, S, f.log_S, true, s));                    // v*w, coefficients 0..2n-2
+        // t[k] = (v w)[2n-2-k], k < n-1
+        hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, FRP(f.bufB), (const uint32_t*)FRP(f.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
+        ZKCHK(ntt_forward(f.bufB.p, S, f.log_S, s));
+        ZKCHK(fr_pointwise_mul(f.bufB.p, f.bufB.p, f.iz_ntt.p, S, s));
+        ZKCHK(ntt_inverse(f.bufB.p, S, f.log_S, true, s));
+        // h[j] = hh[n-2-j], j < n-1
+        hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(f.h), (const uint32_t*)FRP(f.bufB), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" int zk_fr_poly_mul(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, uint8_t* out, size_t* nout) {
+    if (!nout) ZK_FAIL(ZK_ERR_ARG, "zk_fr_poly_mul: null nout");
+    *nout = 0;
+    if (na == 0 || nb == 0) return ZK_OK;                         // mul_scalar / sum of nothing = [] (polynomial.ml:117-131)
+    if (!a || !b || !out) ZK_FAIL(ZK_ERR_ARG, "zk_fr_poly_mul: null buffer");
+    ZKCHK(ensure_init());
+    Ctx& c = ctx();
+    size_t n = na + nb - 1;
+    DevBuf A, B, Oo, flag;
+    ZKCHK(A.alloc(32 * na));
+    ZKCHK(B.alloc(32 * nb));
+    ZKCHK(Oo.alloc(32 * n));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
+    HIPCHK(hipMemcpyAsync(A.p, a, 32 * na, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(B.p, b, 32 * nb, hipMemcpyHostToDevice, c.stream));
+    ZKCHK(fr_to_mont(A.p, A.p, na, flag.as<int>(), c.stream));
+    ZKCHK(fr_to_mont(B.p, B.p, nb, flag.as<int>(), c.stream));
+    ZKCHK(dev_poly_mul(A.p, na, B.p, nb, Oo.p, c.stream));
+    ZKCHK(fr_from_mont(Oo.p, Oo.p, n, c.stream));
+    int hf = 0;
+    HIPCHK(hipMemcpyAsync(&hf, flag.p, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(out, Oo.p, 32 * n, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (hf) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "zk_fr_poly_mul: coefficient >= r");
+    // Polynomial.normalize (polynomial.ml:100-107): strip trailing zeros
+    while (n) {
+        const uint8_t* p = out + 32 * (n - 1);
+        bool z = true;
+        for (int i = 0; i < 32; i++) z = z && p[i] == 0;
+        if (!z) break;
+        n--;
+    }
+    *nout = n;
+    return ZK_OK;
+}

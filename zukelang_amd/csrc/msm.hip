@@ -534,7 +534,7 @@ int xyzz_sum_columns(Curve curve, void* d_out, const void* d_parts, uint32_t cou
     return ZK_OK;
 }
 
-static DevBuf g_pow2[2];
+static DevBuf* const g_pow2 = new DevBuf[2];   // never destroyed (see ntt.hip)
 static void msm_release() { g_pow2[0].release(); g_pow2[1].release(); }
 static CleanupRegistrar g_msm_cleanup(msm_release);
 

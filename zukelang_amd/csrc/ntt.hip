@@ -12,14 +12,11 @@
 // (bit-reversed -> natural): convolutions never pay a permutation; only the public zk_fr_ntt
 // (natural in/out like FFT.ml) adds one.  Twiddles come from per-level tables (level k holds
 // zeta_{2^k}^j contiguously), which the late, small-stride stages hit in L2.
-#include "ff.cuh"
+#include "ntt_lds.cuh"
 #include "zk_common.h"
 
 namespace zk {
 
-static constexpr int NTT_LOG_T = 10;
-static constexpr int NTT_T = 1 << NTT_LOG_T;
-static constexpr int NTT_THREADS = 256;
 
 __device__ static const uint32_t OMEGA_MONT[8] = {0x0c17f47cu, 0x9cab6d5cu, 0xfd4b71e5u, 0x1ce1e93du,
                                                   0x471dd505u, 0x0d6db230u, 0x743a3b6au, 0x3f0ee990u};
@@ -80,35 +77,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__
         for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
     }
     __syncthreads();
-    for (uint32_t st = 0; st < a.s; st++) {
-        const uint32_t log_hl = INVERSE ? st : a.s - 1 - st;            // local half = 2^log_hl rows
-        const uint32_t log_hs = log_hl + a.log_RS;
-        const uint32_t hs = 1u << log_hs;
-        const uint32_t hlm = (1u << log_hl) - 1;
-        const uint64_t h = (uint64_t)1 << (log_hl + log_L);              // global half-distance
-        for (uint32_t b = threadIdx.x; b < T / 2; b += NTT_THREADS) {
-            uint32_t e = ((b >> log_hs) << (log_hs + 1)) | (b & (hs - 1));
-            uint32_t rho = (e >> a.log_RS) & hlm;
-            uint32_t c = a.strided ? c0 + (e & RSm) : (e & RSm) & ((1u << log_L) - 1);
-            uint64_t j = ((uint64_t)rho << log_L) + c;
-            Fr w = fe_load<FrParams>(tw + 8 * (h + j));
-            Fr u, v;
-#pragma unroll
-            for (int l = 0; l < 8; l++) { u.v[l] = lds[l][e]; v.v[l] = lds[l][e + hs]; }
-            Fr x, y;
-            if (INVERSE) {
-                v = fe_mul(v, w);
-                x = fe_add(u, v);
-                y = fe_sub(u, v);
-            } else {
-                x = fe_add(u, v);
-                y = fe_mul(fe_sub(u, v), w);
-            }
-#pragma unroll
-            for (int l = 0; l < 8; l++) { lds[l][e] = x.v[l]; lds[l][e + hs] = y.v[l]; }
-        }
-        __syncthreads();
-    }
+    lds_ntt_stages<INVERSE>(lds, tw, T, a.s, a.log_RS, log_L, c0, a.strided != 0);
     Fr sc;
     if (scale) sc = fe_load<FrParams>(scale);
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
@@ -161,7 +130,8 @@ __global__ void k_gen_inv_pow2(uint32_t* out) {
     }
 }
 
-static DevBuf g_tw_fwd, g_tw_inv, g_inv_pow2;
+// heap-allocated and never destroyed: static destructors must not call into a HIP runtime that is already gone
+static DevBuf &g_tw_fwd = *new DevBuf, &g_tw_inv = *new DevBuf, &g_inv_pow2 = *new DevBuf;
 
 int ntt_ensure_twiddles(uint32_t log_n) {
     Ctx& c = ctx();

@@ -7,8 +7,8 @@
 namespace zk {
 
 Ctx& ctx() {
-    static Ctx c;
-    return c;
+    static Ctx* c = new Ctx;   // never destroyed: event / stream handles must not be touched at exit
+    return *c;
 }
 int set_error(int code, const char* what, const char* file, int line) {
     char buf[512];

@@ -1,0 +1,236 @@
+"""Host-side mirror of `Groth16.Make(C) : Protocol.S` (src/groth16/groth16.mli:3-6,
+src/lib/zk/protocol.mli:3-28) for the prove path, backed by the HIP library.
+
+Same names, argument meaning and error behaviour as the OCaml module:
+
+  keygen rng circuit        -> (pkey, vkey)     groth16.ml:227-233 -> setup :45-108
+  prove  rng pkey sol       -> proof            groth16.ml:235-237 -> :123-161
+                                                (the qap argument of the reference is the circuit
+                                                 held by the uploaded key: dense QAP.t is 3*m*n
+                                                 field elements and cannot exist at 2^16+)
+`rng` is any callable returning the next Fr element as a Python int; keygen draws
+alpha, beta, gamma, delta, tau in that order (groth16.ml:51-55) and prove draws r then s
+(groth16.ml:124-125), exactly like `Fr.gen rng` in the reference.
+
+An unsatisfied witness raises AssertionError like `assert (Polynomial.is_zero rem)` (QAP.ml:134).
+`verify` (3 pairings, groth16.ml:163-173) is the next row of the scope table and is
+not part of the accelerated path.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .curve import G1, G2
+from .r1cs import FR_MODULUS, R1CS, fr_bytes
+
+ZK_ERR_REMAINDER = -4
+
+
+def _p(arr):
+    return arr.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _csr(M):
+    c = _lib.CSR()
+    c.row_ptr = M.ptr.ctypes.data_as(C.POINTER(C.c_uint32))
+    c.col = M.col.ctypes.data_as(C.POINTER(C.c_uint32))
+    c.val = M.val.ctypes.data_as(C.POINTER(C.c_uint8))
+    return c
+
+
+@dataclass
+class PKey:
+    """groth16.ml:24-34, fields in declaration order, flattened per group:
+    g1 = a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid[n_mid] (96 B each)
+    g2 = b2 | d2 | ti2[n+2] (192 B each)"""
+    g1: np.ndarray
+    g2: np.ndarray
+
+
+@dataclass
+class VKey:
+    """groth16.ml:36-43 without `ab` (a GT element: needs the pairing)."""
+    one1: bytes
+    ltgm_io: np.ndarray     # [L_k(tau)/gamma]_1 for k in io, Var order
+    one2: bytes
+    gm: bytes
+    d: bytes
+
+
+@dataclass
+class Proof:
+    a: bytes   # G1 96 B
+    b: bytes   # G2 192 B
+    c: bytes   # G1 96 B
+
+    def to_compressed(self):
+        """The JSON form of groth16.ml:110-114 (curve.ml:199,208): 48 | 96 | 48 B."""
+        return G1.to_compressed_bytes(self.a) + G2.to_compressed_bytes(self.b) + G1.to_compressed_bytes(self.c)
+
+
+def _lagrange_at(n, tau):
+    """l_i(tau) for the integer domain 0..n-1 and Z(tau) (QAP.ml:84,92), O(n) with one inversion."""
+    P = FR_MODULUS
+    fact = [1] * (n + 1)
+    for i in range(1, n + 1):
+        fact[i] = fact[i - 1] * i % P
+    zt = 1
+    den = [0] * n
+    for i in range(n):
+        d = (tau - i) % P
+        zt = zt * d % P
+        x = d * fact[i] % P * fact[n - 1 - i] % P
+        den[i] = (P - x) % P if (n - 1 - i) & 1 else x
+    pre = [1] * (n + 1)
+    for i in range(n):
+        pre[i + 1] = pre[i] * den[i] % P
+    inv = pow(pre[n], P - 2, P)
+    lag = [0] * n
+    for i in range(n - 1, -1, -1):
+        lag[i] = inv * pre[i] % P * zt % P
+        inv = inv * den[i] % P
+    return lag, zt
+
+
+class Groth16:
+    @staticmethod
+    def keygen(rng, circuit: R1CS):
+        """Groth16 setup (groth16.ml:45-108): the exponents are host integers, the points come from the
+        fixed-base kernel.  L_k(tau) is evaluated through the Lagrange basis of the integer domain
+        instead of Poly.apply on dense polynomials (same field element)."""
+        P = FR_MODULUS
+        a, b, gm, d, t = (rng() % P for _ in range(5))
+        n, m = circuit.n, circuit.m
+        lag, zt = _lagrange_at(n, t)
+        dinv, ginv = pow(d, P - 2, P), pow(gm, P - 2, P)
+        Lk = [0] * m
+        for M, mult in ((circuit.L, b), (circuit.R, a), (circuit.O, 1)):
+            vals = bytes(M.val)
+            for g in range(n):
+                for e in range(M.ptr[g], M.ptr[g + 1]):
+                    coef = int.from_bytes(vals[32 * e:32 * e + 32], "little")
+                    Lk[M.col[e]] = (Lk[M.col[e]] + coef * lag[g] % P * mult) % P
+        ex1 = [a, d, b]
+        ti = 1
+        for _ in range(n + 2):
+            ex1.append(ti)
+            ti = ti * t % P
+        ztd = zt * dinv % P
+        ti = 1
+        for _ in range(n - 1):
+            ex1.append(ti * ztd % P)
+            ti = ti * t % P
+        ex1 += [Lk[k] * dinv % P for k in range(m) if circuit.mid[k]]
+        ex2 = [b, d]
+        ti = 1
+        for _ in range(n + 2):
+            ex2.append(ti)
+            ti = ti * t % P
+        exio = [Lk[k] * ginv % P for k in range(m) if not circuit.mid[k]]
+        pk = PKey(G1.of_Fr(fr_bytes(ex1)), G2.of_Fr(fr_bytes(ex2)))
+        vk = VKey(bytes(G1.of_Fr(fr_bytes([1]))), G1.of_Fr(fr_bytes(exio)), bytes(G2.of_Fr(fr_bytes([1]))),
+                  bytes(G2.of_Fr(fr_bytes([gm]))), bytes(G2.of_Fr(fr_bytes([d]))))
+        return pk, vk
+
+    def __init__(self, circuit: R1CS, pkey: PKey, rank=0, world=1):
+        """Uploads the proving key and the circuit once (device-resident until `close`)."""
+        self.circuit = circuit
+        self.rank, self.world = rank, world
+        self._keep = (circuit, pkey)
+        L, R, O = _csr(circuit.L), _csr(circuit.R), _csr(circuit.O)
+        h = C.c_uint64()
+        g1 = np.ascontiguousarray(pkey.g1, dtype=np.uint8)
+        g2 = np.ascontiguousarray(pkey.g2, dtype=np.uint8)
+        mid = np.ascontiguousarray(circuit.mid, dtype=np.uint8)
+        lib = _lib.lib()
+        if world == 1:
+            rc = lib.zk_groth16_pk_upload(C.c_uint32(circuit.n), C.c_uint32(circuit.m), C.byref(L), C.byref(R), C.byref(O), _p(mid),
+                                          _p(g1), C.c_size_t(len(g1) // 96), _p(g2), C.c_size_t(len(g2) // 192), C.byref(h))
+        else:
+            rc = lib.zk_groth16_pk_upload_sharded(C.c_uint32(circuit.n), C.c_uint32(circuit.m), C.byref(L), C.byref(R), C.byref(O),
+                                                  _p(mid), _p(g1), C.c_size_t(len(g1) // 96), _p(g2), C.c_size_t(len(g2) // 192),
+                                                  C.c_uint32(rank), C.c_uint32(world), C.byref(h))
+        _lib.check(rc)
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            _lib.lib().zk_groth16_pk_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _sol_bytes(sol):
+        if isinstance(sol, np.ndarray):
+            return np.ascontiguousarray(sol, dtype=np.uint8).reshape(-1)
+        if isinstance(sol, (bytes, bytearray)):
+            return np.frombuffer(bytes(sol), dtype=np.uint8)
+        return fr_bytes(sol)
+
+    def prove(self, rng, sol):
+        """Groth16.prove rng qap pkey sol (groth16.ml:235-237): draws r then s from rng."""
+        r = rng() % FR_MODULUS
+        s = rng() % FR_MODULUS
+        return self.prove_rs(sol, r, s)
+
+    def prove_rs(self, sol, r, s):
+        w = self._sol_bytes(sol)
+        if len(w) != 32 * self.circuit.m:
+            raise AssertionError("Variable not found")          # var.ml:75-77
+        rb, sb = fr_bytes([r]), fr_bytes([s])
+        out = np.zeros(384, dtype=np.uint8)
+        if self.world == 1:
+            rc = _lib.lib().zk_groth16_prove(self.handle, _p(w), _p(rb), _p(sb), _p(out))
+        else:
+            part = self.prove_partial(w, rb, sb)
+            gathered = self._all_gather(part)
+            rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
+        if rc == ZK_ERR_REMAINDER:
+            raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
+        _lib.check(rc)
+        b = bytes(out)
+        return Proof(b[:96], b[96:288], b[288:])
+
+    def prove_partial(self, w, rb, sb):
+        part = np.zeros(768, dtype=np.uint8)
+        rc = _lib.lib().zk_groth16_prove_partial(self.handle, _p(w), _p(rb), _p(sb), _p(part))
+        if rc == ZK_ERR_REMAINDER:
+            raise AssertionError("Polynomial.is_zero rem")
+        _lib.check(rc)
+        return part
+
+    def _all_gather(self, part):
+        """The exchange step of SURVEY 8e: all-gather of the raw partial sums (768 B per rank) --
+        RCCL on the GPU box (backend nccl), gloo in the CPU tests."""
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(part.copy())
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = t.to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return np.ascontiguousarray(torch.cat(out).cpu().numpy())
+
+    def qap_eval(self, sol):
+        """QAP.eval (QAP.ml:120-135): coefficient vectors (v, w, h) padded with zeros to n, n, n-1."""
+        w = self._sol_bytes(sol)
+        n = self.circuit.n
+        v = np.zeros(32 * n, dtype=np.uint8)
+        ww = np.zeros(32 * n, dtype=np.uint8)
+        h = np.zeros(32 * (n - 1), dtype=np.uint8)
+        rc = _lib.lib().zk_groth16_qap_eval(self.handle, _p(w), _p(v), _p(ww), _p(h))
+        if rc == ZK_ERR_REMAINDER:
+            raise AssertionError("Polynomial.is_zero rem")
+        _lib.check(rc)
+        return v, ww, h
+
+    @staticmethod
+    def verify(input_output, vkey, proof):
+        raise NotImplementedError("Groth16.verify needs the pairing (groth16.ml:163-173): scope row f1, not on the accelerated path")
