@@ -107,6 +107,9 @@ int zk_groth16_pk_free(uint64_t handle);
  * Returns ZK_ERR_REMAINDER when the witness does not satisfy the gates (QAP.ml:134). */
 int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
                      uint8_t proof[384]);
+/* Keeps a witness resident in HBM; a later zk_groth16_prove / _prove_partial / _qap_eval called with
+ * sol = NULL uses it (no host -> device copy inside the call). */
+int zk_groth16_set_witness(uint64_t handle, const uint8_t* sol);
 
 /* QAP.eval (src/lib/zk/QAP.ml:120-135) on the uploaded circuit: coefficient vectors of
  * v = sum_k sol_k v_k, w, and h = (v*w - y)/Z, each padded with zeros to n (h: n-1). Any out

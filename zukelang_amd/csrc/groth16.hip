@@ -34,6 +34,7 @@ struct Groth16Key {
     DevBuf mid_idx;                     // variable index of the j-th mid variable
     DevBuf scalA, scalC, scalB;         // canonical scalars, full pool length
     DevBuf wit_raw, rs, results;        // results: A, C (G1 XYZZ) then B (G2 XYZZ)
+    bool have_witness = false;
 };
 
 static std::map<uint64_t, std::unique_ptr<Groth16Key>>& g_keys = *new std::map<uint64_t, std::unique_ptr<Groth16Key>>;   // never destroyed (see ntt.hip)
@@ -132,7 +133,8 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
 // Fr stage + the three MSMs over this rank's slice; results left in k.results (A, C, B as XYZZ)
 static int prove_core(Groth16Key& k, const uint8_t* sol, const uint8_t* r, const uint8_t* s, int with_blinding) {
     Ctx& c = ctx();
-    HIPCHK(hipMemcpyAsync(k.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, c.stream));
+    if (sol) { HIPCHK(hipMemcpyAsync(k.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, c.stream)); k.have_witness = true; }
+    else if (!k.have_witness) ZK_FAIL(ZK_ERR_ARG, "no witness: pass sol or call zk_groth16_set_witness first");
     if (with_blinding) {
         HIPCHK(hipMemcpyAsync(k.rs.p, r, 32, hipMemcpyHostToDevice, c.stream));
         HIPCHK(hipMemcpyAsync((char*)k.rs.p + 32, s, 32, hipMemcpyHostToDevice, c.stream));
@@ -199,17 +201,27 @@ int zk_groth16_pk_free(uint64_t handle) {
 int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint8_t proof[384]) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    if (!sol || !r || !s || !proof) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove: null argument");
+    if (!r || !s || !proof) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove: null argument");
     if (k->world != 1) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove: key is sharded; use prove_partial + combine");
     ZKCHK(prove_core(*k, sol, r, s, 1));
     ZKCHK(check_flag(*k));
     return emit_proof(k->results.p, proof);
 }
+int zk_groth16_set_witness(uint64_t handle, const uint8_t* sol) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_set_witness: null");
+    Ctx& c = ctx();
+    HIPCHK(hipMemcpyAsync(k->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    k->have_witness = true;
+    return ZK_OK;
+}
 int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
                              uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    if (!sol || !r || !s || !partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial: null argument");
+    if (!r || !s || !partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial: null argument");
     ZKCHK(prove_core(*k, sol, r, s, 1));
     ZKCHK(check_flag(*k));
     Ctx& c = ctx();
@@ -239,9 +251,9 @@ int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[38
 int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: null witness");
     Ctx& c = ctx();
-    HIPCHK(hipMemcpyAsync(k->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, c.stream));
+    if (sol) { HIPCHK(hipMemcpyAsync(k->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, c.stream)); k->have_witness = true; }
+    else if (!k->have_witness) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: no witness");
     ZKCHK(frstage_eval(k->fr, k->wit_raw.p, c.stream));
     ZKCHK(check_flag(*k));
     DevBuf tmp;

@@ -180,14 +180,24 @@ class Groth16:
         s = rng() % FR_MODULUS
         return self.prove_rs(sol, r, s)
 
-    def prove_rs(self, sol, r, s):
+    def set_witness(self, sol):
+        """Uploads a witness once; later prove_rs(None, r, s) calls use the HBM-resident copy."""
         w = self._sol_bytes(sol)
         if len(w) != 32 * self.circuit.m:
             raise AssertionError("Variable not found")          # var.ml:75-77
+        _lib.check(_lib.lib().zk_groth16_set_witness(self.handle, _p(w)))
+
+    def prove_rs(self, sol, r, s):
+        if sol is None:
+            w = None
+        else:
+            w = self._sol_bytes(sol)
+            if len(w) != 32 * self.circuit.m:
+                raise AssertionError("Variable not found")          # var.ml:75-77
         rb, sb = fr_bytes([r]), fr_bytes([s])
         out = np.zeros(384, dtype=np.uint8)
         if self.world == 1:
-            rc = _lib.lib().zk_groth16_prove(self.handle, _p(w), _p(rb), _p(sb), _p(out))
+            rc = _lib.lib().zk_groth16_prove(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), _p(out))
         else:
             part = self.prove_partial(w, rb, sb)
             gathered = self._all_gather(part)
@@ -200,7 +210,7 @@ class Groth16:
 
     def prove_partial(self, w, rb, sb):
         part = np.zeros(768, dtype=np.uint8)
-        rc = _lib.lib().zk_groth16_prove_partial(self.handle, _p(w), _p(rb), _p(sb), _p(part))
+        rc = _lib.lib().zk_groth16_prove_partial(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), _p(part))
         if rc == ZK_ERR_REMAINDER:
             raise AssertionError("Polynomial.is_zero rem")
         _lib.check(rc)
