@@ -107,6 +107,12 @@ int zk_groth16_pk_free(uint64_t handle);
  * Returns ZK_ERR_REMAINDER when the witness does not satisfy the gates (QAP.ml:134). */
 int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
                      uint8_t proof[384]);
+/* Pipelined form: up to 8 proofs in flight on one key, each on its own `slot` (own scratch and
+ * HIP streams).  _async enqueues and returns; _wait blocks for that slot and delivers the proof.
+ * The single-wave tails of one proof (bucket reduction, affine conversion) then run under the
+ * bulk kernels of the next.  zk_groth16_prove == _async + _wait on slot 0. */
+int zk_groth16_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot);
+int zk_groth16_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[384]);
 /* Keeps a witness resident in HBM; a later zk_groth16_prove / _prove_partial / _qap_eval called with
  * sol = NULL uses it (no host -> device copy inside the call). */
 int zk_groth16_set_witness(uint64_t handle, const uint8_t* sol);
@@ -141,7 +147,8 @@ int zk_profile_reset(void);
 int zk_profile_get(const char* family, double* total_ms, uint64_t* launches);
 int zk_profile_names(char* buf, size_t buflen);   /* comma-separated family names */
 int zk_sync(void);                                 /* hipStreamSynchronize on the library's streams */
-/* Throughput of the register-resident Montgomery multiplier (kind 0 = Fr, 1 = Fp): ALU ceiling. */
+/* Throughput of the register-resident Montgomery multiplier (kind 0 = Fr, 1 = Fp): ALU ceiling.
+ * kind | 4: one wave on the whole chip (dependent-chain latency). */
 int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s);
 
 #if defined(__GNUC__)

@@ -9,3 +9,5 @@ for kind, name in ((0, "Fr"), (1, "Fp")):
     g = C.c_double()
     _lib.check(L.zk_bench_field_mul(kind, 2000, C.byref(g)))
     print("%s Montgomery mul: %.1f G mul/s" % (name, g.value))
+    _lib.check(L.zk_bench_field_mul(kind | 4, 2000, C.byref(g)))
+    print("%s single-wave dependent chain: %.2f us per mul" % (name, 64 / (g.value * 1e9) * 1e6))

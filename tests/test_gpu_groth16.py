@@ -118,6 +118,33 @@ def test_unsatisfied_witness_raises_like_the_reference():
     prover.close()
 
 
+def test_pipelined_proofs_equal_serial_ones():
+    """Several proofs in flight on one key (slots) give the same bytes as one at a time."""
+    cs, w = RC.iterated_cubic(512, 0xABCDEF)
+    rng = seeded_rng(77)
+    pk, _ = Groth16.keygen(rng, cs)
+    prover = Groth16(cs, pk)
+    rs = [(rng(), rng()) for _ in range(7)]
+    serial = [prover.prove_rs(w, r, s) for r, s in rs]
+    prover.set_witness(w)
+    depth = 3
+    got = [None] * len(rs)
+    for i, (r, s) in enumerate(rs):
+        if i >= depth:
+            got[i - depth] = prover.prove_wait(i % depth)
+        prover.prove_async(None, r, s, i % depth)
+    for i in range(len(rs) - depth, len(rs)):
+        got[i] = prover.prove_wait(i % depth)
+    assert got == serial
+    # a second witness through the host-buffer path while slots are reused
+    cs2, w2 = RC.iterated_cubic(512, 5)
+    prover.prove_async(w2, 1, 2, 0)
+    prover.prove_async(w, 3, 4, 1)
+    p0, p1 = prover.prove_wait(0), prover.prove_wait(1)
+    assert p0 == prover.prove_rs(w2, 1, 2) and p1 == prover.prove_rs(w, 3, 4)
+    prover.close()
+
+
 @pytest.mark.parametrize("log_n", [16, 18])
 def test_full_size_trapdoor_and_verify(log_n):
     """BASELINE configs 2 (2^16) and up: expected proof bytes from the trapdoor evaluation (exact at

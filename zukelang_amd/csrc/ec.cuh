@@ -62,7 +62,7 @@ template <class F> FF_INLINE bool aff_on_curve(const Aff<F>& p) {
 }
 
 // dbl-2008-s-1 (a = 0)
-template <class F> FF_INLINE Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+template <class F> FF_INLINE Xyzz<F> xyzz_dbl_impl(const Xyzz<F>& p) {
     if (xyzz_is_inf(p) || fe_is_zero(p.y)) return xyzz_inf<F>();
     F U = fe_dbl(p.y);
     F V = fe_sqr(U);
@@ -88,7 +88,7 @@ template <class F> FF_INLINE Xyzz<F> xyzz_dbl_aff(const Aff<F>& p) {
     return {X3, Y3, V, W};
 }
 // madd-2008-s: acc += q (q affine)
-template <class F> FF_INLINE void xyzz_madd(Xyzz<F>& acc, const Aff<F>& q) {
+template <class F> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) {
     if (aff_is_inf(q)) return;
     if (xyzz_is_inf(acc)) {
         acc = {q.x, q.y, FieldOps<F>::one(), FieldOps<F>::one()};
@@ -114,7 +114,7 @@ template <class F> FF_INLINE void xyzz_madd(Xyzz<F>& acc, const Aff<F>& q) {
     acc.zzz = fe_mul(acc.zzz, PPP);
 }
 // add-2008-s: acc += q (both XYZZ)
-template <class F> FF_INLINE void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
+template <class F> FF_INLINE void xyzz_add_impl(Xyzz<F>& acc, const Xyzz<F>& q) {
     if (xyzz_is_inf(q)) return;
     if (xyzz_is_inf(acc)) {
         acc = q;
@@ -127,7 +127,7 @@ template <class F> FF_INLINE void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
     F P = fe_sub(U2, U1);
     F R = fe_sub(S2, S1);
     if (fe_is_zero(P)) {
-        if (fe_is_zero(R)) acc = xyzz_dbl(acc);
+        if (fe_is_zero(R)) acc = xyzz_dbl_impl(acc);
         else acc = xyzz_inf<F>();
         return;
     }
@@ -141,6 +141,23 @@ template <class F> FF_INLINE void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), PP);
     acc.zzz = fe_mul(fe_mul(acc.zzz, q.zzz), PPP);
 }
+// The group operations are REAL functions (one copy per coordinate field in each translation
+// unit), with operands passed by address: kernels that chain many of them stay small, which keeps
+// hipcc's compile time in minutes and its register allocator out of trouble (a fully inlined G2
+// Horner loop -- hundreds of thousands of instructions -- was miscompiled by ROCm 7.2's clang).
+// The data crosses the call through the wave's private memory: ~1 KB of scratch traffic against
+// ~10^4 ALU instructions per operation.
+template <class F> __device__ __noinline__ void xyzz_add_fn(Xyzz<F>* acc, const Xyzz<F>* q) { xyzz_add_impl(*acc, *q); }
+template <class F> __device__ __noinline__ void xyzz_madd_fn(Xyzz<F>* acc, const Aff<F>* q) { xyzz_madd_impl(*acc, *q); }
+template <class F> __device__ __noinline__ void xyzz_dbl_fn(Xyzz<F>* r, const Xyzz<F>* p) { *r = xyzz_dbl_impl(*p); }
+template <class F> FF_INLINE void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) { xyzz_add_fn<F>(&acc, &q); }
+template <class F> FF_INLINE void xyzz_madd(Xyzz<F>& acc, const Aff<F>& q) { xyzz_madd_fn<F>(&acc, &q); }
+template <class F> FF_INLINE Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+    Xyzz<F> r;
+    xyzz_dbl_fn<F>(&r, &p);
+    return r;
+}
+
 // one inversion: 1/(ZZ*ZZZ)
 template <class F> FF_INLINE Aff<F> xyzz_to_aff(const Xyzz<F>& p) {
     if (xyzz_is_inf(p)) return aff_inf<F>();

@@ -13,6 +13,8 @@
 
 #define FF_INLINE __device__ __forceinline__
 
+#include "ff_mul_gen.cuh"
+
 namespace zk {
 
 struct FrParams {
@@ -41,16 +43,24 @@ __device__ static const uint32_t FP_R2[12] = {0x1c341746u, 0xf4df1f34u, 0x09d104
                                               0x4c95b6d5u, 0x8de5476cu, 0x939d83c0u, 0x67eb88a9u,
                                               0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
 
+__device__ static const uint32_t FR_R3[8] = {0x439b73afu, 0xc62c1807u, 0x8cf06990u, 0x1b3e0d18u,
+                                             0xc7b5f418u, 0x73d13c71u, 0xc8db33e9u, 0x6e2a5bb9u};
+__device__ static const uint32_t FP_R3[12] = {0xd94ca1e0u, 0xed48ac6bu, 0x03a7adf8u, 0x315f831eu,
+                                              0x615e29ddu, 0x9a53352au, 0x921e1761u, 0x34c04e5eu,
+                                              0x65724728u, 0x2512d435u, 0x91755d4du, 0x0aa63460u};
+
 template <class P> struct Consts;
 template <> struct Consts<FrParams> {
     static FF_INLINE uint32_t mod(int i) { return FR_MOD[i]; }
     static FF_INLINE uint32_t r1(int i) { return FR_R1[i]; }
     static FF_INLINE uint32_t r2(int i) { return FR_R2[i]; }
+    static FF_INLINE uint32_t r3(int i) { return FR_R3[i]; }
 };
 template <> struct Consts<FpParams> {
     static FF_INLINE uint32_t mod(int i) { return FP_MOD[i]; }
     static FF_INLINE uint32_t r1(int i) { return FP_R1[i]; }
     static FF_INLINE uint32_t r2(int i) { return FP_R2[i]; }
+    static FF_INLINE uint32_t r3(int i) { return FP_R3[i]; }
 };
 
 template <class P> struct Fe {
@@ -146,42 +156,18 @@ template <class P> FF_INLINE Fe<P> fe_neg(const Fe<P>& a) {
 }
 template <class P> FF_INLINE Fe<P> fe_dbl(const Fe<P>& a) { return fe_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod p, CIOS, fully reduced.
+// Montgomery product a*b*R^-1 mod p, fully reduced.  The straight-line body is generated
+// (scripts/gen_mont_mul.py): finely integrated product scanning, 2N^2 + N partial products at two
+// instructions each (v_mad_u64_u32 + v_addc_co_u32), one asm statement per column.
 template <class P> FF_INLINE Fe<P> fe_mul_inline(const Fe<P>& a, const Fe<P>& b) {
-    constexpr int N = P::N;
-    uint32_t t[N + 1];
-#pragma unroll
-    for (int i = 0; i <= N; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            c = (uint64_t)a.v[j] * b.v[i] + t[j] + c;   // < 2^64: (2^32-1)^2 + 2(2^32-1)
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        uint32_t tn = t[N] + (uint32_t)c;   // fits: the running value stays < 2p*2^32
-        uint32_t m = t[0] * P::INV;
-        c = (uint64_t)m * Consts<P>::mod(0) + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < N; j++) {
-            c = (uint64_t)m * Consts<P>::mod(j) + t[j] + c;
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += tn;
-        t[N - 1] = (uint32_t)c;
-        t[N] = (uint32_t)(c >> 32);
-    }
     Fe<P> r;
-#pragma unroll
-    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    if constexpr (P::N == 8) mont_mul_fr(r.v, a.v, b.v);
+    else mont_mul_fp(r.v, a.v, b.v);
+    // the product is < 2p < 2^(32N): one conditional subtraction
     fe_cond_sub(r);
     return r;
 }
-// The 12-limb product is ~1.3k instructions: as a real function (operands and result travel in
+// The 12-limb product is ~0.8k instructions: as a real function (operands and result travel in
 // VGPRs under the AMDGPU calling convention) every kernel shares one copy -- the hot loops stay
 // inside the instruction cache and the library compiles in minutes instead of an hour.
 __device__ __noinline__ static Fe<FpParams> fp_mul_call(Fe<FpParams> a, Fe<FpParams> b) { return fe_mul_inline(a, b); }
@@ -212,21 +198,68 @@ template <class P> FF_INLINE bool fe_is_canonical(const Fe<P>& a) {
     }
     return bw != 0;
 }
-// a^(mod-2) by square-and-multiply over the constant exponent (not unrolled: code size).
+// Modular inverse by the binary extended Euclid on plain limbs (shifts and subtractions only):
+// ~2 * bits iterations of a few N-limb operations, an order of magnitude cheaper than Fermat's
+// a^(p-2) (~580 Montgomery products) -- it matters because conversions to affine sit on
+// single-lane tails.  Input and output in Montgomery form: (aR)^-1 * R^3 * R^-1 = a^-1 R.  inv(0) = 0.
 template <class P> __device__ __noinline__ Fe<P> fe_inv(const Fe<P>& a) {
-    Fe<P> acc = fe_one<P>();
-    Fe<P> base = a;
-    uint32_t borrow = 2;   // exponent = mod - 2, limb by limb
-    for (int l = 0; l < P::N; l++) {
-        uint32_t m = Consts<P>::mod(l);
-        uint32_t w = m - borrow;
-        borrow = (m < borrow) ? 1u : 0u;
-        for (int i = 0; i < 32; i++) {
-            if ((w >> i) & 1) acc = fe_mul(acc, base);
-            base = fe_sqr(base);
+    constexpr int N = P::N;
+    if (fe_is_zero(a)) return a;
+    uint32_t u[N], v[N], x1[N], x2[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) { u[i] = a.v[i]; v[i] = Consts<P>::mod(i); x1[i] = 0; x2[i] = 0; }
+    x1[0] = 1;
+    auto is_one = [](const uint32_t* x) {
+        uint32_t o = x[0] ^ 1u;
+#pragma unroll
+        for (int i = 1; i < N; i++) o |= x[i];
+        return o == 0;
+    };
+    auto shr1 = [](uint32_t* x) {
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[N - 1] >>= 1;
+    };
+    auto halve_mod = [&](uint32_t* x) {          // x/2 mod p
+        if (x[0] & 1) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) { c += (uint64_t)x[i] + Consts<P>::mod(i); x[i] = (uint32_t)c; c >>= 32; }
         }
+        shr1(x);
+    };
+    auto geq = [](const uint32_t* x, const uint32_t* y) {
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) { uint64_t d = (uint64_t)x[i] - y[i] - bw; bw = (d >> 32) & 1; }
+        return bw == 0;
+    };
+    auto sub = [](uint32_t* x, const uint32_t* y) {      // x -= y (x >= y)
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) { uint64_t d = (uint64_t)x[i] - y[i] - bw; x[i] = (uint32_t)d; bw = (d >> 32) & 1; }
+    };
+    auto sub_mod = [&](uint32_t* x, const uint32_t* y) {  // x = x - y mod p
+        uint64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) { uint64_t d = (uint64_t)x[i] - y[i] - bw; x[i] = (uint32_t)d; bw = (d >> 32) & 1; }
+        if (bw) {
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) { c += (uint64_t)x[i] + Consts<P>::mod(i); x[i] = (uint32_t)c; c >>= 32; }
+        }
+    };
+    for (int guard = 0; guard < 4 * 32 * N && !is_one(u) && !is_one(v); guard++) {
+        while (!(u[0] & 1)) { shr1(u); halve_mod(x1); }
+        while (!(v[0] & 1)) { shr1(v); halve_mod(x2); }
+        if (geq(u, v)) { sub(u, v); sub_mod(x1, x2); }
+        else { sub(v, u); sub_mod(x2, x1); }
     }
-    return acc;
+    Fe<P> r, r3;
+    const bool use1 = is_one(u);
+#pragma unroll
+    for (int i = 0; i < N; i++) { r.v[i] = use1 ? x1[i] : x2[i]; r3.v[i] = Consts<P>::r3(i); }
+    return fe_mul(r, r3);
 }
 template <class P> FF_INLINE Fe<P> fe_from_u32(uint32_t x) {
     Fe<P> r = fe_zero<P>();

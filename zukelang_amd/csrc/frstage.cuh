@@ -19,15 +19,18 @@ struct FrStage {
     DevBuf pntt;                      // log_n2 levels x n2: NTT_len(P_{s,len/2}) / len per node
     DevBuf iz_ntt;                    // NTT_S of (rev Z)^-1 mod x^(n-1)
     DevBuf z;                         // Z coefficients, n + 1 (Montgomery)
-    // per-proof scratch
+};
+// per-proof scratch: one per proof in flight
+struct FrScratch {
     DevBuf wit, abc, d, tmp, bufA, bufB, h, flag;
 };
 
 int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, hipStream_t s);
-// witness: m canonical Fr on device.  Leaves v = f.d[0..n), w = f.d[n2..n2+n), h = f.h[0..n-1) in
-// Montgomery form; *f.flag |= 1 when some gate is violated (QAP.ml:134), |= 2 when a witness
-// value is not canonical.
-int frstage_eval(FrStage& f, const void* d_witness_canonical, hipStream_t s);
+int frstage_scratch_alloc(const FrStage& f, FrScratch& sc);
+// witness: m canonical Fr on device.  Leaves v = sc.d[0..n), w = sc.d[n2..n2+n), h = sc.h[0..n-1) in
+// Montgomery form; *sc.flag |= 1 when some gate is violated (QAP.ml:134), |= 2 when a witness
+// value is not canonical.  Everything is enqueued on `s`; nothing synchronizes.
+int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_witness_canonical, hipStream_t s);
 
 // a*b via NTT on device (Montgomery in/out); out must hold na+nb-1 elements
 int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, void* d_out, hipStream_t s);

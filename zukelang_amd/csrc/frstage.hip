@@ -261,7 +261,7 @@ static int upload_csr(CsrDev& d, const zk_csr* h, uint32_t n, uint32_t m, hipStr
 }
 
 // Newton -> monomial for `batch` vectors of n2 coefficients stored back to back in d (in place).
-static int tree_convert(FrStage& f, void* d, uint32_t batch, uint32_t levels, void* tmp, hipStream_t s) {
+static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t levels, void* tmp, hipStream_t s) {
     Ctx& c = ctx();
     const uint64_t total = (uint64_t)batch * f.n2;
     const uint32_t log_total = ceil_log2(total);
@@ -301,14 +301,8 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     ZKCHK(f.pntt.alloc(32 * (size_t)n2 * (f.log_n2 ? f.log_n2 : 1)));
     ZKCHK(f.iz_ntt.alloc(32 * (size_t)S));
     ZKCHK(f.z.alloc(32 * (size_t)(n + 1)));
-    ZKCHK(f.wit.alloc(32 * (size_t)m));
-    ZKCHK(f.abc.alloc(32 * (size_t)3 * n));
-    ZKCHK(f.d.alloc(32 * (size_t)2 * n2));
-    ZKCHK(f.tmp.alloc(32 * (size_t)2 * n2));
-    ZKCHK(f.bufA.alloc(32 * (size_t)S));
-    ZKCHK(f.bufB.alloc(32 * (size_t)S));
-    ZKCHK(f.h.alloc(32 * (size_t)n));
-    ZKCHK(f.flag.alloc(4));
+    FrScratch sc0;                       // only used to derive Z for n that is not a power of two
+    ZKCHK(frstage_scratch_alloc(f, sc0));
 
     // ---- 1/i! and the alternating kernel of the Newton convolution
     {
@@ -348,10 +342,10 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
             hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, FRP(f.z) + 8 * (uint64_t)n);
         } else {
             // Z = X^(n falling) : Newton coordinates e_n, converted through the tree (n < n2)
-            HIPCHK(hipMemsetAsync(f.d.p, 0, 32 * (size_t)n2, s));
-            hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, FRP(f.d) + 8 * (uint64_t)n);
-            ZKCHK(tree_convert(f, f.d.p, 1, f.log_n2, f.tmp.p, s));
-            HIPCHK(hipMemcpyAsync(f.z.p, f.d.p, 32 * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemsetAsync(sc0.d.p, 0, 32 * (size_t)n2, s));
+            hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, FRP(sc0.d) + 8 * (uint64_t)n);
+            ZKCHK(tree_convert(f, sc0.d.p, 1, f.log_n2, sc0.tmp.p, s));
+            HIPCHK(hipMemcpyAsync(f.z.p, sc0.d.p, 32 * (size_t)(n + 1), hipMemcpyDeviceToDevice, s));
         }
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -385,52 +379,64 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     return ZK_OK;
 }
 
-int frstage_eval(FrStage& f, const void* d_wit_canon, hipStream_t s) {
+int frstage_scratch_alloc(const FrStage& f, FrScratch& sc) {
+    ZKCHK(sc.wit.alloc(32 * (size_t)f.m));
+    ZKCHK(sc.abc.alloc(32 * (size_t)3 * f.n));
+    ZKCHK(sc.d.alloc(32 * (size_t)2 * f.n2));
+    ZKCHK(sc.tmp.alloc(32 * (size_t)2 * f.n2));
+    ZKCHK(sc.bufA.alloc(32 * (size_t)f.S));
+    ZKCHK(sc.bufB.alloc(32 * (size_t)f.S));
+    ZKCHK(sc.h.alloc(32 * (size_t)f.n));
+    ZKCHK(sc.flag.alloc(4));
+    return ZK_OK;
+}
+
+int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipStream_t s) {
     const uint32_t n = f.n, n2 = f.n2, S = f.S;
-    uint32_t* a = FRP(f.abc);
+    uint32_t* a = FRP(sc.abc);
     uint32_t* b = a + 8 * (uint64_t)n;
     uint32_t* cc = b + 8 * (uint64_t)n;
-    HIPCHK(hipMemsetAsync(f.flag.p, 0, 4, s));
+    HIPCHK(hipMemsetAsync(sc.flag.p, 0, 4, s));
     {
         ScopedTimer t("fr_spmv", s);
         // witness -> Montgomery; a non-canonical value sets bit 0 of a scratch flag which we fold into bit 1
-        DevBuf& w = f.wit;
-        hipLaunchKernelGGL(k_fr_to_mont_flag2, g1d(f.m), dim3(256), 0, s, FRP(w), (const uint32_t*)d_wit_canon, (uint64_t)f.m, f.flag.as<int>());
+        DevBuf& w = sc.wit;
+        hipLaunchKernelGGL(k_fr_to_mont_flag2, g1d(f.m), dim3(256), 0, s, FRP(w), (const uint32_t*)d_wit_canon, (uint64_t)f.m, sc.flag.as<int>());
         hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.L.ptr), (const uint32_t*)FRP(f.L.col), (const uint32_t*)FRP(f.L.val), (const uint32_t*)FRP(w), a, n);
         hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.R.ptr), (const uint32_t*)FRP(f.R.col), (const uint32_t*)FRP(f.R.val), (const uint32_t*)FRP(w), b, n);
         hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.O.ptr), (const uint32_t*)FRP(f.O.col), (const uint32_t*)FRP(f.O.val), (const uint32_t*)FRP(w), cc, n);
-        hipLaunchKernelGGL(k_check_r1cs, g1d(n), dim3(256), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)cc, n, f.flag.as<int>());
+        hipLaunchKernelGGL(k_check_r1cs, g1d(n), dim3(256), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)cc, n, sc.flag.as<int>());
     }
     // ---- values -> Newton coefficients (both vectors), into d[0..n2) and d[n2..2 n2)
     {
         ScopedTimer t("fr_newton", s);
         for (int k = 0; k < 2; k++) {
             const uint32_t* src = k == 0 ? a : b;
-            hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.bufA), src, (const uint32_t*)FRP(f.invfact), (uint64_t)n, (uint64_t)S);
-            ZKCHK(ntt_forward(f.bufA.p, S, f.log_S, s));
-            ZKCHK(fr_pointwise_mul(f.bufA.p, f.bufA.p, f.e_ntt.p, S, s));
-            ZKCHK(ntt_inverse(f.bufA.p, S, f.log_S, true, s));
-            hipLaunchKernelGGL(k_scale_pad, g1d(n2), dim3(256), 0, s, FRP(f.d) + 8 * (uint64_t)k * n2, (const uint32_t*)FRP(f.bufA), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)n2);
+            hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), src, (const uint32_t*)FRP(f.invfact), (uint64_t)n, (uint64_t)S);
+            ZKCHK(ntt_forward(sc.bufA.p, S, f.log_S, s));
+            ZKCHK(fr_pointwise_mul(sc.bufA.p, sc.bufA.p, f.e_ntt.p, S, s));
+            ZKCHK(ntt_inverse(sc.bufA.p, S, f.log_S, true, s));
+            hipLaunchKernelGGL(k_scale_pad, g1d(n2), dim3(256), 0, s, FRP(sc.d) + 8 * (uint64_t)k * n2, (const uint32_t*)FRP(sc.bufA), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)n2);
         }
     }
     // ---- Newton -> monomial
-    ZKCHK(tree_convert(f, f.d.p, 2, f.log_n2, f.tmp.p, s));
+    ZKCHK(tree_convert(f, sc.d.p, 2, f.log_n2, sc.tmp.p, s));
     // ---- h
     {
         ScopedTimer t("fr_quotient", s);
-        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.bufA), (const uint32_t*)FRP(f.d), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
-        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.bufB), (const uint32_t*)(FRP(f.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
-        ZKCHK(ntt_forward(f.bufA.p, S, f.log_S, s));
-        ZKCHK(ntt_forward(f.bufB.p, S, f.log_S, s));
-        ZKCHK(fr_pointwise_mul(f.bufA.p, f.bufA.p, f.bufB.p, S, s));
-        ZKCHK(ntt_inverse(f.bufA.p, S, f.log_S, true, s));                    // v*w, coefficients 0..2n-2
+        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), (const uint32_t*)FRP(sc.d), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
+        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufB), (const uint32_t*)(FRP(sc.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
+        ZKCHK(ntt_forward(sc.bufA.p, S, f.log_S, s));
+        ZKCHK(ntt_forward(sc.bufB.p, S, f.log_S, s));
+        ZKCHK(fr_pointwise_mul(sc.bufA.p, sc.bufA.p, sc.bufB.p, S, s));
+        ZKCHK(ntt_inverse(sc.bufA.p, S, f.log_S, true, s));                    // v*w, coefficients 0..2n-2
         // t[k] = (v w)[2n-2-k], k < n-1
-        hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, FRP(f.bufB), (const uint32_t*)FRP(f.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
-        ZKCHK(ntt_forward(f.bufB.p, S, f.log_S, s));
-        ZKCHK(fr_pointwise_mul(f.bufB.p, f.bufB.p, f.iz_ntt.p, S, s));
-        ZKCHK(ntt_inverse(f.bufB.p, S, f.log_S, true, s));
+        hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufB), (const uint32_t*)FRP(sc.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
+        ZKCHK(ntt_forward(sc.bufB.p, S, f.log_S, s));
+        ZKCHK(fr_pointwise_mul(sc.bufB.p, sc.bufB.p, f.iz_ntt.p, S, s));
+        ZKCHK(ntt_inverse(sc.bufB.p, S, f.log_S, true, s));
         // h[j] = hh[n-2-j], j < n-1
-        hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(f.h), (const uint32_t*)FRP(f.bufB), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
+        hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufB), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;

@@ -22,6 +22,26 @@
 
 namespace zk {
 
+// Everything one proof in flight owns: scratch of the Fr stage, the three scalar vectors, one MSM
+// workspace and one stream per product, pinned host landing buffers.  Several slots let the shallow
+// single-wave tails of one proof (bucket reduction, affine conversion) run under the bulk kernels
+// of the next.
+struct Slot {
+    FrScratch fs;
+    DevBuf scalA, scalC, scalB, wit_raw, rs, results, out_dev;
+    MsmWorkspace wsA, wsC, wsB;
+    hipStream_t s0 = nullptr, s1 = nullptr, s2 = nullptr;     // C + Fr stage | B (G2) | A
+    hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, done = nullptr;
+    uint8_t* host = nullptr;            // pinned: proof 384 B | flag 4 B | r 32 B | s 32 B
+    bool busy = false;
+    ~Slot() {
+        if (s0) { (void)hipStreamDestroy(s0); (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2); }
+        if (fork) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join1); (void)hipEventDestroy(join2); (void)hipEventDestroy(done); }
+        if (host) (void)hipHostFree(host);
+    }
+};
+static constexpr uint32_t MAX_SLOTS = 8;
+
 struct Groth16Key {
     uint32_t n = 0, m = 0, n_mid = 0;
     uint32_t rank = 0, world = 1;
@@ -30,11 +50,10 @@ struct Groth16Key {
     uint64_t lo2 = 0, hi2 = 0;
     FrStage fr;
     MsmBases g1, g2;
-    MsmWorkspace ws1, ws2;
     DevBuf mid_idx;                     // variable index of the j-th mid variable
-    DevBuf scalA, scalC, scalB;         // canonical scalars, full pool length
-    DevBuf wit_raw, rs, results;        // results: A, C (G1 XYZZ) then B (G2 XYZZ)
+    DevBuf wit_resident;                // zk_groth16_set_witness
     bool have_witness = false;
+    std::unique_ptr<Slot> slots[MAX_SLOTS];
 };
 
 static std::map<uint64_t, std::unique_ptr<Groth16Key>>& g_keys = *new std::map<uint64_t, std::unique_ptr<Groth16Key>>;   // never destroyed (see ntt.hip)
@@ -48,16 +67,15 @@ static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n
 __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __restrict__ scalC, uint32_t* __restrict__ scalB,
                                   const uint32_t* __restrict__ v, const uint32_t* __restrict__ w, const uint32_t* __restrict__ h,
                                   const uint32_t* __restrict__ wit_mont, const uint32_t* __restrict__ mid_idx,
-                                  const uint32_t* __restrict__ rs, uint32_t n, uint32_t n_mid, int with_blinding) {
+                                  const uint32_t* __restrict__ rs, uint32_t n, uint32_t n_mid) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t p1 = 3 + (uint64_t)(n + 2) + (n - 1) + n_mid;
     if (i >= p1) return;
-    Fr r = fe_zero<FrParams>(), s = r;
-    if (with_blinding) { r = fe_to_mont(fe_load<FrParams>(rs)); s = fe_to_mont(fe_load<FrParams>(rs + 8)); }
+    const Fr r = fe_to_mont(fe_load<FrParams>(rs)), s = fe_to_mont(fe_load<FrParams>(rs + 8));
     const Fr zero = fe_zero<FrParams>(), one = fe_one<FrParams>();
     Fr a = zero, c = zero;
     const uint64_t ti = 3, tz = ti + n + 2, lt = tz + (n - 1);
-    if (i == 0) { a = with_blinding ? one : zero; c = s; }                       // alpha
+    if (i == 0) { a = one; c = s; }                                               // alpha
     else if (i == 1) { a = r; c = fe_mul(r, s); }                                 // delta
     else if (i == 2) { c = r; }                                                   // beta_1
     else if (i < tz) {
@@ -74,7 +92,7 @@ __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __rest
     const uint64_t p2 = 2 + (uint64_t)(n + 2);
     if (i < p2) {
         Fr b = zero;
-        if (i == 0) b = with_blinding ? one : zero;                               // beta_2
+        if (i == 0) b = one;                                                      // beta_2
         else if (i == 1) b = s;                                                   // delta_2
         else if (i - 2 < n) b = fe_load<FrParams>(w + 8 * (i - 2));
         fe_store<FrParams>(scalB + 8 * i, fe_from_mont(b));
@@ -85,6 +103,35 @@ static int key_lookup(uint64_t handle, Groth16Key** out) {
     auto it = g_keys.find(handle);
     if (it == g_keys.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Groth16 key handle");
     *out = it->second.get();
+    return ZK_OK;
+}
+
+static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
+    if (idx >= MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "slot index out of range (max 8 proofs in flight)");
+    if (!k.slots[idx]) {
+        auto sl = std::make_unique<Slot>();
+        ZKCHK(frstage_scratch_alloc(k.fr, sl->fs));
+        ZKCHK(sl->scalA.alloc(32 * k.p1));
+        ZKCHK(sl->scalC.alloc(32 * k.p1));
+        ZKCHK(sl->scalB.alloc(32 * k.p2));
+        ZKCHK(sl->wit_raw.alloc(32 * (size_t)k.m));
+        ZKCHK(sl->rs.alloc(64));
+        ZKCHK(sl->results.alloc(2 * xyzz_bytes(CURVE_G1) + xyzz_bytes(CURVE_G2)));
+        ZKCHK(sl->out_dev.alloc(384));
+        ZKCHK(msm_workspace_alloc(sl->wsA, k.g1));
+        ZKCHK(msm_workspace_alloc(sl->wsC, k.g1));
+        ZKCHK(msm_workspace_alloc(sl->wsB, k.g2));
+        HIPCHK(hipStreamCreateWithFlags(&sl->s0, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&sl->s1, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&sl->s2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl->join1, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl->join2, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void**)&sl->host, 512, hipHostMallocDefault));
+        k.slots[idx] = std::move(sl);
+    }
+    *out = k.slots[idx].get();
     return ZK_OK;
 }
 
@@ -114,59 +161,60 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     if (k.hi1 == k.lo1 || k.hi2 == k.lo2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: more ranks than key points");
     ZKCHK(msm_bases_from_bytes(k.g1, CURVE_G1, pk_g1 + 96 * k.lo1, k.hi1 - k.lo1, 0, true, c.stream));
     ZKCHK(msm_bases_from_bytes(k.g2, CURVE_G2, pk_g2 + 192 * k.lo2, k.hi2 - k.lo2, 0, true, c.stream));
-    ZKCHK(msm_workspace_alloc(k.ws1, k.g1));
-    ZKCHK(msm_workspace_alloc(k.ws2, k.g2));
     ZKCHK(k.mid_idx.alloc(4 * (size_t)(k.n_mid ? k.n_mid : 1)));
     if (k.n_mid) HIPCHK(hipMemcpyAsync(k.mid_idx.p, mids.data(), 4 * (size_t)k.n_mid, hipMemcpyHostToDevice, c.stream));
-    ZKCHK(k.scalA.alloc(32 * k.p1));
-    ZKCHK(k.scalC.alloc(32 * k.p1));
-    ZKCHK(k.scalB.alloc(32 * k.p2));
-    ZKCHK(k.wit_raw.alloc(32 * (size_t)m));
-    ZKCHK(k.rs.alloc(64));
-    ZKCHK(k.results.alloc(2 * xyzz_bytes(CURVE_G1) + xyzz_bytes(CURVE_G2)));
+    ZKCHK(k.wit_resident.alloc(32 * (size_t)m));
     HIPCHK(hipStreamSynchronize(c.stream));
+    Slot* sl;
+    ZKCHK(slot_get(k, 0, &sl));
     *handle = g_next_handle++;
     g_keys[*handle] = std::move(key);
     return ZK_OK;
 }
 
-// Fr stage + the three MSMs over this rank's slice; results left in k.results (A, C, B as XYZZ)
-static int prove_core(Groth16Key& k, const uint8_t* sol, const uint8_t* r, const uint8_t* s, int with_blinding) {
-    Ctx& c = ctx();
-    if (sol) { HIPCHK(hipMemcpyAsync(k.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, c.stream)); k.have_witness = true; }
-    else if (!k.have_witness) ZK_FAIL(ZK_ERR_ARG, "no witness: pass sol or call zk_groth16_set_witness first");
-    if (with_blinding) {
-        HIPCHK(hipMemcpyAsync(k.rs.p, r, 32, hipMemcpyHostToDevice, c.stream));
-        HIPCHK(hipMemcpyAsync((char*)k.rs.p + 32, s, 32, hipMemcpyHostToDevice, c.stream));
-    }
-    ZKCHK(frstage_eval(k.fr, k.wit_raw.p, c.stream));
-    const uint32_t* v = k.fr.d.as<uint32_t>();
+// Enqueues one proof on the slot's streams and returns without waiting:
+// Fr stage -> scalar vectors -> {C on s0, B on s1, A on s2} -> affine bytes -> pinned host buffer.
+static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, bool raw) {
+    if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call zk_groth16_prove_wait first");
+    const void* wit = k.wit_resident.p;
+    if (sol) {
+        HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, sl.s0));
+        wit = sl.wit_raw.p;
+    } else if (!k.have_witness) ZK_FAIL(ZK_ERR_ARG, "no witness: pass sol or call zk_groth16_set_witness first");
+    memcpy(sl.host + 392, r, 32);
+    memcpy(sl.host + 424, s, 32);
+    HIPCHK(hipMemcpyAsync(sl.rs.p, sl.host + 392, 64, hipMemcpyHostToDevice, sl.s0));
+    ZKCHK(frstage_eval(k.fr, sl.fs, wit, sl.s0));
+    const uint32_t* v = sl.fs.d.as<uint32_t>();
     const uint32_t* w = v + 8 * (uint64_t)k.fr.n2;
-    hipLaunchKernelGGL(k_groth16_scalars, g1d(k.p1), dim3(256), 0, c.stream, k.scalA.as<uint32_t>(), k.scalC.as<uint32_t>(), k.scalB.as<uint32_t>(), v, w,
-                       (const uint32_t*)k.fr.h.as<uint32_t>(), (const uint32_t*)k.fr.wit.as<uint32_t>(), (const uint32_t*)k.mid_idx.as<uint32_t>(),
-                       (const uint32_t*)k.rs.as<uint32_t>(), k.n, k.n_mid, with_blinding);
+    hipLaunchKernelGGL(k_groth16_scalars, g1d(k.p1), dim3(256), 0, sl.s0, sl.scalA.as<uint32_t>(), sl.scalC.as<uint32_t>(), sl.scalB.as<uint32_t>(), v, w,
+                       (const uint32_t*)sl.fs.h.as<uint32_t>(), (const uint32_t*)sl.fs.wit.as<uint32_t>(), (const uint32_t*)k.mid_idx.as<uint32_t>(),
+                       (const uint32_t*)sl.rs.as<uint32_t>(), k.n, k.n_mid);
     HIPCHK(hipGetLastError());
-    char* res = k.results.as<char>();
-    // fork: G2 on stream2
-    HIPCHK(hipEventRecord(c.ev_fork, c.stream));
-    HIPCHK(hipStreamWaitEvent(c.stream2, c.ev_fork, 0));
-    ZKCHK(msm_run(k.g2, k.ws2, k.scalB.as<char>() + 32 * k.lo2, res + 2 * xyzz_bytes(CURVE_G1), c.stream2));
-    HIPCHK(hipEventRecord(c.ev_join, c.stream2));
-    ZKCHK(msm_run(k.g1, k.ws1, k.scalA.as<char>() + 32 * k.lo1, res, c.stream));
-    ZKCHK(msm_run(k.g1, k.ws1, k.scalC.as<char>() + 32 * k.lo1, res + xyzz_bytes(CURVE_G1), c.stream));
-    HIPCHK(hipStreamWaitEvent(c.stream, c.ev_join, 0));
+    char* res = sl.results.as<char>();
+    char* out = sl.out_dev.as<char>();
+    const size_t g1b = xyzz_bytes(CURVE_G1);
+    HIPCHK(hipEventRecord(sl.fork, sl.s0));
+    HIPCHK(hipStreamWaitEvent(sl.s1, sl.fork, 0));
+    HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
+    // B (G2, the longest chain) first
+    ZKCHK(msm_run(k.g2, sl.wsB, sl.scalB.as<char>() + 32 * k.lo2, res + 2 * g1b, sl.s1));
+    if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, res + 2 * g1b, 1, out + 96, sl.s1));
+    HIPCHK(hipEventRecord(sl.join1, sl.s1));
+    ZKCHK(msm_run(k.g1, sl.wsC, sl.scalC.as<char>() + 32 * k.lo1, res + g1b, sl.s0));
+    if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + g1b, 1, out + 288, sl.s0));
+    ZKCHK(msm_run(k.g1, sl.wsA, sl.scalA.as<char>() + 32 * k.lo1, res, sl.s2));
+    if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res, 1, out, sl.s2));
+    HIPCHK(hipEventRecord(sl.join2, sl.s2));
+    HIPCHK(hipStreamWaitEvent(sl.s0, sl.join1, 0));
+    HIPCHK(hipStreamWaitEvent(sl.s0, sl.join2, 0));
+    if (!raw) HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 384, hipMemcpyDeviceToHost, sl.s0));
+    HIPCHK(hipMemcpyAsync(sl.host + 384, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, sl.s0));
+    HIPCHK(hipEventRecord(sl.done, sl.s0));
+    sl.busy = true;
     return ZK_OK;
 }
-static int check_flag(Groth16Key& k) {
-    Ctx& c = ctx();
-    int hf = 0;
-    HIPCHK(hipMemcpyAsync(&hf, k.fr.flag.p, 4, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
-    if (hf & 2) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "witness value >= r");
-    if (hf & 1) ZK_FAIL(ZK_ERR_REMAINDER, "p mod Z != 0");
-    return ZK_OK;
-}
-// proof bytes: a | b | c  from results laid out A, C, B
+// proof bytes a | b | c from three XYZZ results laid out A, C (G1), B (G2)
 static int emit_proof(const void* d_results, uint8_t* proof) {
     Ctx& c = ctx();
     uint8_t g1pts[192];
@@ -174,6 +222,16 @@ static int emit_proof(const void* d_results, uint8_t* proof) {
     ZKCHK(points_xyzz_to_bytes(CURVE_G2, (const char*)d_results + 2 * xyzz_bytes(CURVE_G1), 1, proof + 96, c.stream));
     memcpy(proof, g1pts, 96);
     memcpy(proof + 288, g1pts + 96, 96);
+    return ZK_OK;
+}
+static int prove_finish(Slot& sl) {
+    if (!sl.busy) ZK_FAIL(ZK_ERR_ARG, "no proof in flight on this slot");
+    HIPCHK(hipEventSynchronize(sl.done));
+    sl.busy = false;
+    int hf;
+    memcpy(&hf, sl.host + 384, 4);
+    if (hf & 2) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "witness value >= r");
+    if (hf & 1) ZK_FAIL(ZK_ERR_REMAINDER, "p mod Z != 0");
     return ZK_OK;
 }
 
@@ -194,25 +252,40 @@ int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const 
 int zk_groth16_pk_free(uint64_t handle) {
     auto it = g_keys.find(handle);
     if (it == g_keys.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Groth16 key handle");
-    (void)zk_sync();
+    (void)hipDeviceSynchronize();
     g_keys.erase(it);
     return ZK_OK;
 }
-int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint8_t proof[384]) {
+int zk_groth16_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    if (!r || !s || !proof) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove: null argument");
-    if (k->world != 1) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove: key is sharded; use prove_partial + combine");
-    ZKCHK(prove_core(*k, sol, r, s, 1));
-    ZKCHK(check_flag(*k));
-    return emit_proof(k->results.p, proof);
+    if (!r || !s) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_async: null argument");
+    if (k->world != 1) ZK_FAIL(ZK_ERR_ARG, "key is sharded; use prove_partial + combine");
+    Slot* sl;
+    ZKCHK(slot_get(*k, slot, &sl));
+    return prove_enqueue(*k, *sl, sol, r, s, false);
+}
+int zk_groth16_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[384]) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (!proof) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_wait: null proof");
+    if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_wait: slot never used");
+    Slot& sl = *k->slots[slot];
+    ZKCHK(prove_finish(sl));
+    memcpy(proof, sl.host, 384);
+    return ZK_OK;
+}
+int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint8_t proof[384]) {
+    ZKCHK(zk_groth16_prove_async(handle, sol, r, s, 0));
+    return zk_groth16_prove_wait(handle, 0, proof);
 }
 int zk_groth16_set_witness(uint64_t handle, const uint8_t* sol) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_set_witness: null");
     Ctx& c = ctx();
-    HIPCHK(hipMemcpyAsync(k->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, c.stream));
+    (void)hipDeviceSynchronize();      // no proof may still be reading the previous witness
+    HIPCHK(hipMemcpyAsync(k->wit_resident.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     k->have_witness = true;
     return ZK_OK;
@@ -222,11 +295,11 @@ int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t 
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (!r || !s || !partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial: null argument");
-    ZKCHK(prove_core(*k, sol, r, s, 1));
-    ZKCHK(check_flag(*k));
-    Ctx& c = ctx();
-    HIPCHK(hipMemcpyAsync(partial, k->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    Slot* sl;
+    ZKCHK(slot_get(*k, 0, &sl));
+    ZKCHK(prove_enqueue(*k, *sl, sol, r, s, true));      // raw XYZZ partial sums: no affine conversion
+    ZKCHK(prove_finish(*sl));
+    HIPCHK(hipMemcpy(partial, sl->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost));
     return ZK_OK;
 }
 int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[384]) {
@@ -251,22 +324,31 @@ int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[38
 int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    Ctx& c = ctx();
-    if (sol) { HIPCHK(hipMemcpyAsync(k->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, c.stream)); k->have_witness = true; }
-    else if (!k->have_witness) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: no witness");
-    ZKCHK(frstage_eval(k->fr, k->wit_raw.p, c.stream));
-    ZKCHK(check_flag(*k));
+    Slot* sl;
+    ZKCHK(slot_get(*k, 0, &sl));
+    if (sl->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: slot 0 has a proof in flight");
+    const void* wit = k->wit_resident.p;
+    if (sol) {
+        HIPCHK(hipMemcpyAsync(sl->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, sl->s0));
+        wit = sl->wit_raw.p;
+    } else if (!k->have_witness) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: no witness");
+    ZKCHK(frstage_eval(k->fr, sl->fs, wit, sl->s0));
+    int hf = 0;
+    HIPCHK(hipMemcpyAsync(&hf, sl->fs.flag.p, 4, hipMemcpyDeviceToHost, sl->s0));
+    HIPCHK(hipStreamSynchronize(sl->s0));
+    if (hf & 2) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "witness value >= r");
+    if (hf & 1) ZK_FAIL(ZK_ERR_REMAINDER, "p mod Z != 0");
     DevBuf tmp;
     ZKCHK(tmp.alloc(32 * (size_t)k->n));
-    const char* v = k->fr.d.as<char>();
-    const void* srcs[3] = {v, v + 32 * (size_t)k->fr.n2, k->fr.h.p};
+    const char* v = sl->fs.d.as<char>();
+    const void* srcs[3] = {v, v + 32 * (size_t)k->fr.n2, sl->fs.h.p};
     uint8_t* outs[3] = {v_out, w_out, h_out};
     size_t cnt[3] = {k->n, k->n, (size_t)k->n - 1};
     for (int i = 0; i < 3; i++) {
         if (!outs[i]) continue;
-        ZKCHK(fr_from_mont(tmp.p, srcs[i], cnt[i], c.stream));
-        HIPCHK(hipMemcpyAsync(outs[i], tmp.p, 32 * cnt[i], hipMemcpyDeviceToHost, c.stream));
-        HIPCHK(hipStreamSynchronize(c.stream));
+        ZKCHK(fr_from_mont(tmp.p, srcs[i], cnt[i], sl->s0));
+        HIPCHK(hipMemcpyAsync(outs[i], tmp.p, 32 * cnt[i], hipMemcpyDeviceToHost, sl->s0));
+        HIPCHK(hipStreamSynchronize(sl->s0));
     }
     return ZK_OK;
 }

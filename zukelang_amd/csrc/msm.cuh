@@ -41,6 +41,8 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b);
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_result_xyzz, hipStream_t s);
 // XYZZ (device) -> uncompressed bytes (host); count points
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s);
+// same, asynchronous: device XYZZ -> device bytes (no allocation, no synchronization)
+int points_xyzz_to_bytes_dev(Curve curve, const void* d_xyzz, uint64_t count, void* d_bytes, hipStream_t s);
 // bytes (device copy of host encoding) -> affine Montgomery; *d_flag |= 1 not on curve, |= 2 bad encoding
 int points_bytes_to_affine(Curve curve, void* d_affine, const void* d_bytes, uint64_t n, int* d_flag, hipStream_t s);
 int points_affine_to_bytes(Curve curve, void* d_bytes, const void* d_affine, uint64_t n, hipStream_t s);

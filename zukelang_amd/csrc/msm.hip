@@ -121,50 +121,56 @@ template <class F> __global__ void k_precompute(uint8_t* table, uint64_t n, uint
 }
 
 // ------------------------------------------------------------------ digits
+// Signed c-bit digits d_j in [-(2^(c-1) - 1), 2^(c-1)] with sum_j d_j 2^(cj) = s.  Adding the constant
+// K = sum_j (2^(c-1) - 1) 2^(cj) turns the recoding into plain base-2^c digit extraction:
+// d_j = ((s + K) >> cj & mask) - (2^(c-1) - 1), so every (scalar, window) pair is independent and
+// gets its own lane: one atomic per lane in flight instead of nw dependent ones.
 struct DigitArgs {
     uint64_t n;
     uint32_t c, nw, precomp, nb_per_window;
+    uint32_t K[9];         // the recoding constant, 288 bits
 };
-// Calls f(key, val) for every non-zero signed digit of scalar i.
-template <class Fn> FF_INLINE void for_each_digit(const uint32_t* __restrict__ scalars, uint64_t i, const DigitArgs& a, Fn f) {
+FF_INLINE bool digit_of(const uint32_t* __restrict__ scalars, uint64_t i, uint32_t j, const DigitArgs& a, uint32_t& key, uint32_t& val) {
     const uint32_t* sp = scalars + 8 * i;
-    uint32_t s[8];
     uint4 lo = reinterpret_cast<const uint4*>(sp)[0], hi = reinterpret_cast<const uint4*>(sp)[1];
-    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
-    if ((s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) == 0) return;
-    const uint32_t mask = (1u << a.c) - 1, half = 1u << (a.c - 1);
-    uint32_t carry = 0;
-    for (uint32_t j = 0; j < a.nw; j++) {
-        uint32_t off = j * a.c, w = off >> 5, b = off & 31;
-        uint32_t x0 = 0, x1 = 0;
-        // static indexing keeps the scalar in registers
+    uint32_t s[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0};
+    if ((s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) == 0) return false;
+    uint64_t cy = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((int)w == k) x0 = s[k];
-            if ((int)w + 1 == k) x1 = s[k];
-        }
-        uint64_t x = ((uint64_t)x1 << 32) | x0;
-        uint32_t d = (w < 8 ? (uint32_t)(x >> b) & mask : 0u) + carry;
-        uint32_t neg = 0;
-        carry = 0;
-        if (d > half) { d = (1u << a.c) - d; neg = 1; carry = 1; }
-        if (d) {
-            uint32_t key = (a.precomp ? 0u : j * a.nb_per_window) + (d - 1);
-            uint32_t val = (uint32_t)(a.precomp ? (uint64_t)j * a.n + i : i) | (neg << 31);
-            f(key, val);
-        }
+    for (int k = 0; k < 9; k++) {
+        cy += (uint64_t)s[k] + a.K[k];
+        s[k] = (uint32_t)cy;
+        cy >>= 32;
     }
+    const uint32_t off = j * a.c, w = off >> 5, b = off & 31;
+    uint32_t x0 = 0, x1 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {        // static indexing keeps the scalar in registers
+        if ((int)w == k) x0 = s[k];
+        if ((int)w + 1 == k) x1 = s[k];
+    }
+    const uint64_t x = ((uint64_t)x1 << 32) | x0;
+    const uint32_t e = (uint32_t)(x >> b) & ((1u << a.c) - 1);
+    const uint32_t bias = (1u << (a.c - 1)) - 1;
+    if (e == bias) return false;                        // digit 0
+    const uint32_t neg = e < bias ? 1u : 0u;
+    const uint32_t d = neg ? bias - e : e - bias;
+    key = (a.precomp ? 0u : j * a.nb_per_window) + (d - 1);
+    val = (uint32_t)(a.precomp ? (uint64_t)j * a.n + i : i) | (neg << 31);
+    return true;
 }
 __global__ void k_msm_count(const uint32_t* __restrict__ scalars, DigitArgs a, uint32_t* __restrict__ counts) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    for_each_digit(scalars, i, a, [&](uint32_t key, uint32_t) { atomicAdd(&counts[key], 1u); });
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n * a.nw) return;
+    uint32_t key, val;
+    if (digit_of(scalars, g / a.nw, (uint32_t)(g % a.nw), a, key, val)) atomicAdd(&counts[key], 1u);
 }
 __global__ void k_msm_scatter(const uint32_t* __restrict__ scalars, DigitArgs a, uint32_t* __restrict__ cursor,
                               uint32_t* __restrict__ sorted) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    for_each_digit(scalars, i, a, [&](uint32_t key, uint32_t val) { sorted[atomicAdd(&cursor[key], 1u)] = val; });
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n * a.nw) return;
+    uint32_t key, val;
+    if (digit_of(scalars, g / a.nw, (uint32_t)(g % a.nw), a, key, val)) sorted[atomicAdd(&cursor[key], 1u)] = val;
 }
 // single workgroup: offsets[k] = sum_{q<k} counts[q], offsets[nb] = total; cursor = offsets
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
@@ -212,24 +218,32 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restric
         if (offsets[mid] <= pos) lo = mid; else hi = mid;
     }
     uint32_t kb = lo;
+    // Flat loop: one mixed addition per lane per iteration whatever the run boundaries are (a loop
+    // nest over runs would make the wave pay the longest run of every lane in turn).  A lane
+    // crossing into the next bucket stores its running sum first -- a short divergent epilogue.
+    uint32_t bstart = offsets[kb], bend = offsets[kb + 1];
+    uint32_t seg_start = pos;
     bool first = true;
-    while (pos < end) {
-        uint32_t bstart = offsets[kb], bend = offsets[kb + 1];
-        if (bend <= pos) { kb++; continue; }           // empty bucket
-        uint32_t seg_end = min(bend, end);
-        Xyzz<F> acc = xyzz_inf<F>();
-        bool complete = (pos == bstart) && (seg_end == bend);
-        for (uint32_t e = pos; e < seg_end; e++) {
-            uint32_t v = sorted[e];
-            Aff<F> p = aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
-            if (v >> 31) p.y = fe_neg(p.y);
-            xyzz_madd(acc, p);
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (; pos < end; pos++) {
+        if (pos == bend) {                              // run finished inside the chunk
+            const bool complete = seg_start == bstart;
+            uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
+            xyzz_store<F>(dst, acc);
+            first = false;
+            acc = xyzz_inf<F>();
+            do { kb++; bstart = bend; bend = offsets[kb + 1]; } while (bend == bstart);   // skip empty buckets
+            seg_start = pos;
         }
+        uint32_t v = sorted[pos];
+        Aff<F> p = aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
+        if (v >> 31) p.y = fe_neg(p.y);
+        xyzz_madd(acc, p);
+    }
+    {
+        const bool complete = (seg_start == bstart) && (end == bend);
         uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
         xyzz_store<F>(dst, acc);
-        first = false;
-        pos = seg_end;
-        if (pos == bend) kb++;
     }
 }
 template <class F>
@@ -251,45 +265,20 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
     xyzz_store<F>(buckets + (uint64_t)XB * kb, acc);
 }
 
-// ------------------------------------------------------------------ bucket reduction: sum_b (b+1) * B_b per window
-// lane: slice of `per` consecutive buckets, running sums from the top, + lo * (slice sum)
-template <class F>
-__global__ __launch_bounds__(128) void k_msm_reduce_slices(const uint8_t* __restrict__ buckets, uint32_t nb_per_window,
-                                                           uint32_t per, uint32_t slices_per_window, uint32_t total_slices,
-                                                           uint8_t* __restrict__ red) {
-    constexpr int XB = FieldOps<F>::WORDS * 16;
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_slices) return;
-    const uint32_t w = g / slices_per_window, sl = g % slices_per_window;
-    const uint32_t lo = sl * per, hi = min(lo + per, nb_per_window);
-    const uint8_t* bw = buckets + (uint64_t)XB * w * nb_per_window;
-    Xyzz<F> acc = xyzz_inf<F>(), sum = xyzz_inf<F>();
-    for (uint32_t b = hi; b-- > lo;) {
-        Xyzz<F> q = xyzz_load<F>(bw + (uint64_t)XB * b);
-        xyzz_add(acc, q);
-        xyzz_add(sum, acc);
-    }
-    if (lo) {
-        Xyzz<F> m = xyzz_mul_u32(acc, lo);
-        xyzz_add(sum, m);
-    }
-    xyzz_store<F>(red + (uint64_t)XB * g, sum);
-}
-// one workgroup per window: tree-sum the slice results through LDS
-template <class F>
-__global__ __launch_bounds__(256) void k_msm_window_sum(const uint8_t* __restrict__ red, uint32_t slices_per_window,
-                                                        uint8_t* __restrict__ wsum) {
-    constexpr int XB = FieldOps<F>::WORDS * 16;
+// ------------------------------------------------------------------ bucket reduction: R = sum_w w * B_w, w = b + 1
+// A lone wave issues one instruction every ~4 cycles, so a chain of dependent EC additions costs
+// ~20 us per link whatever the chip is doing: the reduction must be SHALLOW, not merely parallel.
+// Write w = hi * 2^lb + lo.  Then R = sum_lo lo * S0[lo] + 2^lb * sum_hi hi * S1[hi] with the digit
+// sums S0[d] = sum of buckets whose low digit is d, S1[d] = those whose high digit is d:
+//   digit_sums    one wave per (digit, value): strided loads + LDS tree          depth ~ 2 + 6
+//   digit_weight  d * S[d] by double-and-add (d < 2^lb), LDS tree over d         depth ~ 2 lb + 8
+//   final         2^lb * V1 + V0 (and Horner over windows in classic mode)        depth ~ lb + 1
+// ~40 links instead of the ~100+ of per-lane running sums, and 2x the bucket reads (cheap).
+template <class F, int NT> FF_INLINE void block_tree_sum(Xyzz<F>& acc, uint32_t (*lds)[NT]) {
     constexpr int XW = FieldOps<F>::WORDS * 4;
-    __shared__ uint32_t lds[XW][256];                  // limb-major: conflict-free column access
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
-    Xyzz<F> acc = xyzz_inf<F>();
-    for (uint32_t sl = t; sl < slices_per_window; sl += 256) {
-        Xyzz<F> q = xyzz_load<F>(red + (uint64_t)XB * ((uint64_t)w * slices_per_window + sl));
-        xyzz_add(acc, q);
-    }
+    const uint32_t t = threadIdx.x;
     __attribute__((aligned(16))) uint32_t tmp[XW];
-    for (uint32_t d = 128; d >= 1; d >>= 1) {
+    for (uint32_t d = NT / 2; d >= 1; d >>= 1) {
         __syncthreads();
         if (t >= d && t < 2 * d) {
             xyzz_store<F>(tmp, acc);
@@ -304,17 +293,63 @@ __global__ __launch_bounds__(256) void k_msm_window_sum(const uint8_t* __restric
             xyzz_add(acc, q);
         }
     }
-    if (t == 0) xyzz_store<F>(wsum + (uint64_t)XB * w, acc);
 }
-// classic mode: result = sum_j 2^(c*j) * W_j by Horner from the top window (one lane)
-template <class F> __global__ void k_msm_final(const uint8_t* __restrict__ wsum, uint32_t nw, uint32_t c, uint8_t* __restrict__ out) {
+struct DigitPlan {
+    uint32_t nbw, lb, nd0, nd1;
+};
+template <class F>
+__global__ __launch_bounds__(64) void k_msm_digit_sums(const uint8_t* __restrict__ buckets, DigitPlan p, uint8_t* __restrict__ S) {
+    constexpr int XB = FieldOps<F>::WORDS * 16, XW = FieldOps<F>::WORDS * 4;
+    __shared__ uint32_t lds[XW][64];
+    const uint32_t b = blockIdx.x, win = blockIdx.y, t = threadIdx.x;
+    const uint8_t* bw = buckets + (uint64_t)XB * win * p.nbw;
+    const bool low = b < p.nd0;
+    const uint32_t d = low ? b : b - p.nd0;
+    const uint32_t cnt = low ? p.nd1 : p.nd0;
+    Xyzz<F> acc = xyzz_inf<F>();
+    if (d != 0) {                                   // weight 0 never contributes
+        for (uint32_t e = t; e < cnt; e += 64) {
+            uint32_t w = low ? (e << p.lb) + d : (d << p.lb) + e;
+            if (w >= 1 && w <= p.nbw) {
+                Xyzz<F> q = xyzz_load<F>(bw + (uint64_t)XB * (w - 1));
+                xyzz_add(acc, q);
+            }
+        }
+    }
+    block_tree_sum<F, 64>(acc, lds);
+    if (t == 0) xyzz_store<F>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
+}
+// V[win][k] = sum_d d * S[win][k][d]
+template <class F>
+__global__ __launch_bounds__(256) void k_msm_digit_weight(const uint8_t* __restrict__ S, DigitPlan p, uint8_t* __restrict__ V) {
+    constexpr int XB = FieldOps<F>::WORDS * 16, XW = FieldOps<F>::WORDS * 4;
+    __shared__ uint32_t lds[XW][256];
+    const uint32_t k = blockIdx.x, win = blockIdx.y, t = threadIdx.x;
+    const uint32_t cnt = k == 0 ? p.nd0 : p.nd1;
+    const uint8_t* base = S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + (k == 0 ? 0 : p.nd0));
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (uint32_t d = t; d < cnt; d += 256) {
+        if (!d) continue;
+        Xyzz<F> q = xyzz_load<F>(base + (uint64_t)XB * d);
+        Xyzz<F> m = xyzz_mul_u32(q, d);
+        xyzz_add(acc, m);
+    }
+    block_tree_sum<F, 256>(acc, lds);
+    if (t == 0) xyzz_store<F>(V + (uint64_t)XB * (2 * win + k), acc);
+}
+// W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one lane)
+template <class F> __global__ __launch_bounds__(64) void k_msm_final(const uint8_t* __restrict__ V, uint32_t nw, uint32_t c, uint32_t lb, uint8_t* __restrict__ out) {
     constexpr int XB = FieldOps<F>::WORDS * 16;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    Xyzz<F> acc = xyzz_load<F>(wsum + (uint64_t)XB * (nw - 1));
-    for (uint32_t j = nw - 1; j-- > 0;) {
-        for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
-        Xyzz<F> q = xyzz_load<F>(wsum + (uint64_t)XB * j);
-        xyzz_add(acc, q);
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (uint32_t j = nw; j-- > 0;) {
+        if (j != nw - 1)
+            for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
+        Xyzz<F> hi = xyzz_load<F>(V + (uint64_t)XB * (2 * j + 1));
+        for (uint32_t k = 0; k < lb; k++) hi = xyzz_dbl(hi);
+        xyzz_add(acc, hi);
+        Xyzz<F> lo = xyzz_load<F>(V + (uint64_t)XB * (2 * j));
+        xyzz_add(acc, lo);
     }
     xyzz_store<F>(out, acc);
 }
@@ -382,11 +417,13 @@ __global__ __launch_bounds__(128) void k_fixed_base_mul(uint8_t* __restrict__ ou
 
 // ================================================================== host side
 static inline dim3 grid_for(uint64_t n, unsigned threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
-// buckets per reduce lane: 32 for big windows, fewer when the window is small (keeps >= 256 lanes busy)
-static inline uint32_t reduce_per(uint32_t nbw) {
-    if (nbw >= 32 * 256) return 32;
-    uint32_t per = nbw / 256;
-    return per ? per : 1;
+static inline DigitPlan digit_plan(uint32_t c) {
+    DigitPlan p;
+    p.nbw = 1u << (c - 1);
+    p.lb = (c + 1) / 2;
+    p.nd0 = 1u << p.lb;
+    p.nd1 = (p.nbw >> p.lb) + 1;
+    return p;
 }
 
 uint32_t msm_auto_window(uint64_t n, bool precomp) {
@@ -433,12 +470,16 @@ int points_affine_to_bytes(Curve curve, void* d_bytes, const void* d_aff, uint64
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
+int points_xyzz_to_bytes_dev(Curve curve, const void* d_xyzz, uint64_t count, void* d_bytes, hipStream_t s) {
+    if (curve == CURVE_G1) hipLaunchKernelGGL(k_xyzz_to_bytes<Fp>, grid_for(count, 64), dim3(64), 0, s, (uint8_t*)d_bytes, (const uint8_t*)d_xyzz, count);
+    else hipLaunchKernelGGL(k_xyzz_to_bytes<Fp2>, grid_for(count, 64), dim3(64), 0, s, (uint8_t*)d_bytes, (const uint8_t*)d_xyzz, count);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s) {
     DevBuf tmp;
     ZKCHK(tmp.alloc(aff_bytes(curve) * count));
-    if (curve == CURVE_G1) hipLaunchKernelGGL(k_xyzz_to_bytes<Fp>, grid_for(count, 64), dim3(64), 0, s, tmp.as<uint8_t>(), (const uint8_t*)d_xyzz, count);
-    else hipLaunchKernelGGL(k_xyzz_to_bytes<Fp2>, grid_for(count, 64), dim3(64), 0, s, tmp.as<uint8_t>(), (const uint8_t*)d_xyzz, count);
-    HIPCHK(hipGetLastError());
+    ZKCHK(points_xyzz_to_bytes_dev(curve, d_xyzz, count, tmp.p, s));
     HIPCHK(hipMemcpyAsync(host_out, tmp.p, aff_bytes(curve) * count, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return ZK_OK;
@@ -483,24 +524,36 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     ZKCHK(w.buckets.alloc(XB * w.nbuckets));
     ZKCHK(w.head.alloc(XB * w.nthreads));
     ZKCHK(w.tail.alloc(XB * w.nthreads));
-    const uint32_t per = reduce_per(nbw);
-    const uint32_t spw = (nbw + per - 1) / per;
-    ZKCHK(w.red.alloc(XB * (size_t)spw * (b.precomp ? 1 : b.nw)));
-    ZKCHK(w.wsum.alloc(XB * (b.precomp ? 1 : b.nw)));
+    const DigitPlan dp = digit_plan(b.c);
+    ZKCHK(w.red.alloc(XB * (size_t)(dp.nd0 + dp.nd1) * (b.precomp ? 1 : b.nw)));
+    ZKCHK(w.wsum.alloc(XB * 2 * (b.precomp ? 1 : b.nw)));
     return ZK_OK;
 }
 
 template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
     const uint32_t nbw = 1u << (b.c - 1);
     const uint32_t nwin = b.precomp ? 1 : b.nw;
-    DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw};
+    DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
+        uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
+        uint32_t off = j * b.c, w = off >> 5, sh = off & 31;
+        unsigned __int128 add = (unsigned __int128)v << sh;
+        uint64_t cy = 0;
+        for (uint32_t k = w; k < 9; k++) {
+            cy += (uint64_t)da.K[k] + (uint32_t)(add & 0xffffffffu);
+            da.K[k] = (uint32_t)cy;
+            cy >>= 32;
+            add >>= 32;
+            if (!add && !cy) break;
+        }
+    }
     const size_t XB = xyzz_bytes(b.curve);
     {
         ScopedTimer t("msm_sort", s);
         HIPCHK(hipMemsetAsync(w.counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
-        hipLaunchKernelGGL(k_msm_count, grid_for(b.n, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.counts.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_count, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.counts.as<uint32_t>());
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
-        hipLaunchKernelGGL(k_msm_scatter, grid_for(b.n, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.cursor.as<uint32_t>(), w.sorted.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_scatter, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.cursor.as<uint32_t>(), w.sorted.as<uint32_t>());
         HIPCHK(hipMemsetAsync(w.buckets.p, 0, XB * w.nbuckets, s));
     }
     {
@@ -512,13 +565,10 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
         hipLaunchKernelGGL(k_msm_fixup<F>, grid_for(w.nbuckets, 128), dim3(128), 0, s, w.offsets.as<uint32_t>(), w.nbuckets, w.chunk,
                            w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
-        const uint32_t per = reduce_per(nbw);
-        const uint32_t spw = (nbw + per - 1) / per;
-        hipLaunchKernelGGL(k_msm_reduce_slices<F>, grid_for((uint64_t)spw * nwin, 128), dim3(128), 0, s, w.buckets.as<uint8_t>(), nbw, per, spw,
-                           spw * nwin, w.red.as<uint8_t>());
-        hipLaunchKernelGGL(k_msm_window_sum<F>, dim3(nwin), dim3(256), 0, s, w.red.as<uint8_t>(), spw, w.wsum.as<uint8_t>());
-        if (nwin > 1) hipLaunchKernelGGL(k_msm_final<F>, dim3(1), dim3(64), 0, s, w.wsum.as<uint8_t>(), nwin, b.c, (uint8_t*)d_out);
-        else HIPCHK(hipMemcpyAsync(d_out, w.wsum.p, XB, hipMemcpyDeviceToDevice, s));
+        const DigitPlan dp = digit_plan(b.c);
+        hipLaunchKernelGGL(k_msm_digit_sums<F>, dim3(dp.nd0 + dp.nd1, nwin), dim3(64), 0, s, w.buckets.as<uint8_t>(), dp, w.red.as<uint8_t>());
+        hipLaunchKernelGGL(k_msm_digit_weight<F>, dim3(2, nwin), dim3(256), 0, s, w.red.as<uint8_t>(), dp, w.wsum.as<uint8_t>());
+        hipLaunchKernelGGL(k_msm_final<F>, dim3(1), dim3(64), 0, s, w.wsum.as<uint8_t>(), nwin, b.c, dp.lb, (uint8_t*)d_out);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
@@ -664,3 +714,4 @@ int zk_g2_of_fr(const uint8_t* scalars, size_t n, uint8_t* out) { return of_fr_a
 int zk_g1_powers(uint32_t d, const uint8_t s[32], uint8_t* out) { return powers_api(CURVE_G1, d, s, out); }
 int zk_g2_powers(uint32_t d, const uint8_t s[32], uint8_t* out) { return powers_api(CURVE_G2, d, s, out); }
 }
+

@@ -105,6 +105,8 @@ int zk_init(int device) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c.ev_join3, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
     c.device = device;
@@ -122,6 +124,8 @@ int zk_shutdown(void) {
     (void)hipEventDestroy(c.ev_join);
     (void)hipStreamDestroy(c.stream);
     (void)hipStreamDestroy(c.stream2);
+    (void)hipStreamDestroy(c.stream3);
+    (void)hipEventDestroy(c.ev_join3);
     c.inited = false;
     c.device = -1;
     return ZK_OK;
@@ -132,6 +136,7 @@ int zk_sync(void) {
     if (!c.inited) return ZK_OK;
     HIPCHK(hipStreamSynchronize(c.stream));
     HIPCHK(hipStreamSynchronize(c.stream2));
+    HIPCHK(hipStreamSynchronize(c.stream3));
     return ZK_OK;
 }
 
@@ -186,7 +191,9 @@ int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s) {
     hipEvent_t a, b;
     HIPCHK(hipEventCreate(&a));
     HIPCHK(hipEventCreate(&b));
-    const unsigned blocks = 256 * 8, threads = 256;
+    // kind bit 2 set: ONE wave on the whole chip -> dependent-chain latency instead of throughput
+    const unsigned blocks = (kind & 4) ? 1 : 256 * 8, threads = (kind & 4) ? 64 : 256;
+    kind &= 3;
     for (int rep = 0; rep < 2; rep++) {
         HIPCHK(hipEventRecord(a, c.stream));
         if (kind == 0) hipLaunchKernelGGL(k_bench_mul<FrParams>, dim3(blocks), dim3(threads), 0, c.stream, out.as<uint32_t>(), iters);

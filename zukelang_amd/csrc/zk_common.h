@@ -19,8 +19,9 @@ struct Ctx {
     bool inited = false;
     int device = -1;
     hipStream_t stream = nullptr;      // main stream (G1 work, Fr stage)
-    hipStream_t stream2 = nullptr;     // second stream (G2 MSM overlaps the G1 MSMs)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr;     // G2 MSM
+    hipStream_t stream3 = nullptr;     // second G1 MSM: the shallow single-wave tails of one product overlap the bulk of another
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     // twiddles: heap layout, level k (NTT size 2^k) at offset 2^(k-1); fwd = w^j, inv = w^-j
     void* tw_fwd = nullptr;
     void* tw_inv = nullptr;

@@ -208,6 +208,22 @@ class Groth16:
         b = bytes(out)
         return Proof(b[:96], b[96:288], b[288:])
 
+    def prove_async(self, sol, r, s, slot):
+        """Enqueue one proof on `slot` (0..7) and return; `prove_wait(slot)` collects it.  Several
+        slots keep several proofs in flight on one key."""
+        w = None if sol is None else self._sol_bytes(sol)
+        rb, sb = fr_bytes([r]), fr_bytes([s])
+        _lib.check(_lib.lib().zk_groth16_prove_async(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), C.c_uint32(slot)))
+
+    def prove_wait(self, slot):
+        out = np.zeros(384, dtype=np.uint8)
+        rc = _lib.lib().zk_groth16_prove_wait(self.handle, C.c_uint32(slot), _p(out))
+        if rc == ZK_ERR_REMAINDER:
+            raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
+        _lib.check(rc)
+        b = bytes(out)
+        return Proof(b[:96], b[96:288], b[288:])
+
     def prove_partial(self, w, rb, sb):
         part = np.zeros(768, dtype=np.uint8)
         rc = _lib.lib().zk_groth16_prove_partial(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), _p(part))
