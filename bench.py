@@ -19,6 +19,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before torch / HIP initialise (see zk_api.hip)
 
 import numpy as np  # noqa: E402
 
@@ -68,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3, help="proofs kept in flight on one GPU (1 = strictly serial)")
+    ap.add_argument("--inflight", type=int, default=6, help="proofs kept in flight on one GPU (1 = strictly serial)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -18,6 +18,7 @@
 
 #include <map>
 #include <memory>
+#include <stdlib.h>
 #include <string.h>
 
 namespace zk {
@@ -33,9 +34,9 @@ struct Slot {
     hipStream_t s0 = nullptr, s1 = nullptr, s2 = nullptr;     // C + Fr stage | B (G2) | A
     hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, done = nullptr;
     uint8_t* host = nullptr;            // pinned: proof 384 B | flag 4 B | r 32 B | s 32 B
-    bool busy = false;
+    bool busy = false, serial = false;
     ~Slot() {
-        if (s0) { (void)hipStreamDestroy(s0); (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2); }
+        if (s0) { (void)hipStreamDestroy(s0); if (!serial) { (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2); } }
         if (fork) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join1); (void)hipEventDestroy(join2); (void)hipEventDestroy(done); }
         if (host) (void)hipHostFree(host);
     }
@@ -122,8 +123,13 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
         ZKCHK(msm_workspace_alloc(sl->wsC, k.g1));
         ZKCHK(msm_workspace_alloc(sl->wsB, k.g2));
         HIPCHK(hipStreamCreateWithFlags(&sl->s0, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&sl->s1, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&sl->s2, hipStreamNonBlocking));
+        if (getenv("ZK_SERIAL_STREAMS")) {       // profiling aid: un-overlapped kernel durations
+            sl->s1 = sl->s2 = sl->s0;
+            sl->serial = true;
+        } else {
+            HIPCHK(hipStreamCreateWithFlags(&sl->s1, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&sl->s2, hipStreamNonBlocking));
+        }
         HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->join1, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->join2, hipEventDisableTiming));
