@@ -137,6 +137,10 @@ int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const 
                                  uint64_t* handle);
 int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
                              uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]);
+/* pipelined form (slots as in zk_groth16_prove_async): the exchange and combine of one proof run on
+ * the host while the GPU is already working on the partial sums of the next ones */
+int zk_groth16_prove_partial_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot);
+int zk_groth16_prove_partial_wait(uint64_t handle, uint32_t slot, uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]);
 int zk_groth16_combine(const uint8_t* partials /* world * 768 */, uint32_t world, uint8_t proof[384]);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------

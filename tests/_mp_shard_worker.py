@@ -1,0 +1,88 @@
+"""Worker of tests/test_multiproc.py (one process per rank, started by torch.distributed.run).
+
+mode "cpu": world_size ranks on the CPU with gloo.  The per-rank partial products are computed by
+            the ORACLE over the rank's slice of the key pools (no GPU here), exchanged with the
+            product's all_gather_bytes, summed, and compared with the single-rank oracle proof:
+            covers the slicing rule, the scalar-vector layout, the exchange and its ordering.
+mode "gpu": the real path: every rank uploads its slice to the (shared) GPU, proves its partial
+            sums with the HIP kernels, all-gathers 768 B per rank, combines on the GPU.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch.distributed as dist  # noqa: E402
+
+import oracle_lib as O  # noqa: E402
+from oracle import pyref as P  # noqa: E402
+from zukelang_amd import r1cs as RC  # noqa: E402
+from zukelang_amd.groth16 import all_gather_bytes, msm_scalar_vectors, shard_bounds  # noqa: E402
+
+
+def frs(xs):
+    return b"".join(P.fr_to_bytes(x) for x in xs)
+
+
+def main():
+    mode = sys.argv[1]
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cs, w = RC.iterated_cubic(n, 0xFEED)
+    csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+    st = P.fr_stream(0x5EED0002)
+    toxic = [next(st) for _ in range(5)]
+    r, s = next(st), next(st)
+    expect = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    if mode == "cpu":
+        q = O.QAP(cs.n, cs.m, *csr)
+        pk1, pk2, _, _ = q.groth16_setup(frs(toxic), cs.mid)
+        v, ww, _ = q.eval_vwy(frs(w))
+        rc, _, h = q.eval(frs(w))
+        assert rc == 0
+        sa, sc, sb = msm_scalar_vectors(n, RC.fr_ints(v), RC.fr_ints(ww), RC.fr_ints(h), w, cs.mid, r, s)
+        p1, p2 = len(pk1) // 96, len(pk2) // 192
+        assert len(sa) == len(sc) == p1 and len(sb) == p2
+        lo1, hi1 = shard_bounds(p1, rank, world)
+        lo2, hi2 = shard_bounds(p2, rank, world)
+        _, A = O.g1_msm_naive(pk1[96 * lo1:96 * hi1], frs(sa[lo1:hi1]))
+        _, Cc = O.g1_msm_naive(pk1[96 * lo1:96 * hi1], frs(sc[lo1:hi1]))
+        _, B = O.g2_msm_naive(pk2[192 * lo2:192 * hi2], frs(sb[lo2:hi2]))
+        import numpy as np
+        gathered = bytes(all_gather_bytes(np.frombuffer(A + Cc + B, dtype=np.uint8), world))
+        blk = 96 + 96 + 192
+        inf1, inf2 = bytes([0x40]) + bytes(95), bytes([0x40]) + bytes(191)
+        a, c, b = inf1, inf1, inf2
+        for j in range(world):
+            part = gathered[blk * j:blk * (j + 1)]
+            a = O.g1_add(a, part[:96]); c = O.g1_add(c, part[96:192]); b = O.g2_add(b, part[192:])
+        assert (a, b, c) == expect, "rank %d: sharded sum differs from the single-rank proof" % rank
+    else:
+        from zukelang_amd import _lib
+        from zukelang_amd.groth16 import Groth16
+        _lib.check(_lib.lib().zk_init(0))
+        it = iter(toxic)
+        pk, _ = Groth16.keygen(lambda: next(it), cs)
+        prover = Groth16(cs, pk, rank, world)
+        proof = prover.prove_rs(w, r, s)
+        assert (proof.a, proof.b, proof.c) == expect, "rank %d: sharded GPU proof differs" % rank
+        # pipelined: three sharded proofs in flight, collected in order (every rank runs the same
+        # sequence of all-gathers)
+        prover.set_witness(w)
+        for slot in range(3):
+            prover.prove_async(None, r, s, slot)
+        for slot in range(3):
+            p2 = prover.prove_wait(slot)
+            assert (p2.a, p2.b, p2.c) == expect, "rank %d slot %d: pipelined sharded proof differs" % (rank, slot)
+        prover.close()
+    dist.barrier()
+    if rank == 0:
+        print("MP-OK", mode, world, n)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

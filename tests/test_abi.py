@@ -1,0 +1,94 @@
+"""CPU-only checks of the drop-in boundary: libzkmi355x.so loads, exports every symbol that
+include/zkmi355x.h declares, fails loudly without a GPU (no CPU fallback), and its pure byte-level
+helpers agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "zkmi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), "missing export: " + s
+    assert sorted(_lib.EXPORTS) == syms, "zukelang_amd/_lib.py EXPORTS is out of sync with include/zkmi355x.h"
+
+
+def test_no_torch_types_in_the_header():
+    text = open(os.path.join(ROOT, "include", "zkmi355x.h")).read()
+    assert 'extern "C"' in text
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert "torch" not in code and "at::" not in code and "std::" not in code and "template" not in code
+
+
+def test_strerror_codes():
+    lib = _lib.lib()
+    assert lib.zk_strerror(0) == b"ok"
+    for code in range(-8, 0):
+        assert lib.zk_strerror(code) not in (b"ok", b"unknown error")
+    assert lib.zk_strerror(-99) == b"unknown error"
+
+
+def _gpu_present():
+    return _lib.lib().zk_device_count() > 0
+
+
+@pytest.mark.skipif(_gpu_present(), reason="a GPU is visible")
+def test_fails_loudly_without_a_gpu():
+    """The product path has no CPU fallback: every compute entry point reports ZK_ERR_HIP."""
+    lib = _lib.lib()
+    assert lib.zk_device_count() == 0
+    assert lib.zk_init(0) == -5
+    assert b"no HIP device" in lib.zk_last_error()
+    buf = (C.c_uint8 * 64)()
+    assert lib.zk_fr_ntt(buf, 1, 0) == -5
+    out = (C.c_uint8 * 96)()
+    g = O.g1_generator()
+    assert lib.zk_msm_g1(g, C.c_size_t(1), P.fr_to_bytes(1), C.c_size_t(1), 0, out) == -5
+    from zukelang_amd.curve import FFT_Fr
+    with pytest.raises(_lib.ZkError) as e:
+        FFT_Fr.fft(P.fr_to_bytes(1) * 2, 1)
+    assert e.value.code == -5
+
+
+def test_argument_errors_need_no_gpu():
+    lib = _lib.lib()
+    out = (C.c_uint8 * 96)()
+    g = O.g1_generator()
+    # curve.ml:116 invalid_arg "apply_powers": more coefficients than points
+    assert lib.zk_msm_g1(g, C.c_size_t(1), P.fr_to_bytes(1) * 2, C.c_size_t(2), 0, out) == -6
+    assert lib.zk_msm_g1(g, C.c_size_t(1), P.fr_to_bytes(1), C.c_size_t(1), 0, None) == -1
+    assert lib.zk_fr_ntt(None, 3, 0) == -1
+    assert lib.zk_groth16_pk_free(C.c_uint64(12345)) == -7
+    n = C.c_size_t(99)
+    assert lib.zk_fr_poly_mul(None, C.c_size_t(0), None, C.c_size_t(0), None, C.byref(n)) == 0 and n.value == 0
+
+
+def test_compress_matches_oracle():
+    """to_compressed_bytes (curve.ml:199,208) is pure byte logic in the library."""
+    lib = _lib.lib()
+    for k in (1, 2, 3, 5, 12345, P.R - 1, P.R - 2, 0x1234567890ABCDEF):
+        p1 = O.g1_mul(O.g1_generator(), P.fr_to_bytes(k))
+        p2 = O.g2_mul(O.g2_generator(), P.fr_to_bytes(k))
+        o1 = (C.c_uint8 * 48)()
+        o2 = (C.c_uint8 * 96)()
+        assert lib.zk_g1_compress(p1, o1) == 0 and bytes(o1) == O.g1_compress(p1)
+        assert lib.zk_g2_compress(p2, o2) == 0 and bytes(o2) == O.g2_compress(p2)
+    inf1 = bytes([0x40]) + bytes(95)
+    o1 = (C.c_uint8 * 48)()
+    assert lib.zk_g1_compress(inf1, o1) == 0 and bytes(o1) == bytes([0xC0]) + bytes(47)

@@ -34,6 +34,7 @@ struct Slot {
     hipStream_t s0 = nullptr, s1 = nullptr, s2 = nullptr;     // C + Fr stage | B (G2) | A
     hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, done = nullptr;
     uint8_t* host = nullptr;            // pinned: proof 384 B | flag 4 B | r 32 B | s 32 B
+    uint8_t* host_partial = nullptr;    // pinned: 768 B of raw partial sums (sharded mode)
     bool busy = false, serial = false;
     ~Slot() {
         if (s0) { (void)hipStreamDestroy(s0); if (!serial) { (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2); } }
@@ -134,7 +135,8 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
         HIPCHK(hipEventCreateWithFlags(&sl->join1, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->join2, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
-        HIPCHK(hipHostMalloc((void**)&sl->host, 512, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&sl->host, 512 + ZK_GROTH16_PARTIAL_BYTES, hipHostMallocDefault));
+        sl->host_partial = sl->host + 512;
         k.slots[idx] = std::move(sl);
     }
     *out = k.slots[idx].get();
@@ -296,17 +298,32 @@ int zk_groth16_set_witness(uint64_t handle, const uint8_t* sol) {
     k->have_witness = true;
     return ZK_OK;
 }
-int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
-                             uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]) {
+int zk_groth16_prove_partial_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    if (!r || !s || !partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial: null argument");
+    if (!r || !s) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_async: null argument");
     Slot* sl;
-    ZKCHK(slot_get(*k, 0, &sl));
+    ZKCHK(slot_get(*k, slot, &sl));
     ZKCHK(prove_enqueue(*k, *sl, sol, r, s, true));      // raw XYZZ partial sums: no affine conversion
-    ZKCHK(prove_finish(*sl));
-    HIPCHK(hipMemcpy(partial, sl->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost));
+    // the 768-byte partial block follows the proof on the slot's stream into pinned memory
+    HIPCHK(hipMemcpyAsync(sl->host_partial, sl->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost, sl->s0));
+    HIPCHK(hipEventRecord(sl->done, sl->s0));
     return ZK_OK;
+}
+int zk_groth16_prove_partial_wait(uint64_t handle, uint32_t slot, uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (!partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait: null");
+    if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait: slot never used");
+    Slot& sl = *k->slots[slot];
+    ZKCHK(prove_finish(sl));
+    memcpy(partial, sl.host_partial, ZK_GROTH16_PARTIAL_BYTES);
+    return ZK_OK;
+}
+int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
+                             uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]) {
+    ZKCHK(zk_groth16_prove_partial_async(handle, sol, r, s, 0));
+    return zk_groth16_prove_partial_wait(handle, 0, partial);
 }
 int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[384]) {
     if (!partials || !proof || world == 0) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_combine: bad argument");

@@ -94,6 +94,42 @@ def _lagrange_at(n, tau):
     return lag, zt
 
 
+def all_gather_bytes(part, world):
+    """The exchange step of the point-sharded prover: every rank contributes one
+    fixed-size uint8 block, every rank receives all of them in rank order.  RCCL on the GPU box
+    (backend nccl), gloo in the CPU tests.  EC addition is not an RCCL reduction operator, so this
+    is an all-gather of raw bytes followed by a local EC reduction."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(part, dtype=np.uint8).copy())
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.ascontiguousarray(torch.cat(out).cpu().numpy())
+
+
+def msm_scalar_vectors(n, v, w, h, wit, mid, r, s):
+    """Host mirror (Python ints) of the library's k_groth16_scalars: the three scalar vectors laid
+    over the key pools g1 = a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid and g2 = b2 | d2 | ti2[n+2]:
+      A = <g1, scalA>,  C = <g1, scalC>,  B = <g2, scalB>
+    with s*A + r*B1 - r*s*delta folded into C (see groth16.hip)."""
+    P = FR_MODULUS
+    pad = lambda x, k: list(x) + [0] * (k - len(x))
+    v, w, h = pad(v, n), pad(w, n), pad(h, n - 1)
+    wm = [wit[k] for k in range(len(mid)) if mid[k]]
+    scalA = [1, r, 0] + v + [0, 0] + [0] * (n - 1) + [0] * len(wm)
+    scalC = [s, r * s % P, r] + [(s * v[i] + r * w[i]) % P for i in range(n)] + [0, 0] + h + wm
+    scalB = [1, s] + w + [0, 0]
+    return scalA, scalC, scalB
+
+
+def shard_bounds(size, rank, world):
+    """Contiguous slice [lo, hi) of a base pool owned by `rank` (the same rule as the library's
+    zk_groth16_pk_upload_sharded: lo = size*rank/world)."""
+    return size * rank // world, size * (rank + 1) // world
+
+
 class Groth16:
     @staticmethod
     def keygen(rng, circuit: R1CS):
@@ -200,7 +236,7 @@ class Groth16:
             rc = _lib.lib().zk_groth16_prove(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), _p(out))
         else:
             part = self.prove_partial(w, rb, sb)
-            gathered = self._all_gather(part)
+            gathered = all_gather_bytes(part, self.world)
             rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
         if rc == ZK_ERR_REMAINDER:
             raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
@@ -210,14 +246,23 @@ class Groth16:
 
     def prove_async(self, sol, r, s, slot):
         """Enqueue one proof on `slot` (0..7) and return; `prove_wait(slot)` collects it.  Several
-        slots keep several proofs in flight on one key."""
+        slots keep several proofs in flight on one key.  On a sharded key the slot produces this
+        rank's partial sums; prove_wait then runs the exchange (all-gather) and the combine."""
         w = None if sol is None else self._sol_bytes(sol)
         rb, sb = fr_bytes([r]), fr_bytes([s])
-        _lib.check(_lib.lib().zk_groth16_prove_async(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), C.c_uint32(slot)))
+        fn = _lib.lib().zk_groth16_prove_async if self.world == 1 else _lib.lib().zk_groth16_prove_partial_async
+        _lib.check(fn(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), C.c_uint32(slot)))
 
     def prove_wait(self, slot):
         out = np.zeros(384, dtype=np.uint8)
-        rc = _lib.lib().zk_groth16_prove_wait(self.handle, C.c_uint32(slot), _p(out))
+        if self.world == 1:
+            rc = _lib.lib().zk_groth16_prove_wait(self.handle, C.c_uint32(slot), _p(out))
+        else:
+            part = np.zeros(768, dtype=np.uint8)
+            rc = _lib.lib().zk_groth16_prove_partial_wait(self.handle, C.c_uint32(slot), _p(part))
+            if rc == 0:
+                gathered = all_gather_bytes(part, self.world)
+                rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
         if rc == ZK_ERR_REMAINDER:
             raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
         _lib.check(rc)
@@ -231,18 +276,6 @@ class Groth16:
             raise AssertionError("Polynomial.is_zero rem")
         _lib.check(rc)
         return part
-
-    def _all_gather(self, part):
-        """The exchange step of SURVEY 8e: all-gather of the raw partial sums (768 B per rank) --
-        RCCL on the GPU box (backend nccl), gloo in the CPU tests."""
-        import torch
-        import torch.distributed as dist
-        t = torch.from_numpy(part.copy())
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = t.to(dev)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t)
-        return np.ascontiguousarray(torch.cat(out).cpu().numpy())
 
     def qap_eval(self, sol):
         """QAP.eval (QAP.ml:120-135): coefficient vectors (v, w, h) padded with zeros to n, n, n-1."""
