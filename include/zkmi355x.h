@@ -143,6 +143,22 @@ int zk_groth16_prove_partial_async(uint64_t handle, const uint8_t* sol, const ui
 int zk_groth16_prove_partial_wait(uint64_t handle, uint32_t slot, uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]);
 int zk_groth16_combine(const uint8_t* partials /* world * 768 */, uint32_t world, uint8_t proof[384]);
 
+/* ---- protocol seam: Pinocchio.Make(C).{NonZK,ZK}.prove (src/pinocchio/pinocchio.ml:536-538,559-561) ----
+ * Evaluation key of pinocchio.ml:37-60 flattened per group (maps in Var.Map key order over I_mid, resp.
+ * over all m variables for v_all / w_all; lists as stored):
+ *   g1: vv | yy | vav | yay | bvwy  (n_mid each) | si (n+1) | v_all (m) | w_all (m) | vt | yt | vavt | yayt | vbt | wbt | ybt
+ *   g2: ww | waw (n_mid each) | si2 (n+1, not used by the prover) | wt | wawt
+ * zk_pinocchio_prove = ZKCompute.f (:427-514) with dv, dw, dy supplied in the order the reference draws
+ * them (:428-430); all three zero gives Compute.f (:210-248), i.e. NonZK.prove.
+ * proof: vv (G1) | ww (G2) | yy | h | vavv | waww (G2) | yayy | bvwy = 960 B uncompressed, the field order
+ * of Compute.proof (:195-208).  ZK_ERR_REMAINDER as for Groth16. */
+int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
+                           const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
+                           const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
+int zk_pinocchio_pk_free(uint64_t handle);
+int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32],
+                       const uint8_t dy[32], uint8_t proof[960]);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------
  * With profiling on, kernel families are bracketed by HIP events on the stream they run on;
  * zk_profile_get returns the summed milliseconds and launch count since the last reset. */

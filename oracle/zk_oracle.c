@@ -604,3 +604,221 @@ API void orc_r1cs_spmv(uint32_t n, const uint32_t *ptr, const uint32_t *col, con
         fr_to_bytes(out + 32 * (size_t)g, &acc);
     }
 }
+
+/* ================================================================== Pinocchio Protocol 2
+ * src/pinocchio/pinocchio.ml.  toxic = rv, rw, s, av, aw, ay, b, gm in the order KeyGen.generate draws
+ * them (:83-91); ry = rv*rw (:93).  Every key element is a known multiple of a generator, so the key is
+ * returned as exponents (the points are `G.of_Fr` of them: oracle g1_mul at small n, the fixed-base
+ * kernel at large n -- spot-checked against the oracle).
+ *
+ * literal = 1: u_k(s) by Poly.apply on the dense QAP polynomials, as map_apply_s does (:104-109);
+ * literal = 0: u_k(s) = sum_g M[g,k] * l_g(s) through the Lagrange basis of the integer domain
+ *              (same field element, O(nnz + n), any n).
+ *
+ * G1 exponent layout (n_mid = |mids|, in variable order):
+ *   vv[n_mid] | yy[n_mid] | vav[n_mid] | yay[n_mid] | bvwy[n_mid] | si[n+1] | v_all[m] | w_all[m] |
+ *   vt | yt | vavt | yayt | vbt | wbt | ybt
+ * G2: ww[n_mid] | waw[n_mid] | si2[n+1] | wt | wawt
+ * vkey G1: one | aw | bgm | vv_io[n_io] | yy_io[n_io]        vkey G2: one2 | av | ay | gm2 | bgm2 | yt | ww_io[n_io] */
+static void pin_uks(fr_t *vk, fr_t *wk, fr_t *yk, fr_t *t_at_s, uint32_t n, uint32_t m, const qap_t *q,
+                    const csr_t *Ms, const fr_t *s, int literal) {
+    if (literal) {
+        for (uint32_t k = 0; k < m; k++) {
+            poly_apply(&vk[k], q->v + (size_t)k * n, n, s);
+            poly_apply(&wk[k], q->w + (size_t)k * n, n, s);
+            poly_apply(&yk[k], q->y + (size_t)k * n, n, s);
+        }
+        poly_apply(t_at_s, q->target, n + 1, s);
+        return;
+    }
+    lagtab_t T; lagrange_at(&T, n, s);
+    *t_at_s = T.zt;
+    fr_t *outs[3] = {vk, wk, yk};
+    for (int qi = 0; qi < 3; qi++) {
+        for (uint32_t k = 0; k < m; k++) outs[qi][k] = FR_ZERO;
+        for (uint32_t g = 0; g < n; g++)
+            for (uint32_t e = Ms[qi].ptr[g]; e < Ms[qi].ptr[g + 1]; e++) {
+                fr_t c, x; fr_from_bytes(&c, Ms[qi].val + 32 * (size_t)e);
+                fr_mul(&x, &c, &T.lag[g]);
+                fr_add(&outs[qi][Ms[qi].col[e]], &outs[qi][Ms[qi].col[e]], &x);
+            }
+    }
+    free(T.lag);
+}
+API void orc_pinocchio_keygen_exponents(void *hq /* may be NULL when literal = 0 */, uint32_t n, uint32_t m,
+                                        const uint32_t *l_ptr, const uint32_t *l_col, const uint8_t *l_val,
+                                        const uint32_t *r_ptr, const uint32_t *r_col, const uint8_t *r_val,
+                                        const uint32_t *o_ptr, const uint32_t *o_col, const uint8_t *o_val,
+                                        const uint8_t *mid, const uint8_t toxic[8 * 32], int literal,
+                                        uint8_t *pk_g1, uint8_t *pk_g2, uint8_t *vk_g1, uint8_t *vk_g2) {
+    fr_t rv, rw, s, av, aw, ay, b, gm, ry;
+    fr_from_bytes(&rv, toxic); fr_from_bytes(&rw, toxic + 32); fr_from_bytes(&s, toxic + 64);
+    fr_from_bytes(&av, toxic + 96); fr_from_bytes(&aw, toxic + 128); fr_from_bytes(&ay, toxic + 160);
+    fr_from_bytes(&b, toxic + 192); fr_from_bytes(&gm, toxic + 224);
+    fr_mul(&ry, &rv, &rw);                                                   /* :93 */
+    const csr_t Ms[3] = {{l_ptr, l_col, l_val}, {r_ptr, r_col, r_val}, {o_ptr, o_col, o_val}};
+    fr_t *vk = malloc(sizeof(fr_t) * m), *wk = malloc(sizeof(fr_t) * m), *yk = malloc(sizeof(fr_t) * m), t;
+    pin_uks(vk, wk, yk, &t, n, m, (const qap_t *)hq, Ms, &s, literal);
+    uint32_t n_mid = 0;
+    for (uint32_t k = 0; k < m; k++) n_mid += mid[k] ? 1 : 0;
+    uint8_t *o = pk_g1;
+#define PUT(ptr, val) do { fr_to_bytes(ptr, &(val)); ptr += 32; } while (0)
+    fr_t x, y, z;
+    for (uint32_t k = 0; k < m; k++) if (mid[k]) { fr_mul(&x, &rv, &vk[k]); PUT(o, x); }                       /* vv   :113 */
+    for (uint32_t k = 0; k < m; k++) if (mid[k]) { fr_mul(&x, &ry, &yk[k]); PUT(o, x); }                       /* yy   :118 */
+    for (uint32_t k = 0; k < m; k++) if (mid[k]) { fr_mul(&x, &rv, &vk[k]); fr_mul(&x, &x, &av); PUT(o, x); }  /* vav  :126 */
+    for (uint32_t k = 0; k < m; k++) if (mid[k]) { fr_mul(&x, &ry, &yk[k]); fr_mul(&x, &x, &ay); PUT(o, x); }  /* yay  :130 */
+    for (uint32_t k = 0; k < m; k++) if (mid[k]) {                                                            /* bvwy :137-140 */
+        fr_mul(&x, &rv, &vk[k]); fr_mul(&y, &rw, &wk[k]); fr_mul(&z, &ry, &yk[k]);
+        fr_add(&x, &x, &y); fr_add(&x, &x, &z); fr_mul(&x, &x, &b); PUT(o, x);
+    }
+    fr_t si = FR_ONE;
+    for (uint32_t i = 0; i <= n; i++) { PUT(o, si); fr_mul(&si, &si, &s); }                                  /* si = powers d s, d = n :133 */
+    for (uint32_t k = 0; k < m; k++) PUT(o, vk[k]);                                                          /* v_all :153 */
+    for (uint32_t k = 0; k < m; k++) PUT(o, wk[k]);                                                          /* w_all :156 */
+    fr_t vt, wt, yt;
+    fr_mul(&vt, &rv, &t); fr_mul(&wt, &rw, &t); fr_mul(&yt, &ry, &t);
+    PUT(o, vt);                                                                                              /* vt   :142 */
+    PUT(o, yt);                                                                                              /* yt   :144 */
+    fr_mul(&x, &vt, &av); PUT(o, x);                                                                         /* vavt :145 */
+    fr_mul(&x, &yt, &ay); PUT(o, x);                                                                         /* yayt :147 */
+    fr_mul(&x, &vt, &b); PUT(o, x);                                                                          /* vbt  :148 */
+    fr_mul(&x, &wt, &b); PUT(o, x);                                                                          /* wbt  :149 */
+    fr_mul(&x, &yt, &b); PUT(o, x);                                                                          /* ybt  :150 */
+    o = pk_g2;
+    for (uint32_t k = 0; k < m; k++) if (mid[k]) { fr_mul(&x, &rw, &wk[k]); PUT(o, x); }                       /* ww   :116 */
+    for (uint32_t k = 0; k < m; k++) if (mid[k]) { fr_mul(&x, &rw, &wk[k]); fr_mul(&x, &x, &aw); PUT(o, x); }  /* waw  :128 */
+    si = FR_ONE;
+    for (uint32_t i = 0; i <= n; i++) { PUT(o, si); fr_mul(&si, &si, &s); }                                  /* si2  :134 */
+    PUT(o, wt);                                                                                              /* wt   :143 */
+    fr_mul(&x, &wt, &aw); PUT(o, x);                                                                         /* wawt :146 */
+    if (vk_g1 && vk_g2) {
+        o = vk_g1;
+        fr_t one = FR_ONE, bg; fr_mul(&bg, &gm, &b);
+        PUT(o, one); PUT(o, aw); PUT(o, bg);                                                                 /* one, aw, bgm :163-169 */
+        for (uint32_t k = 0; k < m; k++) if (!mid[k]) { fr_mul(&x, &rv, &vk[k]); PUT(o, x); }                  /* vv_io :172 */
+        for (uint32_t k = 0; k < m; k++) if (!mid[k]) { fr_mul(&x, &ry, &yk[k]); PUT(o, x); }                  /* yy_io :174 */
+        o = vk_g2;
+        PUT(o, one); PUT(o, av); PUT(o, ay); PUT(o, gm); PUT(o, bg); PUT(o, yt);                             /* one2, av, ay, gm2, bgm2, yt */
+        for (uint32_t k = 0; k < m; k++) if (!mid[k]) { fr_mul(&x, &rw, &wk[k]); PUT(o, x); }                  /* ww_io :173 */
+    }
+#undef PUT
+    free(vk); free(wk); free(yk);
+}
+
+/* ZKCompute.f (pinocchio.ml:427-514), LITERAL: every dot / apply_powers is a left fold of single
+ * scalar multiplications (curve.ml:91-118).  Compute.f (:210-248) is the same with dv = dw = dy = 0
+ * and without the `t` term (identical group elements).  Key points in the layout above.
+ * proof = vv | ww(G2) | yy | h | vavv | waww(G2) | yayy | bvwy  (Compute.proof field order, :195-208). */
+API int orc_pinocchio_prove(void *hq, const uint8_t *pk_g1, const uint8_t *pk_g2, const uint8_t *mid,
+                            const uint8_t *sol, const uint8_t dv_[32], const uint8_t dw_[32], const uint8_t dy_[32],
+                            uint8_t proof[960]) {
+    qap_t *q = hq; uint32_t n = q->n, m = q->m;
+    uint32_t n_mid = 0;
+    for (uint32_t k = 0; k < m; k++) n_mid += mid[k] ? 1 : 0;
+    fr_t *c = malloc(sizeof(fr_t) * m);
+    for (uint32_t k = 0; k < m; k++) fr_from_bytes(&c[k], sol + 32 * (size_t)k);
+    fr_t *vv_ = malloc(sizeof(fr_t) * n * 3), *p = malloc(sizeof(fr_t) * (2 * (size_t)n + 2)), *h = malloc(sizeof(fr_t) * (2 * (size_t)n + 2));
+    size_t np, nh;
+    int rc = qap_eval(q, c, vv_, vv_ + n, vv_ + 2 * n, p, &np, h, &nh);          /* :560 */
+    if (rc) { free(c); free(vv_); free(p); free(h); return rc; }
+    fr_t dv, dw, dy; fr_from_bytes(&dv, dv_); fr_from_bytes(&dw, dw_); fr_from_bytes(&dy, dy_);
+    const uint8_t *VV = pk_g1, *YY = VV + 96 * (size_t)n_mid, *VAV = YY + 96 * (size_t)n_mid, *YAY = VAV + 96 * (size_t)n_mid,
+                  *BV = YAY + 96 * (size_t)n_mid, *SI = BV + 96 * (size_t)n_mid, *VALL = SI + 96 * (size_t)(n + 1),
+                  *WALL = VALL + 96 * (size_t)m, *ONES = WALL + 96 * (size_t)m;
+    const uint8_t *WW = pk_g2, *WAW = WW + 192 * (size_t)n_mid, *ONES2 = WAW + 192 * (size_t)n_mid + 192 * (size_t)(n + 1);
+    g1_t acc, P1, T; g2_t acc2, P2;
+#define DOT1(dst, base)                                                                                    \
+    do { g1_set_inf(&acc); size_t j = 0;                                                                   \
+         for (uint32_t k = 0; k < m; k++) if (mid[k]) { g1_from_bytes(&P1, (base) + 96 * j++); g1_mul(&P1, &P1, &c[k]); g1_add(&acc, &P1, &acc); } \
+         dst = acc; } while (0)
+#define DOT2(dst, base)                                                                                    \
+    do { g2_set_inf(&acc2); size_t j = 0;                                                                  \
+         for (uint32_t k = 0; k < m; k++) if (mid[k]) { g2_from_bytes(&P2, (base) + 192 * j++); g2_mul(&P2, &P2, &c[k]); g2_add(&acc2, &P2, &acc2); } \
+         dst = acc2; } while (0)
+    g1_t vv, yy, hh, vavv, yayy, bvwy, vall, wall, tt; g2_t ww, waww;
+    /* t = apply_powers target si (:431) */
+    g1_set_inf(&tt);
+    for (uint32_t i = 0; i <= n; i++) { g1_from_bytes(&P1, SI + 96 * (size_t)i); g1_mul(&P1, &P1, &q->target[i]); g1_add(&tt, &P1, &tt); }
+    DOT1(vv, VV);   g1_from_bytes(&P1, ONES + 96 * 0); g1_mul(&P1, &P1, &dv); g1_add(&vv, &vv, &P1);          /* :438-439 */
+    DOT2(ww, WW);   g2_from_bytes(&P2, ONES2);         g2_mul(&P2, &P2, &dw); g2_add(&ww, &ww, &P2);          /* :442-443 */
+    DOT1(yy, YY);   g1_from_bytes(&P1, ONES + 96 * 1); g1_mul(&P1, &P1, &dy); g1_add(&yy, &yy, &P1);          /* :446-447 */
+    g1_set_inf(&hh);                                                                                           /* :450 */
+    if (nh > n + 1) { rc = -2; goto out; }
+    for (size_t i = 0; i < nh; i++) { g1_from_bytes(&P1, SI + 96 * i); g1_mul(&P1, &P1, &h[i]); g1_add(&hh, &P1, &hh); }
+    g1_set_inf(&vall); g1_set_inf(&wall);                                                                      /* :483-484 dot over all of c */
+    for (uint32_t k = 0; k < m; k++) {
+        g1_from_bytes(&P1, VALL + 96 * (size_t)k); g1_mul(&P1, &P1, &c[k]); g1_add(&vall, &P1, &vall);
+        g1_from_bytes(&P1, WALL + 96 * (size_t)k); g1_mul(&P1, &P1, &c[k]); g1_add(&wall, &P1, &wall);
+    }
+    g1_mul(&T, &vall, &dw); g1_add(&hh, &hh, &T);                                                              /* :485 */
+    g1_mul(&T, &wall, &dv); g1_add(&hh, &hh, &T);
+    g1_mul(&T, &tt, &dv); g1_mul(&T, &T, &dw); g1_add(&hh, &hh, &T);
+    g1_generator(&T); g1_mul(&T, &T, &dy); g1_neg(&T, &T); g1_add(&hh, &hh, &T);
+    DOT1(vavv, VAV); g1_from_bytes(&P1, ONES + 96 * 2); g1_mul(&P1, &P1, &dv); g1_add(&vavv, &vavv, &P1);      /* :489-490 */
+    DOT2(waww, WAW); g2_from_bytes(&P2, ONES2 + 192);   g2_mul(&P2, &P2, &dw); g2_add(&waww, &waww, &P2);      /* :493-494 */
+    DOT1(yayy, YAY); g1_from_bytes(&P1, ONES + 96 * 3); g1_mul(&P1, &P1, &dy); g1_add(&yayy, &yayy, &P1);      /* :497-498 */
+    DOT1(bvwy, BV);                                                                                            /* :500-505 */
+    g1_from_bytes(&P1, ONES + 96 * 4); g1_mul(&P1, &P1, &dv); g1_add(&bvwy, &bvwy, &P1);
+    g1_from_bytes(&P1, ONES + 96 * 5); g1_mul(&P1, &P1, &dw); g1_add(&bvwy, &bvwy, &P1);
+    g1_from_bytes(&P1, ONES + 96 * 6); g1_mul(&P1, &P1, &dy); g1_add(&bvwy, &bvwy, &P1);
+    g1_to_bytes(proof, &vv); g2_to_bytes(proof + 96, &ww); g1_to_bytes(proof + 288, &yy); g1_to_bytes(proof + 384, &hh);
+    g1_to_bytes(proof + 480, &vavv); g2_to_bytes(proof + 576, &waww); g1_to_bytes(proof + 768, &yayy); g1_to_bytes(proof + 864, &bvwy);
+out:
+    free(c); free(vv_); free(p); free(h);
+    return rc;
+#undef DOT1
+#undef DOT2
+}
+
+/* Trapdoor evaluation of the ZK proof (size-independent exact check, NOT a reference algorithm):
+ *   vv' = [rv (v_mid(s) + dv t)]_1, ww' = [rw (w_mid(s) + dw t)]_2, yy' = [ry (y_mid(s) + dy t)]_1,
+ *   h'  = [h(s) + dw v(s) + dv w(s) + dv dw t - dy]_1,  h(s) = (v(s) w(s) - y(s)) / t,
+ *   vavv' = av vv', waww' = aw ww', yayy' = ay yy',
+ *   bvwy' = [b (rv v_mid + rw w_mid + ry y_mid) + b t (rv dv + rw dw + ry dy)]_1 */
+API void orc_pinocchio_prove_trapdoor(uint32_t n, uint32_t m,
+                                      const uint32_t *l_ptr, const uint32_t *l_col, const uint8_t *l_val,
+                                      const uint32_t *r_ptr, const uint32_t *r_col, const uint8_t *r_val,
+                                      const uint32_t *o_ptr, const uint32_t *o_col, const uint8_t *o_val,
+                                      const uint8_t *mid, const uint8_t *sol, const uint8_t toxic[8 * 32],
+                                      const uint8_t dv_[32], const uint8_t dw_[32], const uint8_t dy_[32], uint8_t proof[960]) {
+    fr_t rv, rw, s, av, aw, ay, b, ry, dv, dw, dy;
+    fr_from_bytes(&rv, toxic); fr_from_bytes(&rw, toxic + 32); fr_from_bytes(&s, toxic + 64);
+    fr_from_bytes(&av, toxic + 96); fr_from_bytes(&aw, toxic + 128); fr_from_bytes(&ay, toxic + 160);
+    fr_from_bytes(&b, toxic + 192);
+    fr_mul(&ry, &rv, &rw);
+    fr_from_bytes(&dv, dv_); fr_from_bytes(&dw, dw_); fr_from_bytes(&dy, dy_);
+    fr_t *c = malloc(sizeof(fr_t) * m);
+    for (uint32_t k = 0; k < m; k++) fr_from_bytes(&c[k], sol + 32 * (size_t)k);
+    lagtab_t T; lagrange_at(&T, n, &s);
+    csr_t L = {l_ptr, l_col, l_val}, Rm = {r_ptr, r_col, r_val}, O = {o_ptr, o_col, o_val};
+    fr_t vs, vm, ws, wm, ys, ym, t = T.zt;
+    csr_at_tau(&vs, &vm, &L, n, c, mid, T.lag);
+    csr_at_tau(&ws, &wm, &Rm, n, c, mid, T.lag);
+    csr_at_tau(&ys, &ym, &O, n, c, mid, T.lag);
+    fr_t e_vv, e_ww, e_yy, e_h, x, y, tinv;
+    fr_mul(&x, &dv, &t); fr_add(&x, &x, &vm); fr_mul(&e_vv, &rv, &x);
+    fr_mul(&x, &dw, &t); fr_add(&x, &x, &wm); fr_mul(&e_ww, &rw, &x);
+    fr_mul(&x, &dy, &t); fr_add(&x, &x, &ym); fr_mul(&e_yy, &ry, &x);
+    fr_inv(&tinv, &t);
+    fr_mul(&e_h, &vs, &ws); fr_sub(&e_h, &e_h, &ys); fr_mul(&e_h, &e_h, &tinv);
+    fr_mul(&x, &dw, &vs); fr_add(&e_h, &e_h, &x);
+    fr_mul(&x, &dv, &ws); fr_add(&e_h, &e_h, &x);
+    fr_mul(&x, &dv, &dw); fr_mul(&x, &x, &t); fr_add(&e_h, &e_h, &x);
+    fr_sub(&e_h, &e_h, &dy);
+    fr_t e_b;
+    fr_mul(&x, &rv, &vm); fr_mul(&y, &rw, &wm); fr_add(&x, &x, &y); fr_mul(&y, &ry, &ym); fr_add(&x, &x, &y); fr_mul(&e_b, &b, &x);
+    fr_mul(&x, &rv, &dv); fr_mul(&y, &rw, &dw); fr_add(&x, &x, &y); fr_mul(&y, &ry, &dy); fr_add(&x, &x, &y);
+    fr_mul(&x, &x, &t); fr_mul(&x, &x, &b); fr_add(&e_b, &e_b, &x);
+    g1_t g1, P1; g2_t g2, P2;
+    g1_generator(&g1); g2_generator(&g2);
+    g1_mul(&P1, &g1, &e_vv); g1_to_bytes(proof, &P1);
+    g2_mul(&P2, &g2, &e_ww); g2_to_bytes(proof + 96, &P2);
+    g1_mul(&P1, &g1, &e_yy); g1_to_bytes(proof + 288, &P1);
+    g1_mul(&P1, &g1, &e_h); g1_to_bytes(proof + 384, &P1);
+    fr_mul(&x, &e_vv, &av); g1_mul(&P1, &g1, &x); g1_to_bytes(proof + 480, &P1);
+    fr_mul(&x, &e_ww, &aw); g2_mul(&P2, &g2, &x); g2_to_bytes(proof + 576, &P2);
+    fr_mul(&x, &e_yy, &ay); g1_mul(&P1, &g1, &x); g1_to_bytes(proof + 768, &P1);
+    g1_mul(&P1, &g1, &e_b); g1_to_bytes(proof + 864, &P1);
+    free(c); free(T.lag);
+}

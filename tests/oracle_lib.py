@@ -206,3 +206,68 @@ def groth16_setup_exponents(n, m, L, R, O, mid, toxic, want_io=True):
     eio = _buf(32 * max(nio, 1))
     lib.orc_groth16_setup_exponents(n, m, *L.args(), *R.args(), *O.args(), _b(bytes(mid)), _b(toxic), e1, e2, eio if want_io else None)
     return bytes(e1), bytes(e2), bytes(eio)[:32 * nio]
+
+
+# ---------------------------------------------------------------- Pinocchio Protocol 2
+def pinocchio_sizes(n, m, mid):
+    nmid = int(np.asarray(mid, dtype=np.int64).sum()); nio = m - nmid
+    return {"n_mid": nmid, "n_io": nio, "pk_g1": 5 * nmid + (n + 1) + 2 * m + 7, "pk_g2": 2 * nmid + (n + 1) + 2,
+            "vk_g1": 3 + 2 * nio, "vk_g2": 6 + nio}
+
+
+def pinocchio_keygen_exponents(qap_or_none, n, m, L, R, O, mid, toxic, literal):
+    sz = pinocchio_sizes(n, m, mid)
+    e1 = _buf(32 * sz["pk_g1"]); e2 = _buf(32 * sz["pk_g2"]); v1 = _buf(32 * sz["vk_g1"]); v2 = _buf(32 * sz["vk_g2"])
+    lib.orc_pinocchio_keygen_exponents(qap_or_none.h if qap_or_none is not None else None, n, m, *L.args(), *R.args(), *O.args(),
+                                       _b(bytes(mid)), _b(toxic), int(literal), e1, e2, v1, v2)
+    return bytes(e1), bytes(e2), bytes(v1), bytes(v2)
+
+
+def pinocchio_prove(qap, pk_g1, pk_g2, mid, sol, dv, dw, dy):
+    out = _buf(960)
+    rc = lib.orc_pinocchio_prove(qap.h, _b(pk_g1), _b(pk_g2), _b(bytes(mid)), _b(sol), _b(dv), _b(dw), _b(dy), out)
+    return rc, bytes(out)
+
+
+def pinocchio_prove_trapdoor(n, m, L, R, O, mid, sol, toxic, dv, dw, dy):
+    out = _buf(960)
+    lib.orc_pinocchio_prove_trapdoor(n, m, *L.args(), *R.args(), *O.args(), _b(bytes(mid)), _b(sol), _b(toxic), _b(dv), _b(dw), _b(dy), out)
+    return bytes(out)
+
+
+def points_of_exponents_g1(ex):
+    g = g1_generator()
+    return b"".join(g1_mul(g, ex[32 * i:32 * i + 32]) for i in range(len(ex) // 32))
+
+
+def points_of_exponents_g2(ex):
+    g = g2_generator()
+    return b"".join(g2_mul(g, ex[32 * i:32 * i + 32]) for i in range(len(ex) // 32))
+
+
+def pinocchio_verify(vk_g1, vk_g2, io_values, proof):
+    """Verify.f (src/pinocchio/pinocchio.ml:254-420) with the Python big-int pairing: the four
+    knowledge-of-coefficient checks (:285,298,311,361-366) and the divisibility check (:418-420).
+    vk layouts as in orc_pinocchio_keygen_exponents; io_values = public c_k in variable order."""
+    from oracle import pyref as P
+    nio = len(io_values)
+    G1p = lambda b: P.g1_from_bytes(b)
+    G2p = lambda b: P.g2_from_bytes(b)
+    one, aw, bgm = (G1p(vk_g1[96 * i:96 * i + 96]) for i in range(3))
+    vv_io = [G1p(vk_g1[96 * (3 + i):96 * (4 + i)]) for i in range(nio)]
+    yy_io = [G1p(vk_g1[96 * (3 + nio + i):96 * (4 + nio + i)]) for i in range(nio)]
+    one2, av, ay, gm2, bgm2, yt = (G2p(vk_g2[192 * i:192 * i + 192]) for i in range(6))
+    ww_io = [G2p(vk_g2[192 * (6 + i):192 * (7 + i)]) for i in range(nio)]
+    vv, ww, yy, h = G1p(proof[:96]), G2p(proof[96:288]), G1p(proof[288:384]), G1p(proof[384:480])
+    vavv, waww, yayy, bvwy = G1p(proof[480:576]), G2p(proof[576:768]), G1p(proof[768:864]), G1p(proof[864:960])
+    neg = P.pt_neg
+    ok = True
+    ok &= P.pairing_product_is_one([(vv, av), (neg(vavv), one2)])                       # :285
+    ok &= P.pairing_product_is_one([(aw, ww), (neg(one), waww)])                        # :298
+    ok &= P.pairing_product_is_one([(yy, ay), (neg(yayy), one2)])                       # :311
+    ok &= P.pairing_product_is_one([(bvwy, gm2), (neg(vv), bgm2), (neg(bgm), ww), (neg(yy), bgm2)])   # :361-366
+    vio = wio = yio = None
+    for c, a, b_, d in zip(io_values, vv_io, ww_io, yy_io):
+        vio = P.pt_add(vio, P.pt_mul(a, c)); wio = P.pt_add(wio, P.pt_mul(b_, c)); yio = P.pt_add(yio, P.pt_mul(d, c))
+    ok &= P.pairing_product_is_one([(P.pt_add(vio, vv), P.pt_add(wio, ww)), (neg(P.pt_add(yio, yy)), one2), (neg(h), yt)])   # :418-420
+    return bool(ok)

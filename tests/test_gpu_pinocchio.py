@@ -1,0 +1,79 @@
+"""GPU parity: Pinocchio Protocol 2 prove (HIP) == the oracle's literal restatement of
+pinocchio.ml:427-514 (bit-exact), plus Verify.f (:254-420) with the oracle pairing."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import r1cs as RC
+from zukelang_amd import pinocchio as PIN
+from zukelang_amd.curve import G1, G2
+
+pytestmark = pytest.mark.gpu
+
+
+def frs(xs):
+    return b"".join(P.fr_to_bytes(x) for x in xs)
+
+
+def csrs(cs):
+    return [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+
+
+@pytest.mark.parametrize("maker,literal", [(lambda: RC.readme_circuit(3), True), (lambda: RC.iterated_cubic(6, 9), True),
+                                           (lambda: RC.iterated_cubic(64, 10), False), (lambda: RC.iterated_cubic(1000, 11), False)])
+def test_pinocchio_zk_and_nonzk_match_oracle(maker, literal):
+    cs, w = maker()
+    L, R_, Oo = csrs(cs)
+    st = P.fr_stream(0x5EED0003)
+    tox = [next(st) for _ in range(11)]
+    toxic = frs(tox[:8])
+    it = iter(tox)
+    rng = lambda: next(it)
+    pk, vk = PIN.ZK.keygen(rng, cs)                               # draws the 8 key scalars
+    ex = O.pinocchio_keygen_exponents(None, cs.n, cs.m, L, R_, Oo, cs.mid, toxic, False)
+    if cs.n <= 64:
+        assert bytes(pk.g1) == O.points_of_exponents_g1(ex[0]) and bytes(pk.g2) == O.points_of_exponents_g2(ex[1])
+        assert bytes(vk.g1) == O.points_of_exponents_g1(ex[2]) and bytes(vk.g2) == O.points_of_exponents_g2(ex[3])
+    prover = PIN.ZK(cs, pk)
+    proof = prover.prove(rng, w)                                  # draws dv, dw, dy = tox[8:11]
+    dv, dw, dy = (P.fr_to_bytes(x) for x in tox[8:])
+    assert proof.to_bytes() == O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), toxic, dv, dw, dy)
+    if literal:
+        q = O.QAP(cs.n, cs.m, L, R_, Oo)
+        rc, ref = O.pinocchio_prove(q, bytes(pk.g1), bytes(pk.g2), cs.mid, frs(w), dv, dw, dy)
+        assert rc == 0 and proof.to_bytes() == ref
+        io = [w[k] for k in range(cs.m) if not cs.mid[k]]
+        assert O.pinocchio_verify(bytes(vk.g1), bytes(vk.g2), io, proof.to_bytes())
+    prover.close()
+    nz = PIN.NonZK(cs, pk)
+    p0 = nz.prove(None, w)
+    z = P.fr_to_bytes(0)
+    assert p0.to_bytes() == O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), toxic, z, z, z)
+    w_bad = list(w)
+    w_bad[2] = (w_bad[2] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        nz.prove(None, w_bad)
+    nz.close()
+
+
+def test_pinocchio_2_18_trapdoor_and_verify():
+    """BASELINE config 5: Pinocchio Protocol-2 prove, 2^18 constraints."""
+    n = 1 << 18
+    cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0001)))
+    L, R_, Oo = csrs(cs)
+    st = P.fr_stream(0x5EED0003)
+    tox = [next(st) for _ in range(11)]
+    toxic = frs(tox[:8])
+    e1, e2, v1, v2 = O.pinocchio_keygen_exponents(None, cs.n, cs.m, L, R_, Oo, cs.mid, toxic, False)
+    pk = PIN.PKey(G1.of_Fr(e1), G2.of_Fr(e2))
+    for i in (0, n, len(e1) // 32 - 1):
+        assert bytes(pk.g1[96 * i:96 * i + 96]) == O.g1_mul(O.g1_generator(), e1[32 * i:32 * i + 32])
+    prover = PIN.ZK(cs, pk)
+    dv, dw, dy = tox[8:]
+    proof = prover.prove_with(w, dv, dw, dy)
+    assert proof.to_bytes() == O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), toxic, *(P.fr_to_bytes(x) for x in (dv, dw, dy)))
+    io = [w[k] for k in range(cs.m) if not cs.mid[k]]
+    assert O.pinocchio_verify(bytes(G1.of_Fr(v1)), bytes(G2.of_Fr(v2)), io, proof.to_bytes())
+    assert len(proof.to_compressed()) == 480
+    prover.close()

@@ -219,3 +219,33 @@ def test_msm_naive_matches_bigint_and_apply_powers_errors():
     rc, out = O.g1_msm_naive(bases1, frs(ss[:3]))
     assert rc == 0 and out == O.g1_mul(O.g1_generator(), frb(sum(k * s for k, s in zip(ks[:3], ss[:3])) % P.R))
     assert O.g1_msm_naive(b"", b"")[1] == P.g1_to_bytes(None)
+
+
+@pytest.mark.parametrize("maker", [lambda: RC.readme_circuit(3), lambda: RC.iterated_cubic(6, 0x77)])
+def test_pinocchio_literal_equals_trapdoor_and_verifies(maker):
+    """pinocchio.ml: KeyGen.generate (:77-189), ZKCompute.f (:427-514), Verify.f (:254-420)."""
+    cs, w = maker()
+    L, R_, Oo = csrs(cs)
+    q = O.QAP(cs.n, cs.m, L, R_, Oo)
+    st = P.fr_stream(0x5EED0003)
+    tox = [next(st) for _ in range(11)]
+    toxic, (dv, dw, dy) = frs(tox[:8]), (frb(x) for x in tox[8:])
+    lit = O.pinocchio_keygen_exponents(q, cs.n, cs.m, L, R_, Oo, cs.mid, toxic, True)      # Poly.apply on dense polys
+    fast = O.pinocchio_keygen_exponents(None, cs.n, cs.m, L, R_, Oo, cs.mid, toxic, False)  # Lagrange basis
+    assert lit == fast
+    pk1, pk2 = O.points_of_exponents_g1(lit[0]), O.points_of_exponents_g2(lit[1])
+    vk1, vk2 = O.points_of_exponents_g1(lit[2]), O.points_of_exponents_g2(lit[3])
+    sol = frs(w)
+    rc, proof = O.pinocchio_prove(q, pk1, pk2, cs.mid, sol, dv, dw, dy)
+    assert rc == 0
+    assert proof == O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, sol, toxic, dv, dw, dy)
+    io = [w[k] for k in range(cs.m) if not cs.mid[k]]
+    assert O.pinocchio_verify(vk1, vk2, io, proof)
+    # NonZK (Compute.f :210-248) = zero blinding; also verifies
+    z = frb(0)
+    rc, proof0 = O.pinocchio_prove(q, pk1, pk2, cs.mid, sol, z, z, z)
+    assert rc == 0 and proof0 != proof and O.pinocchio_verify(vk1, vk2, io, proof0)
+    # tampering breaks it
+    bad = bytearray(proof)
+    bad[384:480] = O.g1_add(bytes(proof[384:480]), O.g1_generator())
+    assert not O.pinocchio_verify(vk1, vk2, io, bytes(bad))

@@ -1,0 +1,143 @@
+"""Host-side mirror of `Pinocchio.Make(C).{NonZK, ZK} : Protocol.S` (src/pinocchio/pinocchio.mli:3-15)
+for the prove path, backed by the HIP library.
+
+  keygen rng circuit  -> (pkey, vkey)   pinocchio.ml:530-534 -> KeyGen.generate :77-189
+                                         (rng draws rv, rw, s, av, aw, ay, b, gm in that order, :83-91)
+  ZK.prove rng sol    -> proof           :559-561 -> ZKCompute.f :427-514 (draws dv, dw, dy, :428-430)
+  NonZK.prove _ sol   -> proof           :536-538 -> Compute.f :210-248 (no randomness)
+
+Key and proof layouts are those of include/zkmi355x.h.  An unsatisfied witness raises AssertionError
+(QAP.ml:134).  `verify` (13 pairings, :254-420) is outside the accelerated path (scope row f1).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .curve import G1, G2
+from .groth16 import _csr, _lagrange_at, _p, ZK_ERR_REMAINDER
+from .r1cs import FR_MODULUS, R1CS, fr_bytes
+
+
+@dataclass
+class PKey:
+    g1: np.ndarray   # vv | yy | vav | yay | bvwy | si | v_all | w_all | vt | yt | vavt | yayt | vbt | wbt | ybt
+    g2: np.ndarray   # ww | waw | si2 | wt | wawt
+
+
+@dataclass
+class VKey:
+    g1: np.ndarray   # one | aw | bgm | vv_io | yy_io
+    g2: np.ndarray   # one2 | av | ay | gm2 | bgm2 | yt | ww_io
+
+
+@dataclass
+class Proof:
+    """Compute.proof (pinocchio.ml:195-208), fields in declaration order."""
+    vv: bytes
+    ww: bytes
+    yy: bytes
+    h: bytes
+    vavv: bytes
+    waww: bytes
+    yayy: bytes
+    bvwy: bytes
+
+    def to_bytes(self):
+        return self.vv + self.ww + self.yy + self.h + self.vavv + self.waww + self.yayy + self.bvwy
+
+    def to_compressed(self):
+        c1, c2 = G1.to_compressed_bytes, G2.to_compressed_bytes
+        return c1(self.vv) + c2(self.ww) + c1(self.yy) + c1(self.h) + c1(self.vavv) + c2(self.waww) + c1(self.yayy) + c1(self.bvwy)
+
+
+def _uks(circuit, s):
+    """v_k(s), w_k(s), y_k(s) for every variable and t(s), through the Lagrange basis of 0..n-1."""
+    P = FR_MODULUS
+    lag, t = _lagrange_at(circuit.n, s)
+    out = []
+    for M in (circuit.L, circuit.R, circuit.O):
+        u = [0] * circuit.m
+        vals = bytes(M.val)
+        for g in range(circuit.n):
+            for e in range(M.ptr[g], M.ptr[g + 1]):
+                u[M.col[e]] = (u[M.col[e]] + int.from_bytes(vals[32 * e:32 * e + 32], "little") * lag[g]) % P
+        out.append(u)
+    return out[0], out[1], out[2], t
+
+
+def keygen(rng, circuit: R1CS):
+    """KeyGen.generate (pinocchio.ml:77-189): exponents on the host, points from the fixed-base kernel."""
+    P = FR_MODULUS
+    rv, rw, s, av, aw, ay, b, gm = (rng() % P for _ in range(8))
+    ry = rv * rw % P
+    vk_, wk_, yk_, t = _uks(circuit, s)
+    mids = [k for k in range(circuit.m) if circuit.mid[k]]
+    ios = [k for k in range(circuit.m) if not circuit.mid[k]]
+    n = circuit.n
+    si = [pow(s, i, P) for i in range(n + 1)]
+    vt, wt, yt = rv * t % P, rw * t % P, ry * t % P
+    e1 = ([rv * vk_[k] % P for k in mids] + [ry * yk_[k] % P for k in mids] + [rv * vk_[k] * av % P for k in mids]
+          + [ry * yk_[k] * ay % P for k in mids] + [(rv * vk_[k] + rw * wk_[k] + ry * yk_[k]) * b % P for k in mids]
+          + si + vk_ + wk_ + [vt, yt, vt * av % P, yt * ay % P, vt * b % P, wt * b % P, yt * b % P])
+    e2 = [rw * wk_[k] % P for k in mids] + [rw * wk_[k] * aw % P for k in mids] + si + [wt, wt * aw % P]
+    v1 = [1, aw, gm * b % P] + [rv * vk_[k] % P for k in ios] + [ry * yk_[k] % P for k in ios]
+    v2 = [1, av, ay, gm, gm * b % P, yt] + [rw * wk_[k] % P for k in ios]
+    return (PKey(G1.of_Fr(fr_bytes(e1)), G2.of_Fr(fr_bytes(e2))), VKey(G1.of_Fr(fr_bytes(v1)), G2.of_Fr(fr_bytes(v2))))
+
+
+class _Prover:
+    def __init__(self, circuit: R1CS, pkey: PKey):
+        self.circuit = circuit
+        self._keep = (circuit, pkey)
+        L, R, O = _csr(circuit.L), _csr(circuit.R), _csr(circuit.O)
+        h = C.c_uint64()
+        g1 = np.ascontiguousarray(pkey.g1, dtype=np.uint8)
+        g2 = np.ascontiguousarray(pkey.g2, dtype=np.uint8)
+        mid = np.ascontiguousarray(circuit.mid, dtype=np.uint8)
+        _lib.check(_lib.lib().zk_pinocchio_pk_upload(C.c_uint32(circuit.n), C.c_uint32(circuit.m), C.byref(L), C.byref(R), C.byref(O),
+                                                    _p(mid), _p(g1), C.c_size_t(len(g1) // 96), _p(g2), C.c_size_t(len(g2) // 192), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            _lib.lib().zk_pinocchio_pk_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prove_with(self, sol, dv, dw, dy):
+        w = np.ascontiguousarray(sol, dtype=np.uint8).reshape(-1) if isinstance(sol, np.ndarray) else (
+            np.frombuffer(bytes(sol), dtype=np.uint8) if isinstance(sol, (bytes, bytearray)) else fr_bytes(sol))
+        if len(w) != 32 * self.circuit.m:
+            raise AssertionError("Variable not found")          # var.ml:75-77
+        out = np.zeros(960, dtype=np.uint8)
+        d = [fr_bytes([x]) for x in (dv, dw, dy)]
+        rc = _lib.lib().zk_pinocchio_prove(self.handle, _p(w), _p(d[0]), _p(d[1]), _p(d[2]), _p(out))
+        if rc == ZK_ERR_REMAINDER:
+            raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
+        _lib.check(rc)
+        b = bytes(out)
+        return Proof(b[:96], b[96:288], b[288:384], b[384:480], b[480:576], b[576:768], b[768:864], b[864:960])
+
+
+class ZK(_Prover):
+    keygen = staticmethod(keygen)
+
+    def prove(self, rng, sol):
+        dv = rng() % FR_MODULUS     # pinocchio.ml:428-430: dv, dw, dy in this order
+        dw = rng() % FR_MODULUS
+        dy = rng() % FR_MODULUS
+        return self.prove_with(sol, dv, dw, dy)
+
+
+class NonZK(_Prover):
+    keygen = staticmethod(keygen)
+
+    def prove(self, _rng, sol):
+        return self.prove_with(sol, 0, 0, 0)
