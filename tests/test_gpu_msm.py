@@ -99,3 +99,29 @@ def test_msm_large_trapdoor(G, mul, gen, logn):
         assert bytes(bases[B * i:B * (i + 1)]) == mul(gen(), bytes(ks[32 * i:32 * i + 32]))
     expect = mul(gen(), O.fr_dot(bytes(ks), bytes(scalars)))
     assert bytes(G.apply_powers(scalars, bases, 0)) == expect
+
+
+@pytest.mark.parametrize("kind", ["boolean_heavy", "all_equal", "two_values"])
+def test_msm_skewed_bucket_loads(kind):
+    """Digit distributions that pile most points into one bucket (boolean-heavy witnesses, SURVEY 7.2
+    hard part 4): the chunked accumulate + worklist fix-up must stay exact (and fast)."""
+    n = 1 << 15
+    ks = RC.random_fr_bytes(n, 501)
+    bases = G1.of_Fr(ks)
+    rng = np.random.Generator(np.random.PCG64(7))
+    if kind == "boolean_heavy":
+        vals = np.zeros((n, 32), dtype=np.uint8)
+        vals[:, 0] = rng.integers(0, 2, size=n, dtype=np.uint8)          # 0 / 1
+        full = np.frombuffer(bytes(RC.random_fr_bytes(n, 502)), dtype=np.uint8).reshape(n, 32)
+        pick = rng.random(n) < 0.1
+        vals[pick] = full[pick]
+    elif kind == "all_equal":
+        vals = np.tile(np.frombuffer(P.fr_to_bytes(0x1234567890ABCDEF1234567890ABCDEF), dtype=np.uint8), (n, 1))
+    else:
+        a = np.frombuffer(P.fr_to_bytes(P.R - 1), dtype=np.uint8)
+        b = np.frombuffer(P.fr_to_bytes(3), dtype=np.uint8)
+        vals = np.where(rng.random(n)[:, None] < 0.5, a[None, :], b[None, :]).astype(np.uint8)
+    scalars = np.ascontiguousarray(vals).reshape(-1)
+    expect = O.g1_mul(O.g1_generator(), O.fr_dot(bytes(ks), bytes(scalars)))
+    for c in (0, 8, 15):
+        assert bytes(G1.apply_powers(scalars, bases, c)) == expect, (kind, c)

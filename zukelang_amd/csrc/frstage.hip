@@ -392,6 +392,7 @@ int frstage_scratch_alloc(const FrStage& f, FrScratch& sc) {
 }
 
 int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipStream_t s) {
+    HIPCHK(hipGetLastError());           // a failed launch of an earlier call must not be blamed on this one
     const uint32_t n = f.n, n2 = f.n2, S = f.S;
     uint32_t* a = FRP(sc.abc);
     uint32_t* b = a + 8 * (uint64_t)n;
@@ -406,6 +407,7 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
         hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.R.ptr), (const uint32_t*)FRP(f.R.col), (const uint32_t*)FRP(f.R.val), (const uint32_t*)FRP(w), b, n);
         hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.O.ptr), (const uint32_t*)FRP(f.O.col), (const uint32_t*)FRP(f.O.val), (const uint32_t*)FRP(w), cc, n);
         hipLaunchKernelGGL(k_check_r1cs, g1d(n), dim3(256), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)cc, n, sc.flag.as<int>());
+        HIPCHK(hipGetLastError());
     }
     // ---- values -> Newton coefficients (both vectors), into d[0..n2) and d[n2..2 n2)
     {

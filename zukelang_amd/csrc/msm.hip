@@ -21,6 +21,7 @@
 #include "ec.cuh"
 #include "msm.cuh"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace zk {
@@ -172,6 +173,89 @@ __global__ void k_msm_scatter(const uint32_t* __restrict__ scalars, DigitArgs a,
     uint32_t key, val;
     if (digit_of(scalars, g / a.nw, (uint32_t)(g % a.nw), a, key, val)) sorted[atomicAdd(&cursor[key], 1u)] = val;
 }
+// ---- LDS-privatised counting sort (one bucket set of <= 2^15 buckets: the resident-key mode)
+// Global atomics saturate at a few G/s chip-wide, which made the sort as expensive as the accumulate
+// at 2^20.  Each workgroup instead owns a contiguous range of (scalar, window) pairs and histograms it
+// in LDS (2^15 counters = 128 KiB of the 160 KiB), writes its column of the [bucket][workgroup] count
+// matrix, one exclusive scan over that matrix gives every workgroup its private cursor per bucket, and
+// the scatter pass ranks with LDS atomics again.  No global atomic at all, and the bucket offsets
+// fall out of the same scan.
+static constexpr uint32_t SORT_THREADS = 1024;
+static constexpr uint32_t SORT_MAX_BUCKETS = 32768;
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(const uint32_t* __restrict__ scalars, DigitArgs a, uint64_t per_wg,
+                                                                uint32_t nb, uint32_t* __restrict__ wgcount) {
+    __shared__ uint32_t hist[SORT_MAX_BUCKETS];
+    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) hist[b] = 0;
+    __syncthreads();
+    const uint64_t total = a.n * a.nw, lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, total);
+    for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
+        uint32_t key, val;
+        if (digit_of(scalars, g / a.nw, (uint32_t)(g % a.nw), a, key, val)) atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) wgcount[(uint64_t)b * nwg + wg] = hist[b];
+}
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(const uint32_t* __restrict__ scalars, DigitArgs a, uint64_t per_wg,
+                                                                  uint32_t nb, const uint32_t* __restrict__ base,
+                                                                  uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cur[SORT_MAX_BUCKETS];
+    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cur[b] = base[(uint64_t)b * nwg + wg];
+    __syncthreads();
+    const uint64_t total = a.n * a.nw, lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, total);
+    for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
+        uint32_t key, val;
+        if (digit_of(scalars, g / a.nw, (uint32_t)(g % a.nw), a, key, val)) sorted[atomicAdd(&cur[key], 1u)] = val;
+    }
+}
+// Two-level exclusive scan of `len` counters, 8192 per block (<= 1024 blocks).
+static constexpr uint32_t SCAN_PER_BLOCK = 8192;
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums, uint64_t len) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_PER_BLOCK + (uint64_t)t * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { v[k] = base + k < len ? in[base + k] : 0u; s += v[k]; }
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { if (base + k < len) out[base + k] = run; run += v[k]; }
+    if (t == 1023) block_sums[blockIdx.x] = part[1023];
+}
+__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t s = t < nblocks ? block_sums[t] : 0;
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t x = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    if (t < nblocks) block_sums[t] = part[t] - s;
+    if (t == 1023) *total_out = part[1023];
+}
+// base[i] += block_sums[i / 8192]; offsets[b] = base[b * nwg] (first workgroup's cursor = start of the bucket)
+__global__ void k_scan_finish(uint32_t* __restrict__ base, const uint32_t* __restrict__ block_sums, uint64_t len, uint32_t nwg,
+                              uint32_t* __restrict__ offsets) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const uint32_t v = base[i] + block_sums[i / SCAN_PER_BLOCK];
+    base[i] = v;
+    if (i % nwg == 0) offsets[i / nwg] = v;
+}
+
 // single workgroup: offsets[k] = sum_{q<k} counts[q], offsets[nb] = total; cursor = offsets
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
                                                uint32_t* __restrict__ cursor, uint32_t nb) {
@@ -246,10 +330,15 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restric
         xyzz_store<F>(dst, acc);
     }
 }
+// A run cut by chunk borders left one partial sum per chunk.  Usually that is a handful per bucket
+// (one lane adds them); a bucket that swallowed a large share of the digits (boolean-heavy witnesses,
+// or a top window whose digit is only 0 / 1) leaves thousands: those go to a worklist and get a whole
+// workgroup each (strided lane sums + LDS tree), so the longest chain is count/256 + 8 instead of count.
+static constexpr uint32_t FIXUP_SERIAL_MAX = 16;
 template <class F>
 __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t chunk,
                                                    uint8_t* __restrict__ buckets, const uint8_t* __restrict__ head,
-                                                   const uint8_t* __restrict__ tail) {
+                                                   const uint8_t* __restrict__ tail, uint32_t* __restrict__ worklist) {
     constexpr int XB = FieldOps<F>::WORDS * 16;
     const uint32_t kb = blockIdx.x * blockDim.x + threadIdx.x;
     if (kb >= nb) return;
@@ -257,12 +346,39 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
     if (e == s) return;                                 // empty: the bucket array was zero-filled = identity
     const uint32_t t0 = s / chunk, t1 = (e - 1) / chunk;
     if (t0 == t1) return;                               // whole run inside one chunk: written directly
+    if (t1 - t0 > FIXUP_SERIAL_MAX) {
+        worklist[1 + atomicAdd(&worklist[0], 1u)] = kb;
+        return;
+    }
     Xyzz<F> acc = xyzz_load<F>((s == t0 * chunk ? head : tail) + (uint64_t)XB * t0);
     for (uint32_t t = t0 + 1; t <= t1; t++) {
         Xyzz<F> q = xyzz_load<F>(head + (uint64_t)XB * t);
         xyzz_add(acc, q);
     }
     xyzz_store<F>(buckets + (uint64_t)XB * kb, acc);
+}
+template <class F, int NT> FF_INLINE void block_tree_sum(Xyzz<F>& acc, uint32_t (*lds)[NT]);
+template <class F>
+__global__ __launch_bounds__(256) void k_msm_fixup_big(const uint32_t* __restrict__ offsets, uint32_t chunk,
+                                                       uint8_t* __restrict__ buckets, const uint8_t* __restrict__ head,
+                                                       const uint8_t* __restrict__ tail, const uint32_t* __restrict__ worklist) {
+    constexpr int XB = FieldOps<F>::WORDS * 16, XW = FieldOps<F>::WORDS * 4;
+    __shared__ uint32_t lds[XW][256];
+    const uint32_t count = worklist[0];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {        // block-uniform loop
+        const uint32_t kb = worklist[1 + i];
+        const uint32_t s = offsets[kb], e = offsets[kb + 1];
+        const uint32_t t0 = s / chunk, t1 = (e - 1) / chunk;
+        Xyzz<F> acc = xyzz_inf<F>();
+        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) {
+            const uint8_t* src = (t == t0 && s != t0 * chunk) ? tail : head;
+            Xyzz<F> q = xyzz_load<F>(src + (uint64_t)XB * t);
+            xyzz_add(acc, q);
+        }
+        block_tree_sum<F, 256>(acc, lds);
+        if (threadIdx.x == 0) xyzz_store<F>(buckets + (uint64_t)XB * kb, acc);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ bucket reduction: R = sum_w w * B_w, w = b + 1
@@ -450,7 +566,10 @@ template <class F> static int bases_finish(MsmBases& b, hipStream_t s) {
 }
 static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool precomp) {
     if (n == 0) ZK_FAIL(ZK_ERR_ARG, "msm: empty base set");
-    if (c == 0) c = msm_auto_window(n, precomp);
+    if (c == 0) {
+        const char* e = getenv("ZK_MSM_WINDOW");         // window-size sweeps (BASELINE config 3)
+        c = e ? (uint32_t)atoi(e) : msm_auto_window(n, precomp);
+    }
     if (c < 2 || c > 22) ZK_FAIL(ZK_ERR_ARG, "msm: window_bits must be in [2, 22]");
     b.curve = curve; b.n = n; b.c = c; b.nw = msm_windows(c); b.precomp = precomp;
     if ((precomp ? (uint64_t)b.nw : 1) * n >= ((uint64_t)1 << 31)) ZK_FAIL(ZK_ERR_ARG, "msm: too many points for 31-bit references");
@@ -521,9 +640,21 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     ZKCHK(w.offsets.alloc(4 * (size_t)(w.nbuckets + 1)));
     ZKCHK(w.cursor.alloc(4 * (size_t)(w.nbuckets + 1)));
     ZKCHK(w.sorted.alloc(4 * (size_t)maxN));
+    w.sort_wgs = 0;
+    if (b.precomp && w.nbuckets <= SORT_MAX_BUCKETS) {
+        uint64_t wgs = (maxN + 8191) / 8192;               // >= 8 pairs per lane
+        if (wgs > 256) wgs = 256;
+        if (wgs < 1) wgs = 1;
+        while ((uint64_t)w.nbuckets * wgs > (uint64_t)SCAN_PER_BLOCK * 1024) wgs >>= 1;   // the scan handles 8M counters
+        w.sort_wgs = (uint32_t)wgs;
+        ZKCHK(w.wgcount.alloc(4 * (size_t)w.nbuckets * wgs));
+        ZKCHK(w.wgbase.alloc(4 * (size_t)w.nbuckets * wgs));
+        ZKCHK(w.scan_sums.alloc(4 * 1024));
+    }
     ZKCHK(w.buckets.alloc(XB * w.nbuckets));
     ZKCHK(w.head.alloc(XB * w.nthreads));
     ZKCHK(w.tail.alloc(XB * w.nthreads));
+    ZKCHK(w.worklist.alloc(4 * (size_t)(w.nbuckets + 1)));
     const DigitPlan dp = digit_plan(b.c);
     ZKCHK(w.red.alloc(XB * (size_t)(dp.nd0 + dp.nd1) * (b.precomp ? 1 : b.nw)));
     ZKCHK(w.wsum.alloc(XB * 2 * (b.precomp ? 1 : b.nw)));
@@ -550,10 +681,21 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
     const size_t XB = xyzz_bytes(b.curve);
     {
         ScopedTimer t("msm_sort", s);
-        HIPCHK(hipMemsetAsync(w.counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
-        hipLaunchKernelGGL(k_msm_count, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.counts.as<uint32_t>());
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
-        hipLaunchKernelGGL(k_msm_scatter, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.cursor.as<uint32_t>(), w.sorted.as<uint32_t>());
+        if (w.sort_wgs) {
+            const uint64_t total = b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
+            const uint64_t len = (uint64_t)w.nbuckets * w.sort_wgs;
+            const uint32_t nblk = (uint32_t)((len + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+            hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs), dim3(SORT_THREADS), 0, s, (const uint32_t*)d_scalars, da, per_wg, w.nbuckets, w.wgcount.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)w.wgcount.as<uint32_t>(), w.wgbase.as<uint32_t>(), w.scan_sums.as<uint32_t>(), len);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, w.scan_sums.as<uint32_t>(), nblk, w.offsets.as<uint32_t>() + w.nbuckets);
+            hipLaunchKernelGGL(k_scan_finish, grid_for(len, 256), dim3(256), 0, s, w.wgbase.as<uint32_t>(), (const uint32_t*)w.scan_sums.as<uint32_t>(), len, w.sort_wgs, w.offsets.as<uint32_t>());
+            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs), dim3(SORT_THREADS), 0, s, (const uint32_t*)d_scalars, da, per_wg, w.nbuckets, (const uint32_t*)w.wgbase.as<uint32_t>(), w.sorted.as<uint32_t>());
+        } else {
+            HIPCHK(hipMemsetAsync(w.counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
+            hipLaunchKernelGGL(k_msm_count, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.counts.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
+            hipLaunchKernelGGL(k_msm_scatter, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.cursor.as<uint32_t>(), w.sorted.as<uint32_t>());
+        }
         HIPCHK(hipMemsetAsync(w.buckets.p, 0, XB * w.nbuckets, s));
     }
     {
@@ -563,8 +705,11 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
     }
     {
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
+        HIPCHK(hipMemsetAsync(w.worklist.p, 0, 4, s));
         hipLaunchKernelGGL(k_msm_fixup<F>, grid_for(w.nbuckets, 128), dim3(128), 0, s, w.offsets.as<uint32_t>(), w.nbuckets, w.chunk,
-                           w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
+                           w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), w.worklist.as<uint32_t>());
+        hipLaunchKernelGGL(k_msm_fixup_big<F>, dim3(w.nbuckets < 256 ? w.nbuckets : 256), dim3(256), 0, s, w.offsets.as<uint32_t>(), w.chunk,
+                           w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), (const uint32_t*)w.worklist.as<uint32_t>());
         const DigitPlan dp = digit_plan(b.c);
         hipLaunchKernelGGL(k_msm_digit_sums<F>, dim3(dp.nd0 + dp.nd1, nwin), dim3(64), 0, s, w.buckets.as<uint8_t>(), dp, w.red.as<uint8_t>());
         hipLaunchKernelGGL(k_msm_digit_weight<F>, dim3(2, nwin), dim3(256), 0, s, w.red.as<uint8_t>(), dp, w.wsum.as<uint8_t>());
