@@ -25,7 +25,7 @@ struct MsmBases {
 struct MsmWorkspace {
     DevBuf counts, offsets, cursor, sorted, buckets, head, tail, red, wsum;
     DevBuf worklist;                      // [0] = count, then bucket ids whose fix-up needs a whole workgroup
-    DevBuf wgcount, wgbase, scan_sums;   // LDS-privatised sort: [bucket][workgroup] counts and cursors
+    DevBuf wgcount;                       // LDS-privatised sort: [workgroup][bucket] counts, then ranks
     uint32_t sort_wgs = 0;               // 0 = global-atomic path
     uint64_t cap_points = 0;
     uint32_t c = 0, nw = 0;

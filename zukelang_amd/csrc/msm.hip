@@ -185,7 +185,7 @@ static constexpr uint32_t SORT_MAX_BUCKETS = 32768;
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(const uint32_t* __restrict__ scalars, DigitArgs a, uint64_t per_wg,
                                                                 uint32_t nb, uint32_t* __restrict__ wgcount) {
     __shared__ uint32_t hist[SORT_MAX_BUCKETS];
-    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    const uint32_t wg = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) hist[b] = 0;
     __syncthreads();
     const uint64_t total = a.n * a.nw, lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, total);
@@ -194,14 +194,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(const uint32_t*
         if (digit_of(scalars, g / a.nw, (uint32_t)(g % a.nw), a, key, val)) atomicAdd(&hist[key], 1u);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) wgcount[(uint64_t)b * nwg + wg] = hist[b];
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) wgcount[(uint64_t)wg * nb + b] = hist[b];   // [workgroup][bucket]: coalesced
 }
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(const uint32_t* __restrict__ scalars, DigitArgs a, uint64_t per_wg,
                                                                   uint32_t nb, const uint32_t* __restrict__ base,
-                                                                  uint32_t* __restrict__ sorted) {
+                                                                  const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
     __shared__ uint32_t cur[SORT_MAX_BUCKETS];
-    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
-    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cur[b] = base[(uint64_t)b * nwg + wg];
+    const uint32_t wg = blockIdx.x;
+    for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cur[b] = offsets[b] + base[(uint64_t)wg * nb + b];
     __syncthreads();
     const uint64_t total = a.n * a.nw, lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, total);
     for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
@@ -209,51 +209,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(const uint32_
         if (digit_of(scalars, g / a.nw, (uint32_t)(g % a.nw), a, key, val)) sorted[atomicAdd(&cur[key], 1u)] = val;
     }
 }
-// Two-level exclusive scan of `len` counters, 8192 per block (<= 1024 blocks).
-static constexpr uint32_t SCAN_PER_BLOCK = 8192;
-__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ block_sums, uint64_t len) {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x;
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_PER_BLOCK + (uint64_t)t * 8;
-    uint32_t v[8], s = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { v[k] = base + k < len ? in[base + k] : 0u; s += v[k]; }
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
+// Column scan of the [workgroup][bucket] count matrix: one lane per bucket walks down the workgroups
+// (row-coalesced), turning counts into each workgroup's exclusive rank inside the bucket and leaving
+// the bucket totals, which the single-workgroup k_scan below turns into bucket offsets.
+__global__ void k_sort_colscan(uint32_t* __restrict__ cnt, uint32_t nb, uint32_t nwg, uint32_t* __restrict__ totals) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t run = 0;
+    for (uint32_t wg = 0; wg < nwg; wg++) {
+        const uint32_t x = cnt[(uint64_t)wg * nb + b];
+        cnt[(uint64_t)wg * nb + b] = run;
+        run += x;
     }
-    uint32_t run = part[t] - s;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { if (base + k < len) out[base + k] = run; run += v[k]; }
-    if (t == 1023) block_sums[blockIdx.x] = part[1023];
-}
-__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t* __restrict__ total_out) {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x;
-    uint32_t s = t < nblocks ? block_sums[t] : 0;
-    part[t] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t x = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
-    }
-    if (t < nblocks) block_sums[t] = part[t] - s;
-    if (t == 1023) *total_out = part[1023];
-}
-// base[i] += block_sums[i / 8192]; offsets[b] = base[b * nwg] (first workgroup's cursor = start of the bucket)
-__global__ void k_scan_finish(uint32_t* __restrict__ base, const uint32_t* __restrict__ block_sums, uint64_t len, uint32_t nwg,
-                              uint32_t* __restrict__ offsets) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    const uint32_t v = base[i] + block_sums[i / SCAN_PER_BLOCK];
-    base[i] = v;
-    if (i % nwg == 0) offsets[i / nwg] = v;
+    totals[b] = run;
 }
 
 // single workgroup: offsets[k] = sum_{q<k} counts[q], offsets[nb] = total; cursor = offsets
@@ -322,7 +290,11 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restric
         uint32_t v = sorted[pos];
         Aff<F> p = aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
         if (v >> 31) p.y = fe_neg(p.y);
-        xyzz_madd(acc, p);
+        // G1: the mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk (through
+        // the out-of-line call it round-trips through scratch: measured 1.5 GB of HBM-side traffic per
+        // launch against 25 MB algorithmic).  G2 keeps the call: inlined it needs > 512 registers.
+        if constexpr (FieldOps<F>::WORDS == 12) xyzz_madd_impl(acc, p);
+        else xyzz_madd(acc, p);
     }
     {
         const bool complete = (seg_start == bstart) && (end == bend);
@@ -547,7 +519,9 @@ uint32_t msm_auto_window(uint64_t n, bool precomp) {
     // accumulate pass still has >= ~128k lanes of work
     double best = 1e300;
     uint32_t bc = 8;
-    for (uint32_t c = 6; c <= 20; c++) {
+    // resident keys: at most 2^15 buckets, so the whole histogram of the counting sort fits in LDS
+    const uint32_t cmax = precomp ? 16 : 20;
+    for (uint32_t c = 6; c <= cmax; c++) {
         double nw = msm_windows(c);
         double buckets = (precomp ? 1.0 : nw) * (double)(1u << (c - 1));
         double cost = nw * (double)n + 3.0 * buckets;
@@ -642,14 +616,13 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     ZKCHK(w.sorted.alloc(4 * (size_t)maxN));
     w.sort_wgs = 0;
     if (b.precomp && w.nbuckets <= SORT_MAX_BUCKETS) {
-        uint64_t wgs = (maxN + 8191) / 8192;               // >= 8 pairs per lane
+        // every workgroup zeroes and flushes nbuckets counters: give it >= 4 pairs per counter to amortise that
+        uint64_t wgs = maxN / (4 * (uint64_t)w.nbuckets);
         if (wgs > 256) wgs = 256;
-        if (wgs < 1) wgs = 1;
-        while ((uint64_t)w.nbuckets * wgs > (uint64_t)SCAN_PER_BLOCK * 1024) wgs >>= 1;   // the scan handles 8M counters
-        w.sort_wgs = (uint32_t)wgs;
-        ZKCHK(w.wgcount.alloc(4 * (size_t)w.nbuckets * wgs));
-        ZKCHK(w.wgbase.alloc(4 * (size_t)w.nbuckets * wgs));
-        ZKCHK(w.scan_sums.alloc(4 * 1024));
+        if (wgs >= 64) {                                    // below that too few workgroups: the global-atomic path is cheaper
+            w.sort_wgs = (uint32_t)wgs;
+            ZKCHK(w.wgcount.alloc(4 * (size_t)w.nbuckets * wgs));
+        }
     }
     ZKCHK(w.buckets.alloc(XB * w.nbuckets));
     ZKCHK(w.head.alloc(XB * w.nthreads));
@@ -683,13 +656,11 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
         ScopedTimer t("msm_sort", s);
         if (w.sort_wgs) {
             const uint64_t total = b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
-            const uint64_t len = (uint64_t)w.nbuckets * w.sort_wgs;
-            const uint32_t nblk = (uint32_t)((len + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
             hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs), dim3(SORT_THREADS), 0, s, (const uint32_t*)d_scalars, da, per_wg, w.nbuckets, w.wgcount.as<uint32_t>());
-            hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(1024), 0, s, (const uint32_t*)w.wgcount.as<uint32_t>(), w.wgbase.as<uint32_t>(), w.scan_sums.as<uint32_t>(), len);
-            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, w.scan_sums.as<uint32_t>(), nblk, w.offsets.as<uint32_t>() + w.nbuckets);
-            hipLaunchKernelGGL(k_scan_finish, grid_for(len, 256), dim3(256), 0, s, w.wgbase.as<uint32_t>(), (const uint32_t*)w.scan_sums.as<uint32_t>(), len, w.sort_wgs, w.offsets.as<uint32_t>());
-            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs), dim3(SORT_THREADS), 0, s, (const uint32_t*)d_scalars, da, per_wg, w.nbuckets, (const uint32_t*)w.wgbase.as<uint32_t>(), w.sorted.as<uint32_t>());
+            hipLaunchKernelGGL(k_sort_colscan, grid_for(w.nbuckets, 256), dim3(256), 0, s, w.wgcount.as<uint32_t>(), w.nbuckets, w.sort_wgs, w.counts.as<uint32_t>());
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
+            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs), dim3(SORT_THREADS), 0, s, (const uint32_t*)d_scalars, da, per_wg, w.nbuckets, (const uint32_t*)w.wgcount.as<uint32_t>(),
+                               (const uint32_t*)w.offsets.as<uint32_t>(), w.sorted.as<uint32_t>());
         } else {
             HIPCHK(hipMemsetAsync(w.counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
             hipLaunchKernelGGL(k_msm_count, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.counts.as<uint32_t>());
