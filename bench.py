@@ -32,6 +32,19 @@ def seeded(seed):
     return lambda: next(st)
 
 
+def pmc_traffic(kernel, n, world):
+    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r01_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md says).
+    Counters cannot be read from inside this process; the figure applies to the default workload only."""
+    if n != 1 << 16 or world != 1:
+        return None
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        return doc["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline():
     """The oracle's LITERAL restatement of groth16.ml:116-161 + QAP.ml:120-135 (per-variable
     apply_powers, schoolbook mul / div_rem) on ONE host core, on a bounded sample: n = 64.
@@ -177,9 +190,9 @@ def main():
         avg_ms = fam[dom]["ms_total"] / fam[dom]["launches"]
         ach = alg[dom][0] / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_ms": avg_ms,
+                "traffic": pmc_traffic(dom, n, world), "avg_launch_ms": avg_ms,
                 "note": "algorithmic bytes = 128 B (G1) / 224 B (G2) per scalar-point pair; the kernel is integer-ALU bound "
-                        "(~10 Montgomery products of 1.3k instructions per pair), see DESIGN.md"}
+                        "(~10 Montgomery products of ~800 instructions per pair); traffic >> algorithmic because the resident key stores one precomputed point per (point, window) and G2 accumulators spill to scratch, see DESIGN.md"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

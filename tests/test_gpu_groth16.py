@@ -145,7 +145,7 @@ def test_pipelined_proofs_equal_serial_ones():
     prover.close()
 
 
-@pytest.mark.parametrize("log_n", [16, 18, 20])
+@pytest.mark.parametrize("log_n", [16, 18, 20, 22])
 def test_full_size_trapdoor_and_verify(log_n):
     """BASELINE configs 2 (2^16) and up: expected proof bytes from the trapdoor evaluation (exact at
     any n), and the pairing check."""
