@@ -19,7 +19,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before torch / HIP initialise (see zk_api.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before torch / HIP initialise (see zk_api.hip)
 
 import numpy as np  # noqa: E402
 
