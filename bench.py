@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--inflight", type=int, default=6, help="proofs kept in flight on one GPU (1 = strictly serial)")
     args = ap.parse_args()
 
@@ -133,6 +134,8 @@ def main():
     if world > 1:
         depth = min(depth, 3)      # sharded proofs: the host runs an all-gather + combine per proof
 
+    prover.reserve_slots(depth)          # setup, not warm-up: slots are otherwise created at first use
+
     def run(first, count):
         """count proofs, `depth` of them in flight: proof i goes to slot i % depth."""
         last = None
@@ -150,32 +153,42 @@ def main():
 
     run(0, args.warmup)
     sync()
+    # the dominant kernels (MSM accumulate) are bracketed by HIP events on their own streams DURING the
+    # timed region (level 1: two recycled event records per launch; nothing synchronises)
+    _lib.check(L.zk_profile_reset())
+    _lib.check(L.zk_profile_enable(0 if args.no_live_events else 1))
     t0 = time.perf_counter()
     proof = run(args.warmup, args.steps)
     sync()
     dt = time.perf_counter() - t0
+    _lib.check(L.zk_profile_enable(0))
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- per-kernel-family HIP-event timing of the same step (separate, untimed pass)
+    def collect(nproofs):
+        out = {}
+        buf = C.create_string_buffer(4096)
+        _lib.check(L.zk_profile_names(buf, 4096))
+        for name in buf.value.decode().split(","):
+            if not name:
+                continue
+            ms, cnt = C.c_double(), C.c_uint64()
+            _lib.check(L.zk_profile_get(name.encode(), C.byref(ms), C.byref(cnt)))
+            out[name] = {"ms_total": ms.value, "launches": cnt.value, "ms_per_proof": ms.value / nproofs}
+        return out
+
+    fam = collect(args.steps)           # accumulate kernels, measured inside the timed region (empty with --no-live-events)
+    # every family, in a separate un-timed pass (one proof at a time: un-overlapped between proofs)
     _lib.check(L.zk_profile_reset())
-    _lib.check(L.zk_profile_enable(1))
-    prof_steps = 5
-    for i in range(prof_steps):
-        prover.prove_rs(None, *rs[args.warmup + args.steps + i])      # serial: un-overlapped kernel times
-    fam = {}
-    buf = C.create_string_buffer(4096)
-    _lib.check(L.zk_profile_names(buf, 4096))
-    for name in buf.value.decode().split(","):
-        if not name:
-            continue
-        ms, cnt = C.c_double(), C.c_uint64()
-        _lib.check(L.zk_profile_get(name.encode(), C.byref(ms), C.byref(cnt)))
-        fam[name] = {"ms_total": ms.value, "launches": cnt.value, "ms_per_proof": ms.value / prof_steps}
+    _lib.check(L.zk_profile_enable(2))
+    for i in range(4):
+        prover.prove_rs(None, *rs[args.warmup + args.steps + i])
+    fam_all = collect(4)
     _lib.check(L.zk_profile_enable(0))
+    _lib.check(L.zk_profile_reset())
 
     # ---- roofline of the dominant kernel family (HBM bound: integer/byte work, no MFMA)
     p1 = 3 + (n + 2) + (n - 1) + cs.n_mid
@@ -184,6 +197,8 @@ def main():
     # multiplied, G2 224 B.  Per proof: A uses n+2 pairs, C uses 3n+2+... (the whole pool), B n+2.
     alg = {"msm_accumulate_g1": (128.0 * ((n + 2) + p1) / 2 / world, 2), "msm_accumulate_g2": (224.0 * p2 / world, 1)}
     roof = None
+    if not fam:
+        fam = fam_all
     cands = [k for k in alg if k in fam]
     if cands:
         dom = max(cands, key=lambda k: fam[k]["ms_total"])
@@ -220,7 +235,7 @@ def main():
                        "prove_hbm_frac": 928.0 * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world},
             "roofline": roof,
             "cpu_baseline": cpu,
-            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam.items())},
+            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_all.items())},
             "proof_compressed_hex": proof.to_compressed().hex(),
         }
         print(json.dumps(out))

@@ -111,6 +111,7 @@ int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], c
  * HIP streams).  _async enqueues and returns; _wait blocks for that slot and delivers the proof.
  * The single-wave tails of one proof (bucket reduction, affine conversion) then run under the
  * bulk kernels of the next.  zk_groth16_prove == _async + _wait on slot 0. */
+int zk_groth16_reserve_slots(uint64_t handle, uint32_t count);   /* allocate slots 0..count-1 now instead of at first use */
 int zk_groth16_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot);
 int zk_groth16_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[384]);
 /* Keeps a witness resident in HBM; a later zk_groth16_prove / _prove_partial / _qap_eval called with
@@ -162,7 +163,7 @@ int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32]
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------
  * With profiling on, kernel families are bracketed by HIP events on the stream they run on;
  * zk_profile_get returns the summed milliseconds and launch count since the last reset. */
-int zk_profile_enable(int on);
+int zk_profile_enable(int level);   /* 0 off | 1 the MSM accumulate kernels only (cheap: safe inside a timed region) | 2 every family */
 int zk_profile_reset(void);
 int zk_profile_get(const char* family, double* total_ms, uint64_t* launches);
 int zk_profile_names(char* buf, size_t buflen);   /* comma-separated family names */

@@ -264,6 +264,16 @@ int zk_groth16_pk_free(uint64_t handle) {
     g_keys.erase(it);
     return ZK_OK;
 }
+int zk_groth16_reserve_slots(uint64_t handle, uint32_t count) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (count > MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_reserve_slots: at most 8 slots");
+    for (uint32_t i = 0; i < count; i++) {
+        Slot* sl;
+        ZKCHK(slot_get(*k, i, &sl));
+    }
+    return ZK_OK;
+}
 int zk_groth16_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));

@@ -674,7 +674,7 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
         HIPCHK(hipMemsetAsync(w.buckets.p, 0, XB * w.nbuckets, s));
     }
     {
-        ScopedTimer t(b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2", s);
+        ScopedTimer t(b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2", s, 1);
         hipLaunchKernelGGL(k_msm_accumulate<F>, grid_for(w.nthreads, 128), dim3(128), 0, s, b.table.as<uint8_t>(), w.offsets.as<uint32_t>(),
                            w.sorted.as<uint32_t>(), w.nbuckets, w.chunk, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
     }

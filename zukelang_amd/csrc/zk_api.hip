@@ -33,17 +33,24 @@ int ensure_init() {
     return zk_init(0);
 }
 
-ScopedTimer::ScopedTimer(const char* name, hipStream_t stream) : s(stream) {
+static hipEvent_t pool_event() {
     Ctx& c = ctx();
-    if (!c.profiling) return;
+    if (!c.event_pool.empty()) { hipEvent_t e = c.event_pool.back(); c.event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+ScopedTimer::ScopedTimer(const char* name, hipStream_t stream, int level) : s(stream) {
+    Ctx& c = ctx();
+    if (c.profiling < level) return;
     for (size_t i = 0; i < c.timers.size(); i++)
         if (c.timers[i].name == name) idx = (int)i;
     if (idx < 0) {
         c.timers.push_back(KernelTimer{name, {}});
         idx = (int)c.timers.size() - 1;
     }
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
+    a = pool_event();
+    b = pool_event();
     (void)hipEventRecord(a, s);
 }
 ScopedTimer::~ScopedTimer() {
@@ -148,15 +155,15 @@ int zk_sync(void) {
 }
 
 int zk_profile_enable(int on) {
-    ctx().profiling = on != 0;
+    ctx().profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     return ZK_OK;
 }
 int zk_profile_reset(void) {
     Ctx& c = ctx();
     for (auto& t : c.timers)
         for (auto& sp : t.spans) {
-            (void)hipEventDestroy(sp.first);
-            (void)hipEventDestroy(sp.second);
+            c.event_pool.push_back(sp.first);
+            c.event_pool.push_back(sp.second);
         }
     c.timers.clear();
     return ZK_OK;

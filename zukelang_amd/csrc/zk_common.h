@@ -26,7 +26,8 @@ struct Ctx {
     void* tw_fwd = nullptr;
     void* tw_inv = nullptr;
     uint32_t tw_log = 0;
-    bool profiling = false;
+    int profiling = 0;                 // 0 off, 1 = the dominant (accumulate) kernels only, 2 = every family
+    std::vector<hipEvent_t> event_pool; // recycled events: hipEventCreate costs tens of microseconds
     std::vector<KernelTimer> timers;
     std::string last_error;
 };
@@ -78,7 +79,7 @@ struct ScopedTimer {
     int idx = -1;
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t s;
-    ScopedTimer(const char* name, hipStream_t stream);
+    ScopedTimer(const char* name, hipStream_t stream, int level = 2);
     ~ScopedTimer();
 };
 

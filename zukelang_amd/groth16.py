@@ -244,6 +244,10 @@ class Groth16:
         b = bytes(out)
         return Proof(b[:96], b[96:288], b[288:])
 
+    def reserve_slots(self, count):
+        """Allocate the scratch and streams of `count` proof slots now (otherwise at first use)."""
+        _lib.check(_lib.lib().zk_groth16_reserve_slots(self.handle, C.c_uint32(count)))
+
     def prove_async(self, sol, r, s, slot):
         """Enqueue one proof on `slot` (0..7) and return; `prove_wait(slot)` collects it.  Several
         slots keep several proofs in flight on one key.  On a sharded key the slot produces this
