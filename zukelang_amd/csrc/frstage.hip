@@ -59,29 +59,6 @@ __global__ void k_scale_pad(uint32_t* out, const uint32_t* in, const uint32_t* t
     }
     fe_store<FrParams>(out + 8 * i, x);
 }
-// data[i] *= tab[i & mask]
-__global__ void k_mul_tab(uint32_t* data, const uint32_t* tab, uint64_t total, uint64_t mask) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    fe_store<FrParams>(data + 8 * i, fe_mul(fe_load<FrParams>(data + 8 * i), fe_load<FrParams>(tab + 8 * (i & mask))));
-}
-// tree level, unfused form: scratch = hi half of every node, zero padded to the node length
-__global__ void k_tree_prep(uint32_t* scratch, const uint32_t* d, uint32_t log_len, uint64_t total) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    uint64_t half = (uint64_t)1 << (log_len - 1), j = i & ((half << 1) - 1);
-    Fr x = fe_zero<FrParams>();
-    if (j < half) x = fe_load<FrParams>(d + 8 * (i + half));
-    fe_store<FrParams>(scratch + 8 * i, x);
-}
-__global__ void k_tree_combine(uint32_t* d, const uint32_t* scratch, uint32_t log_len, uint64_t total) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    uint64_t half = (uint64_t)1 << (log_len - 1), j = i & ((half << 1) - 1);
-    Fr x = fe_load<FrParams>(scratch + 8 * i);
-    if (j < half) x = fe_add(x, fe_load<FrParams>(d + 8 * i));
-    fe_store<FrParams>(d + 8 * i, x);
-}
 // tree level fused in LDS (node length 2^log_len <= tile): d[node] <- lo + P_left * hi
 __global__ __launch_bounds__(NTT_THREADS) void k_tree_level_fused(uint32_t* __restrict__ d, const uint32_t* __restrict__ pntt,
                                                                  const uint32_t* __restrict__ tw_fwd, const uint32_t* __restrict__ tw_inv,
@@ -223,10 +200,11 @@ int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, voi
     ZKCHK(B.alloc(32 * S));
     hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(A), (const uint32_t*)d_a, (const uint32_t*)nullptr, na, S);
     hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(B), (const uint32_t*)d_b, (const uint32_t*)nullptr, nb, S);
-    ZKCHK(ntt_forward(A.p, S, lg, s));
-    ZKCHK(ntt_forward(B.p, S, lg, s));
-    ZKCHK(fr_pointwise_mul(A.p, A.p, B.p, S, s));
-    ZKCHK(ntt_inverse(A.p, S, lg, true, s));
+    if (lg == 0) ZKCHK(fr_pointwise_mul(A.p, A.p, B.p, S, s));
+    else {
+        ZKCHK(ntt_forward(B.p, S, lg, s));
+        ZKCHK(ntt_mul_table(A.p, S, lg, B.p, S - 1, true, nullptr, nullptr, s));
+    }
     HIPCHK(hipMemcpyAsync(d_out, A.p, 32 * nout, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // A, B are freed on return
     return ZK_OK;
@@ -274,11 +252,9 @@ static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t leve
             hipLaunchKernelGGL(k_tree_level_fused, dim3((unsigned)(total >> log_T)), dim3(NTT_THREADS), 0, s, (uint32_t*)d, tab,
                                (const uint32_t*)c.tw_fwd, (const uint32_t*)c.tw_inv, l, log_T, (uint64_t)f.n2 - 1);
         } else {
-            hipLaunchKernelGGL(k_tree_prep, g1d(total), dim3(256), 0, s, (uint32_t*)tmp, (const uint32_t*)d, l, total);
-            ZKCHK(ntt_forward(tmp, total, l, s));
-            hipLaunchKernelGGL(k_mul_tab, g1d(total), dim3(256), 0, s, (uint32_t*)tmp, tab, total, (uint64_t)f.n2 - 1);
-            ZKCHK(ntt_inverse(tmp, total, l, false, s));
-            hipLaunchKernelGGL(k_tree_combine, g1d(total), dim3(256), 0, s, (uint32_t*)d, (const uint32_t*)tmp, l, total);
+            // upper halves (zero padded) -> NTT -> * P_left -> iNTT -> + lower halves, with the padding folded
+            // into the first pass, the product into the middle kernel and the addition into the last pass
+            ZKCHK(ntt_mul_table(tmp, total, l, tab, (uint64_t)f.n2 - 1, false, d, d, s));
         }
     }
     HIPCHK(hipGetLastError());
@@ -415,9 +391,7 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
         for (int k = 0; k < 2; k++) {
             const uint32_t* src = k == 0 ? a : b;
             hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), src, (const uint32_t*)FRP(f.invfact), (uint64_t)n, (uint64_t)S);
-            ZKCHK(ntt_forward(sc.bufA.p, S, f.log_S, s));
-            ZKCHK(fr_pointwise_mul(sc.bufA.p, sc.bufA.p, f.e_ntt.p, S, s));
-            ZKCHK(ntt_inverse(sc.bufA.p, S, f.log_S, true, s));
+            ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, f.e_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
             hipLaunchKernelGGL(k_scale_pad, g1d(n2), dim3(256), 0, s, FRP(sc.d) + 8 * (uint64_t)k * n2, (const uint32_t*)FRP(sc.bufA), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)n2);
         }
     }
@@ -428,15 +402,11 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
         ScopedTimer t("fr_quotient", s);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), (const uint32_t*)FRP(sc.d), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufB), (const uint32_t*)(FRP(sc.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
-        ZKCHK(ntt_forward(sc.bufA.p, S, f.log_S, s));
         ZKCHK(ntt_forward(sc.bufB.p, S, f.log_S, s));
-        ZKCHK(fr_pointwise_mul(sc.bufA.p, sc.bufA.p, sc.bufB.p, S, s));
-        ZKCHK(ntt_inverse(sc.bufA.p, S, f.log_S, true, s));                    // v*w, coefficients 0..2n-2
+        ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, sc.bufB.p, (uint64_t)S - 1, true, nullptr, nullptr, s));   // v*w, coefficients 0..2n-2
         // t[k] = (v w)[2n-2-k], k < n-1
         hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufB), (const uint32_t*)FRP(sc.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
-        ZKCHK(ntt_forward(sc.bufB.p, S, f.log_S, s));
-        ZKCHK(fr_pointwise_mul(sc.bufB.p, sc.bufB.p, f.iz_ntt.p, S, s));
-        ZKCHK(ntt_inverse(sc.bufB.p, S, f.log_S, true, s));
+        ZKCHK(ntt_mul_table(sc.bufB.p, S, f.log_S, f.iz_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
         // h[j] = hh[n-2-j], j < n-1
         hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufB), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
     }

@@ -251,10 +251,6 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
 }
 
 // ------------------------------------------------------------------ accumulate
-#ifndef ZK_INLINE_G2
-#define ZK_INLINE_G2 0
-#endif
-static constexpr bool INLINE_G2 = ZK_INLINE_G2;
 template <class F>
 __global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restrict__ table, const uint32_t* __restrict__ offsets,
                                                         const uint32_t* __restrict__ sorted, uint32_t nb, uint32_t chunk,
@@ -296,8 +292,8 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restric
         if (v >> 31) p.y = fe_neg(p.y);
         // G1: the mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk (through
         // the out-of-line call it round-trips through scratch: measured 1.5 GB of HBM-side traffic per
-        // launch against 25 MB algorithmic).  G2 keeps the call: inlined it needs > 512 registers.
-        if (INLINE_G2 || FieldOps<F>::WORDS == 12) xyzz_madd_impl(acc, p);
+        // launch against 25 MB algorithmic).  G2 keeps the call: inlined it needs > 512 registers and measured 5 % slower.
+        if constexpr (FieldOps<F>::WORDS == 12) xyzz_madd_impl(acc, p);
         else xyzz_madd(acc, p);
     }
     {

@@ -50,9 +50,20 @@ struct PassArgs {
     uint32_t strided;    // rows come from stride-L global addresses
 };
 
+// Optional fused edges of a pass (the basis-conversion levels of the Fr stage):
+//   pad_half : element i of a 2^log_len node is read as src[i + len/2] for i < len/2 and as 0 above
+//              (the zero-padded upper half of the node, taken straight from the coefficient array)
+//   add_low  : the stored value gets lo[i] added for i < len/2 (the node's lower half) and goes to dst
+struct PassIO {
+    const uint32_t* src;     // nullptr: read `data`
+    uint32_t* dst;           // nullptr: write `data`
+    const uint32_t* lo;      // add_low source
+    uint32_t log_len;
+    uint32_t pad_half, add_low;
+};
 template <bool INVERSE>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw,
-                                                         PassArgs a, const uint32_t* __restrict__ scale) {
+                                                         PassArgs a, const uint32_t* __restrict__ scale, PassIO io) {
     __shared__ uint32_t lds[8][NTT_T];
     const uint32_t T = 1u << a.log_T;
     const uint32_t log_L = a.log_hi - a.s;
@@ -71,8 +82,14 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__
     auto gidx = [&](uint32_t e) -> uint64_t {
         return a.strided ? base + ((uint64_t)(e >> a.log_RS) << log_L) + (e & RSm) : base + e;
     };
+    const uint64_t half = io.log_len ? (uint64_t)1 << (io.log_len - 1) : 0, lenm = (half << 1) - 1;
+    const uint32_t* src = io.src ? io.src : data;
+    uint32_t* dst = io.dst ? io.dst : data;
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x = fe_load<FrParams>(data + 8 * gidx(e));
+        const uint64_t g = gidx(e);
+        Fr x;
+        if (io.pad_half) x = (g & lenm) < half ? fe_load<FrParams>(src + 8 * (g + half)) : fe_zero<FrParams>();
+        else x = fe_load<FrParams>(src + 8 * g);
 #pragma unroll
         for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
     }
@@ -85,7 +102,46 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__
 #pragma unroll
         for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
         if (scale) x = fe_mul(x, sc);
-        fe_store<FrParams>(data + 8 * gidx(e), x);
+        const uint64_t g = gidx(e);
+        if (io.add_low && (g & lenm) < half) x = fe_add(x, fe_load<FrParams>(io.lo + 8 * g));
+        fe_store<FrParams>(dst + 8 * g, x);
+    }
+}
+// The middle of a convolution in ONE kernel: the last (contiguous) forward pass, the pointwise product
+// with a table that is already in the transform domain, and the first (contiguous) inverse pass all
+// work on the same 1024-element tile, so the data makes one HBM round trip instead of three.
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_mid(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw_fwd,
+                                                        const uint32_t* __restrict__ tw_inv, uint32_t log_T, uint32_t s,
+                                                        const uint32_t* __restrict__ tab, uint64_t tab_mask,
+                                                        const uint32_t* __restrict__ scale) {
+    __shared__ uint32_t lds[8][NTT_T];
+    const uint32_t T = 1u << log_T;
+    const uint64_t base = (uint64_t)blockIdx.x << log_T;
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x = fe_load<FrParams>(data + 8 * (base + e));
+#pragma unroll
+        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+    }
+    __syncthreads();
+    lds_ntt_stages<false>(lds, tw_fwd, T, s, 0, 0, 0, false);
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
+        x = fe_mul(x, fe_load<FrParams>(tab + 8 * ((base + e) & tab_mask)));
+#pragma unroll
+        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+    }
+    __syncthreads();
+    lds_ntt_stages<true>(lds, tw_inv, T, s, 0, 0, 0, false);
+    Fr sc;
+    if (scale) sc = fe_load<FrParams>(scale);
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+        Fr x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
+        if (scale) x = fe_mul(x, sc);
+        fe_store<FrParams>(data + 8 * (base + e), x);
     }
 }
 
@@ -194,12 +250,45 @@ static int run_ntt(void* d, uint64_t total, uint32_t log_len, bool inverse, bool
     ScopedTimer t(inverse ? "ntt_inverse" : "ntt_forward", s);
     if (!inverse) {
         for (auto& p : st)
-            hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_fwd, p, (const uint32_t*)nullptr);
-        hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_fwd, last, (const uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_fwd, p, (const uint32_t*)nullptr, PassIO{});
+        hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_fwd, last, (const uint32_t*)nullptr, PassIO{});
     } else {
-        hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_inv, last, st.empty() ? sc : (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_inv, last, st.empty() ? sc : (const uint32_t*)nullptr, PassIO{});
         for (size_t i = st.size(); i-- > 0;)
-            hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_inv, st[i], i == 0 ? sc : (const uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)c.tw_inv, st[i], i == 0 ? sc : (const uint32_t*)nullptr, PassIO{});
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+// work <- iNTT( NTT(x) * tab ), per 2^log_len segment, everything fused around the tile passes.
+//   pad_src != nullptr : x = upper half of every node of pad_src, zero padded (tree level); else x = work
+//   add_dst != nullptr : the result plus the node's lower half goes to add_dst (tree level); else to work
+// scale: multiply by 2^-log_len (when the table does not already carry it).
+int ntt_mul_table(void* work, uint64_t total, uint32_t log_len, const void* tab, uint64_t tab_mask, bool scale,
+                  const void* pad_src, void* add_dst, hipStream_t s) {
+    if (total == 0 || (total & (total - 1)) || ((uint64_t)1 << log_len) > total || log_len == 0) ZK_FAIL(ZK_ERR_ARG, "ntt_mul_table: bad sizes");
+    ZKCHK(ntt_ensure_twiddles(log_len));
+    Ctx& c = ctx();
+    uint32_t log_total = ceil_log2(total);
+    uint32_t log_T = log_total < (uint32_t)NTT_LOG_T ? log_total : NTT_LOG_T;
+    std::vector<PassArgs> st;
+    PassArgs last;
+    plan(log_len, log_T, st, last);
+    if (st.empty() && (pad_src || add_dst)) ZK_FAIL(ZK_ERR_ARG, "ntt_mul_table: fused edges need a node larger than one tile");
+    dim3 grid((unsigned)(total >> log_T));
+    const uint32_t* sc = scale ? g_inv_pow2.as<uint32_t>() + 8 * log_len : nullptr;
+    ScopedTimer t("ntt_mul_table", s);
+    for (size_t i = 0; i < st.size(); i++) {
+        PassIO io{};
+        if (i == 0 && pad_src) { io.src = (const uint32_t*)pad_src; io.pad_half = 1; io.log_len = log_len; }
+        hipLaunchKernelGGL(k_ntt_pass<false>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)work, (const uint32_t*)c.tw_fwd, st[i], (const uint32_t*)nullptr, io);
+    }
+    hipLaunchKernelGGL(k_ntt_mid, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)work, (const uint32_t*)c.tw_fwd, (const uint32_t*)c.tw_inv, log_T, last.s,
+                       (const uint32_t*)tab, tab_mask, st.empty() ? sc : (const uint32_t*)nullptr);
+    for (size_t i = st.size(); i-- > 0;) {
+        PassIO io{};
+        if (i == 0 && add_dst) { io.dst = (uint32_t*)add_dst; io.lo = (const uint32_t*)add_dst; io.add_low = 1; io.log_len = log_len; }
+        hipLaunchKernelGGL(k_ntt_pass<true>, grid, dim3(NTT_THREADS), 0, s, (uint32_t*)work, (const uint32_t*)c.tw_inv, st[i], i == 0 ? sc : (const uint32_t*)nullptr, io);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
