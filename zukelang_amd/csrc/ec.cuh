@@ -28,6 +28,12 @@ template <> struct FieldOps<Fp2> {
     static constexpr int WORDS = 24;
 };
 
+template <> struct FieldOps<Fp2H> {
+    static FF_INLINE Fp2H zero() { return {fe_zero<FpParams>()}; }
+    static FF_INLINE Fp2H one() { return {pair_comp() ? fe_zero<FpParams>() : fe_one<FpParams>()}; }
+    static constexpr int WORDS = 24;     // memory layout is the one of Fp2: c0 | c1
+};
+
 template <class F> struct Aff {
     F x, y;
 };
@@ -182,6 +188,8 @@ FF_INLINE Fp load_f(const Fp*, const void* p) { return fe_load<FpParams>(p); }
 FF_INLINE Fp2 load_f(const Fp2*, const void* p) {
     return {fe_load<FpParams>(p), fe_load<FpParams>((const char*)p + 48)};
 }
+FF_INLINE Fp2H load_f(const Fp2H*, const void* p) { return {fe_load<FpParams>((const char*)p + 48 * pair_comp())}; }
+FF_INLINE void store_f(void* p, const Fp2H& a) { fe_store<FpParams>((char*)p + 48 * pair_comp(), a.v); }
 FF_INLINE void store_f(void* p, const Fp& a) { fe_store<FpParams>(p, a); }
 FF_INLINE void store_f(void* p, const Fp2& a) {
     fe_store<FpParams>(p, a.c0);

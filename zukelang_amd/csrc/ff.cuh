@@ -315,4 +315,56 @@ __device__ __noinline__ inline Fp2 fe_inv(const Fp2& a) {
     return {fe_mul(a.c0, d), fe_neg(fe_mul(a.c1, d))};
 }
 
+// ------------------------------------------------------------------ Fp2 split over a lane pair
+// Lane 2k holds the c0 component, lane 2k+1 the c1 component of the same Fp2 value; partners trade
+// operands with one DPP quad_perm(1,0,3,2) move per limb.  A product costs each lane two base
+// multiplications (a0 b0, a1 b1 | a0 b1, a1 b0) instead of Karatsuba's three on one lane: 4/3 of the
+// multiplier work, but every lane carries HALF of each value, so a G2 mixed addition has the register
+// footprint of a G1 one (2 waves per SIMD, the accumulator never leaves the VGPRs).  Both lanes of a
+// pair must follow the same control flow; every predicate below is pair-uniform by construction.
+struct Fp2H {
+    Fp v;
+};
+FF_INLINE uint32_t pair_comp() { return threadIdx.x & 1u; }
+FF_INLINE Fp pair_swap(const Fp& a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1, 0xF, 0xF, true);
+    return r;
+}
+FF_INLINE Fp fp_select(bool take_b, const Fp& a, const Fp& b) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.v[i] = take_b ? b.v[i] : a.v[i];
+    return r;
+}
+FF_INLINE bool fe_is_zero(const Fp2H& a) {
+    const int z = fe_is_zero(a.v) ? 1 : 0;
+    return z && __builtin_amdgcn_mov_dpp(z, 0xB1, 0xF, 0xF, true);
+}
+FF_INLINE bool fe_eq(const Fp2H& a, const Fp2H& b) {
+    const int z = fe_eq(a.v, b.v) ? 1 : 0;
+    return z && __builtin_amdgcn_mov_dpp(z, 0xB1, 0xF, 0xF, true);
+}
+FF_INLINE Fp2H fe_add(const Fp2H& a, const Fp2H& b) { return {fe_add(a.v, b.v)}; }
+FF_INLINE Fp2H fe_sub(const Fp2H& a, const Fp2H& b) { return {fe_sub(a.v, b.v)}; }
+FF_INLINE Fp2H fe_neg(const Fp2H& a) { return {fe_neg(a.v)}; }
+FF_INLINE Fp2H fe_dbl(const Fp2H& a) { return {fe_dbl(a.v)}; }
+FF_INLINE Fp2H fe_mul(const Fp2H& a, const Fp2H& b) {
+    const bool c1 = pair_comp() != 0;
+    const Fp ao = pair_swap(a.v), bo = pair_swap(b.v);
+    const Fp a0 = fp_select(c1, a.v, ao), a1 = fp_select(c1, ao, a.v);
+    const Fp m1 = fe_mul(a0, b.v);      // c0 lane: a0 b0   c1 lane: a0 b1
+    const Fp m2 = fe_mul(a1, bo);       // c0 lane: a1 b1   c1 lane: a1 b0
+    return {c1 ? fe_add(m1, m2) : fe_sub(m1, m2)};
+}
+FF_INLINE Fp2H fe_sqr(const Fp2H& a) {
+    const bool c1 = pair_comp() != 0;
+    const Fp ao = pair_swap(a.v);
+    const Fp x = c1 ? ao : fe_add(a.v, ao);          // c0 lane: a0 + a1   c1 lane: a0
+    const Fp y = c1 ? a.v : fe_sub(a.v, ao);         // c0 lane: a0 - a1   c1 lane: a1
+    const Fp m = fe_mul(x, y);
+    return {c1 ? fe_dbl(m) : m};
+}
+
 }  // namespace zk

@@ -23,6 +23,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace zk {
 
@@ -252,12 +253,13 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
 
 // ------------------------------------------------------------------ accumulate
 template <class F>
-__global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restrict__ table, const uint32_t* __restrict__ offsets,
+__global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __restrict__ table, const uint32_t* __restrict__ offsets,
                                                         const uint32_t* __restrict__ sorted, uint32_t nb, uint32_t chunk,
                                                         uint8_t* __restrict__ buckets, uint8_t* __restrict__ head,
                                                         uint8_t* __restrict__ tail) {
     constexpr int AB = FieldOps<F>::WORDS * 8, XB = FieldOps<F>::WORDS * 16;
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr bool PAIR = std::is_same<F, Fp2H>::value;      // G2: two lanes per chunk, one Fp2 component each
+    const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);
     const uint32_t N = offsets[nb];
     uint64_t start64 = t * chunk;
     if (start64 >= N) return;
@@ -290,11 +292,13 @@ __global__ __launch_bounds__(128) void k_msm_accumulate(const uint8_t* __restric
         uint32_t v = sorted[pos];
         Aff<F> p = aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
         if (v >> 31) p.y = fe_neg(p.y);
-        // G1: the mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk (through
-        // the out-of-line call it round-trips through scratch: measured 1.5 GB of HBM-side traffic per
-        // launch against 25 MB algorithmic).  G2 keeps the call: inlined it needs > 512 registers and measured 5 % slower.
-        if constexpr (FieldOps<F>::WORDS == 12) xyzz_madd_impl(acc, p);
-        else xyzz_madd(acc, p);
+        // The mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk (through the
+        // out-of-line call it round-trips through scratch: measured 1.5 GB of HBM-side traffic per G1
+        // launch against 25 MB algorithmic).  G2 runs here as F = Fp2H, one Fp2 component per lane of a
+        // pair, which gives it the register footprint of G1; a whole Fp2 accumulator per lane needs > 512
+        // registers inlined and 2.3 GB of scratch traffic per launch out of line.
+        if constexpr (std::is_same<F, Fp2>::value) xyzz_madd(acc, p);
+        else xyzz_madd_impl(acc, p);
     }
     {
         const bool complete = (seg_start == bstart) && (end == bend);
@@ -671,8 +675,12 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
     }
     {
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2", s, 1);
-        hipLaunchKernelGGL(k_msm_accumulate<F>, grid_for(w.nthreads, 128), dim3(128), 0, s, b.table.as<uint8_t>(), w.offsets.as<uint32_t>(),
-                           w.sorted.as<uint32_t>(), w.nbuckets, w.chunk, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
+        if constexpr (std::is_same<F, Fp2>::value)
+            hipLaunchKernelGGL(k_msm_accumulate<Fp2H>, grid_for(2 * w.nthreads, 128), dim3(128), 0, s, b.table.as<uint8_t>(), w.offsets.as<uint32_t>(),
+                               w.sorted.as<uint32_t>(), w.nbuckets, w.chunk, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
+        else
+            hipLaunchKernelGGL(k_msm_accumulate<F>, grid_for(w.nthreads, 128), dim3(128), 0, s, b.table.as<uint8_t>(), w.offsets.as<uint32_t>(),
+                               w.sorted.as<uint32_t>(), w.nbuckets, w.chunk, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
     }
     {
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
