@@ -14,23 +14,26 @@
 
 namespace zk {
 
+// F is the AT-REST coordinate type (Fp = FpB<64>, Fp2, Fp2H: value bound 64 p, see ff.cuh): struct members
+// and loop-carried accumulators have it; temporaries inside a formula are `auto` and carry their own
+// bound in the type, and assigning one back to an F member checks (at compile time) that it fits.
 template <class F> struct FieldOps;
 template <> struct FieldOps<Fp> {
-    static FF_INLINE Fp zero() { return fe_zero<FpParams>(); }
-    static FF_INLINE Fp one() { return fe_one<FpParams>(); }
-    static FF_INLINE Fp curve_b() { Fp o = one(); return fe_dbl(fe_dbl(o)); }   // 4
+    static FF_INLINE Fp zero() { return fp_zero(); }
+    static FF_INLINE Fp one() { return fp_one(); }
+    static FF_INLINE Fp curve_b() { return fe_dbl(fe_dbl(fp_one())); }   // 4
     static constexpr int WORDS = 12;
 };
 template <> struct FieldOps<Fp2> {
     static FF_INLINE Fp2 zero() { return fp2_zero(); }
     static FF_INLINE Fp2 one() { return fp2_one(); }
-    static FF_INLINE Fp2 curve_b() { Fp f = fe_dbl(fe_dbl(fe_one<FpParams>())); return {f, f}; }  // 4 + 4u
+    static FF_INLINE Fp2 curve_b() { const FpB<4> f = fe_dbl(fe_dbl(fp_one())); return {f, f}; }  // 4 + 4u
     static constexpr int WORDS = 24;
 };
 
 template <> struct FieldOps<Fp2H> {
-    static FF_INLINE Fp2H zero() { return {fe_zero<FpParams>()}; }
-    static FF_INLINE Fp2H one() { return {pair_comp() ? fe_zero<FpParams>() : fe_one<FpParams>()}; }
+    static FF_INLINE Fp2H zero() { return {fp_zero()}; }
+    static FF_INLINE Fp2H one() { return {pair_comp() ? fp_zero() : fp_one()}; }
     static constexpr int WORDS = 24;     // memory layout is the one of Fp2: c0 | c1
 };
 
@@ -56,41 +59,39 @@ template <class F> FF_INLINE Xyzz<F> xyzz_from_aff(const Aff<F>& p) {
     if (aff_is_inf(p)) return xyzz_inf<F>();
     return {p.x, p.y, FieldOps<F>::one(), FieldOps<F>::one()};
 }
-template <class F> FF_INLINE Xyzz<F> xyzz_neg(const Xyzz<F>& p) { return {p.x, fe_neg(p.y), p.zz, p.zzz}; }
-template <class F> FF_INLINE Aff<F> aff_neg(const Aff<F>& p) { return {p.x, fe_neg(p.y)}; }
 
 // y^2 == x^3 + b
 template <class F> FF_INLINE bool aff_on_curve(const Aff<F>& p) {
     if (aff_is_inf(p)) return true;
-    F l = fe_sqr(p.y);
-    F r = fe_add(fe_mul(fe_sqr(p.x), p.x), FieldOps<F>::curve_b());
+    const auto l = fe_sqr(p.y);
+    const auto r = fe_add(fe_mul(fe_sqr(p.x), p.x), FieldOps<F>::curve_b());
     return fe_eq(l, r);
 }
 
 // dbl-2008-s-1 (a = 0)
 template <class F> FF_INLINE Xyzz<F> xyzz_dbl_impl(const Xyzz<F>& p) {
     if (xyzz_is_inf(p) || fe_is_zero(p.y)) return xyzz_inf<F>();
-    F U = fe_dbl(p.y);
-    F V = fe_sqr(U);
-    F W = fe_mul(U, V);
-    F S = fe_mul(p.x, V);
-    F X2 = fe_sqr(p.x);
-    F M = fe_add(fe_dbl(X2), X2);
-    F X3 = fe_sub(fe_sqr(M), fe_dbl(S));
-    F Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
+    const auto U = fe_dbl(p.y);
+    const auto V = fe_sqr(U);
+    const auto W = fe_mul(U, V);
+    const auto S = fe_mul(p.x, V);
+    const auto X2 = fe_sqr(p.x);
+    const auto M = fe_add(fe_dbl(X2), X2);
+    const auto X3 = fe_sub(fe_sqr(M), fe_dbl(S));
+    const auto Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
     return {X3, Y3, fe_mul(V, p.zz), fe_mul(W, p.zzz)};
 }
 // mdbl-2008-s-1: doubling of an affine point
 template <class F> FF_INLINE Xyzz<F> xyzz_dbl_aff(const Aff<F>& p) {
     if (aff_is_inf(p) || fe_is_zero(p.y)) return xyzz_inf<F>();
-    F U = fe_dbl(p.y);
-    F V = fe_sqr(U);
-    F W = fe_mul(U, V);
-    F S = fe_mul(p.x, V);
-    F X2 = fe_sqr(p.x);
-    F M = fe_add(fe_dbl(X2), X2);
-    F X3 = fe_sub(fe_sqr(M), fe_dbl(S));
-    F Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
+    const auto U = fe_dbl(p.y);
+    const auto V = fe_sqr(U);
+    const auto W = fe_mul(U, V);
+    const auto S = fe_mul(p.x, V);
+    const auto X2 = fe_sqr(p.x);
+    const auto M = fe_add(fe_dbl(X2), X2);
+    const auto X3 = fe_sub(fe_sqr(M), fe_dbl(S));
+    const auto Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
     return {X3, Y3, V, W};
 }
 // madd-2008-s: acc += q (q affine)
@@ -100,20 +101,20 @@ template <class F> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) 
         acc = {q.x, q.y, FieldOps<F>::one(), FieldOps<F>::one()};
         return;
     }
-    F U2 = fe_mul(q.x, acc.zz);
-    F S2 = fe_mul(q.y, acc.zzz);
-    F P = fe_sub(U2, acc.x);
-    F R = fe_sub(S2, acc.y);
+    const auto U2 = fe_mul(q.x, acc.zz);
+    const auto S2 = fe_mul(q.y, acc.zzz);
+    const auto P = fe_sub(U2, acc.x);
+    const auto R = fe_sub(S2, acc.y);
     if (fe_is_zero(P)) {
         if (fe_is_zero(R)) acc = xyzz_dbl_aff(q);
         else acc = xyzz_inf<F>();
         return;
     }
-    F PP = fe_sqr(P);
-    F PPP = fe_mul(P, PP);
-    F Q = fe_mul(acc.x, PP);
-    F X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    F Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(acc.y, PPP));
+    const auto PP = fe_sqr(P);
+    const auto PPP = fe_mul(P, PP);
+    const auto Q = fe_mul(acc.x, PP);
+    const auto X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    const auto Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(acc.y, PPP));
     acc.x = X3;
     acc.y = Y3;
     acc.zz = fe_mul(acc.zz, PP);
@@ -126,22 +127,22 @@ template <class F> FF_INLINE void xyzz_add_impl(Xyzz<F>& acc, const Xyzz<F>& q) 
         acc = q;
         return;
     }
-    F U1 = fe_mul(acc.x, q.zz);
-    F U2 = fe_mul(q.x, acc.zz);
-    F S1 = fe_mul(acc.y, q.zzz);
-    F S2 = fe_mul(q.y, acc.zzz);
-    F P = fe_sub(U2, U1);
-    F R = fe_sub(S2, S1);
+    const auto U1 = fe_mul(acc.x, q.zz);
+    const auto U2 = fe_mul(q.x, acc.zz);
+    const auto S1 = fe_mul(acc.y, q.zzz);
+    const auto S2 = fe_mul(q.y, acc.zzz);
+    const auto P = fe_sub(U2, U1);
+    const auto R = fe_sub(S2, S1);
     if (fe_is_zero(P)) {
         if (fe_is_zero(R)) acc = xyzz_dbl_impl(acc);
         else acc = xyzz_inf<F>();
         return;
     }
-    F PP = fe_sqr(P);
-    F PPP = fe_mul(P, PP);
-    F Q = fe_mul(U1, PP);
-    F X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    F Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(S1, PPP));
+    const auto PP = fe_sqr(P);
+    const auto PPP = fe_mul(P, PP);
+    const auto Q = fe_mul(U1, PP);
+    const auto X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    const auto Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(S1, PPP));
     acc.x = X3;
     acc.y = Y3;
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), PP);
@@ -167,9 +168,9 @@ template <class F> FF_INLINE Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
 // one inversion: 1/(ZZ*ZZZ)
 template <class F> FF_INLINE Aff<F> xyzz_to_aff(const Xyzz<F>& p) {
     if (xyzz_is_inf(p)) return aff_inf<F>();
-    F i = fe_inv(fe_mul(p.zz, p.zzz));
-    F izz = fe_mul(i, p.zzz);
-    F izzz = fe_mul(i, p.zz);
+    const auto i = fe_inv(fe_mul(p.zz, p.zzz));
+    const auto izz = fe_mul(i, p.zzz);
+    const auto izzz = fe_mul(i, p.zz);
     return {fe_mul(p.x, izz), fe_mul(p.y, izzz)};
 }
 // k * p for a small non-negative k (bucket index weights), double-and-add from the top bit
@@ -184,16 +185,15 @@ template <class F> FF_INLINE Xyzz<F> xyzz_mul_u32(const Xyzz<F>& p, uint32_t k) 
 
 // ---- memory layout: affine points are stored as consecutive Montgomery coordinates
 //      (G1: x | y = 96 B; G2: x.c0 | x.c1 | y.c0 | y.c1 = 192 B), XYZZ as x | y | zz | zzz.
-FF_INLINE Fp load_f(const Fp*, const void* p) { return fe_load<FpParams>(p); }
-FF_INLINE Fp2 load_f(const Fp2*, const void* p) {
-    return {fe_load<FpParams>(p), fe_load<FpParams>((const char*)p + 48)};
-}
-FF_INLINE Fp2H load_f(const Fp2H*, const void* p) { return {fe_load<FpParams>((const char*)p + 48 * pair_comp())}; }
-FF_INLINE void store_f(void* p, const Fp2H& a) { fe_store<FpParams>((char*)p + 48 * pair_comp(), a.v); }
-FF_INLINE void store_f(void* p, const Fp& a) { fe_store<FpParams>(p, a); }
+//      Memory always holds fully reduced coordinates as 12 dense 32-bit words (48 B).
+FF_INLINE Fp load_f(const Fp*, const void* p) { return fp_load(p); }
+FF_INLINE Fp2 load_f(const Fp2*, const void* p) { return {fp_load(p), fp_load((const char*)p + 48)}; }
+FF_INLINE Fp2H load_f(const Fp2H*, const void* p) { return {fp_load((const char*)p + 48 * pair_comp())}; }
+FF_INLINE void store_f(void* p, const Fp2H& a) { fp_store((char*)p + 48 * pair_comp(), a.v); }
+FF_INLINE void store_f(void* p, const Fp& a) { fp_store(p, a); }
 FF_INLINE void store_f(void* p, const Fp2& a) {
-    fe_store<FpParams>(p, a.c0);
-    fe_store<FpParams>((char*)p + 48, a.c1);
+    fp_store(p, a.c0);
+    fp_store((char*)p + 48, a.c1);
 }
 template <class F> FF_INLINE Aff<F> aff_load(const void* p) {
     constexpr int B = FieldOps<F>::WORDS * 4;

@@ -28,38 +28,38 @@
 namespace zk {
 
 // ------------------------------------------------------------------ byte <-> Montgomery conversions
-// 48 B big-endian -> 12 little-endian u32 limbs
-FF_INLINE Fp fp_from_be(const uint8_t* p) {
-    Fp r;
+// 48 B big-endian <-> 12 little-endian dense words (the plain integer, not Montgomery)
+FF_INLINE FpWords fpw_from_be(const uint8_t* p) {
+    FpWords r;
     const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.v[i] = __builtin_bswap32(w[11 - i]);
+    for (int i = 0; i < 12; i++) r.w[i] = __builtin_bswap32(w[11 - i]);
     return r;
 }
-FF_INLINE void fp_to_be(uint8_t* p, const Fp& a) {
+FF_INLINE void fpw_to_be(uint8_t* p, const FpWords& a) {
     uint32_t* w = reinterpret_cast<uint32_t*>(p);
 #pragma unroll
-    for (int i = 0; i < 12; i++) w[11 - i] = __builtin_bswap32(a.v[i]);
+    for (int i = 0; i < 12; i++) w[11 - i] = __builtin_bswap32(a.w[i]);
 }
-FF_INLINE bool fp_canonical(const Fp& a) { return fe_is_canonical(a); }
+FF_INLINE bool fpw_canonical(const FpWords& a) { return words_are_canonical<FpParams>(a.w); }
 
 // G1: x | y ; G2: x1 | x0 | y1 | y0  (ZCash uncompressed)
 FF_INLINE int aff_decode(Aff<Fp>& out, const uint8_t* p) {
     uint8_t flags = p[0];
     if (flags & 0x80) return 2;                       // compressed encodings are not accepted here
     if (flags & 0x40) { out = aff_inf<Fp>(); return 0; }
-    Fp x = fp_from_be(p), y = fp_from_be(p + 48);
-    if (!fp_canonical(x) || !fp_canonical(y)) return 2;
-    out = {fe_to_mont(x), fe_to_mont(y)};
+    const FpWords x = fpw_from_be(p), y = fpw_from_be(p + 48);
+    if (!fpw_canonical(x) || !fpw_canonical(y)) return 2;
+    out = {fp_to_mont(x), fp_to_mont(y)};
     return 0;
 }
 FF_INLINE int aff_decode(Aff<Fp2>& out, const uint8_t* p) {
     uint8_t flags = p[0];
     if (flags & 0x80) return 2;
     if (flags & 0x40) { out = aff_inf<Fp2>(); return 0; }
-    Fp x1 = fp_from_be(p), x0 = fp_from_be(p + 48), y1 = fp_from_be(p + 96), y0 = fp_from_be(p + 144);
-    if (!fp_canonical(x0) || !fp_canonical(x1) || !fp_canonical(y0) || !fp_canonical(y1)) return 2;
-    out = {{fe_to_mont(x0), fe_to_mont(x1)}, {fe_to_mont(y0), fe_to_mont(y1)}};
+    const FpWords x1 = fpw_from_be(p), x0 = fpw_from_be(p + 48), y1 = fpw_from_be(p + 96), y0 = fpw_from_be(p + 144);
+    if (!fpw_canonical(x0) || !fpw_canonical(x1) || !fpw_canonical(y0) || !fpw_canonical(y1)) return 2;
+    out = {{fp_to_mont(x0), fp_to_mont(x1)}, {fp_to_mont(y0), fp_to_mont(y1)}};
     return 0;
 }
 FF_INLINE void aff_encode(uint8_t* p, const Aff<Fp>& a) {
@@ -69,8 +69,8 @@ FF_INLINE void aff_encode(uint8_t* p, const Aff<Fp>& a) {
         p[0] = 0x40;
         return;
     }
-    fp_to_be(p, fe_from_mont(a.x));
-    fp_to_be(p + 48, fe_from_mont(a.y));
+    fpw_to_be(p, fp_from_mont(a.x));
+    fpw_to_be(p + 48, fp_from_mont(a.y));
 }
 FF_INLINE void aff_encode(uint8_t* p, const Aff<Fp2>& a) {
     if (aff_is_inf(a)) {
@@ -79,10 +79,10 @@ FF_INLINE void aff_encode(uint8_t* p, const Aff<Fp2>& a) {
         p[0] = 0x40;
         return;
     }
-    fp_to_be(p, fe_from_mont(a.x.c1));
-    fp_to_be(p + 48, fe_from_mont(a.x.c0));
-    fp_to_be(p + 96, fe_from_mont(a.y.c1));
-    fp_to_be(p + 144, fe_from_mont(a.y.c0));
+    fpw_to_be(p, fp_from_mont(a.x.c1));
+    fpw_to_be(p + 48, fp_from_mont(a.x.c0));
+    fpw_to_be(p + 96, fp_from_mont(a.y.c1));
+    fpw_to_be(p + 144, fp_from_mont(a.y.c0));
 }
 
 template <class F> __global__ void k_bytes_to_affine(uint8_t* dst, const uint8_t* src, uint64_t n, int* flag) {
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
         }
         uint32_t v = sorted[pos];
         Aff<F> p = aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
-        if (v >> 31) p.y = fe_neg(p.y);
+        if (v >> 31) p.y = fe_neg(fp_assume<1>(p.y));      // table entries are fully reduced: -y = 2p - y
         // The mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk (through the
         // out-of-line call it round-trips through scratch: measured 1.5 GB of HBM-side traffic per G1
         // launch against 25 MB algorithmic).  G2 runs here as F = Fp2H, one Fp2 component per lane of a
@@ -461,23 +461,23 @@ template <class F> __global__ void k_xyzz_sum_columns(uint8_t* out, const uint8_
 // pow2[k] = 2^k * G (affine), 256 entries per curve, built once by 256 lanes.
 template <class F> FF_INLINE Aff<F> generator();
 template <> FF_INLINE Aff<Fp> generator<Fp>() {
-    // canonical generator coordinates as little-endian limbs, converted to Montgomery
-    Fp x = {{0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
-             0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u}};
-    Fp y = {{0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
-             0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u}};
-    return {fe_to_mont(x), fe_to_mont(y)};
+    // canonical generator coordinates as little-endian words, converted to Montgomery
+    const FpWords x = {{0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu,
+                        0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u}};
+    const FpWords y = {{0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu,
+                        0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u}};
+    return {fp_to_mont(x), fp_to_mont(y)};
 }
 template <> FF_INLINE Aff<Fp2> generator<Fp2>() {
-    Fp x0 = {{0xc121bdb8u, 0xd48056c8u, 0xa805bbefu, 0x0bac0326u, 0x7ae3d177u, 0xb4510b64u,
-              0xfa403b02u, 0xc6e47ad4u, 0x2dc51051u, 0x26080527u, 0xf08f0a91u, 0x024aa2b2u}};
-    Fp x1 = {{0x5d042b7eu, 0xe5ac7d05u, 0x13945d57u, 0x334cf112u, 0xdc7f5049u, 0xb5da61bbu,
-              0x9920b61au, 0x596bd0d0u, 0x88274f65u, 0x7dacd3a0u, 0x52719f60u, 0x13e02b60u}};
-    Fp y0 = {{0x08b82801u, 0xe1935486u, 0x3baca289u, 0x923ac9ccu, 0x5160d12cu, 0x6d429a69u,
-              0x8cbdd3a7u, 0xadfd9baau, 0xda2e351au, 0x8cc9cdc6u, 0x727d6e11u, 0x0ce5d527u}};
-    Fp y1 = {{0xf05f79beu, 0xaaa9075fu, 0x5cec1da1u, 0x3f370d27u, 0x572e99abu, 0x267492abu,
-              0x85a763afu, 0xcb3e287eu, 0x2bc28b99u, 0x32acd2b0u, 0x2ea734ccu, 0x0606c4a0u}};
-    return {{fe_to_mont(x0), fe_to_mont(x1)}, {fe_to_mont(y0), fe_to_mont(y1)}};
+    const FpWords x0 = {{0xc121bdb8u, 0xd48056c8u, 0xa805bbefu, 0x0bac0326u, 0x7ae3d177u, 0xb4510b64u,
+                         0xfa403b02u, 0xc6e47ad4u, 0x2dc51051u, 0x26080527u, 0xf08f0a91u, 0x024aa2b2u}};
+    const FpWords x1 = {{0x5d042b7eu, 0xe5ac7d05u, 0x13945d57u, 0x334cf112u, 0xdc7f5049u, 0xb5da61bbu,
+                         0x9920b61au, 0x596bd0d0u, 0x88274f65u, 0x7dacd3a0u, 0x52719f60u, 0x13e02b60u}};
+    const FpWords y0 = {{0x08b82801u, 0xe1935486u, 0x3baca289u, 0x923ac9ccu, 0x5160d12cu, 0x6d429a69u,
+                         0x8cbdd3a7u, 0xadfd9baau, 0xda2e351au, 0x8cc9cdc6u, 0x727d6e11u, 0x0ce5d527u}};
+    const FpWords y1 = {{0xf05f79beu, 0xaaa9075fu, 0x5cec1da1u, 0x3f370d27u, 0x572e99abu, 0x267492abu,
+                         0x85a763afu, 0xcb3e287eu, 0x2bc28b99u, 0x32acd2b0u, 0x2ea734ccu, 0x0606c4a0u}};
+    return {{fp_to_mont(x0), fp_to_mont(x1)}, {fp_to_mont(y0), fp_to_mont(y1)}};
 }
 template <class F> __global__ void k_gen_pow2_table(uint8_t* table) {
     constexpr int AB = FieldOps<F>::WORDS * 8;

@@ -60,23 +60,41 @@ ScopedTimer::~ScopedTimer() {
 }
 
 // one multiplication chain per lane; all 256 CUs x 8 waves/SIMD busy
-template <class P> __global__ void k_bench_mul(uint32_t* out, uint32_t iters) {
-    Fe<P> x, y;
+__global__ void k_bench_mul_fr(uint32_t* out, uint32_t iters) {
+    Fr x, y;
 #pragma unroll
-    for (int i = 0; i < P::N; i++) {
-        x.v[i] = Consts<P>::r1(i) ^ (threadIdx.x * 2654435761u >> (i & 7));
-        y.v[i] = Consts<P>::r2(i) + blockIdx.x;
+    for (int i = 0; i < 8; i++) {
+        x.v[i] = FR_R1[i] ^ (threadIdx.x * 2654435761u >> (i & 7));
+        y.v[i] = FR_R2[i] + blockIdx.x;
     }
-    x.v[P::N - 1] &= 0x0fffffffu;
-    y.v[P::N - 1] &= 0x0fffffffu;
+    x.v[7] &= 0x0fffffffu;
+    y.v[7] &= 0x0fffffffu;
     for (uint32_t i = 0; i < iters; i++) {
         x = fe_mul_inline(x, y);
         y = fe_mul_inline(y, x);
     }
     uint32_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < P::N; i++) acc ^= x.v[i] ^ y.v[i];
+    for (int i = 0; i < 8; i++) acc ^= x.v[i] ^ y.v[i];
     if (acc == 0x12345678u) out[0] = acc;   // keep the chain live
+}
+__global__ void k_bench_mul_fp(uint32_t* out, uint32_t iters) {
+    FpB<2> x, y;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) {
+        x.v[i] = (FP29_R1[i] ^ (threadIdx.x * 2654435761u >> (i & 7))) & FP29_MASK;
+        y.v[i] = (FP29_R2[i] + blockIdx.x) & FP29_MASK;
+    }
+    x.v[FPL - 1] &= 7;
+    y.v[FPL - 1] &= 7;
+    for (uint32_t i = 0; i < iters; i++) {
+        x = fe_mul_inline(x, y);
+        y = fe_mul_inline(y, x);
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) acc ^= x.v[i] ^ y.v[i];
+    if (acc == 0x12345678u) out[0] = acc;
 }
 
 }  // namespace zk
@@ -210,8 +228,8 @@ int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s) {
     kind &= 3;
     for (int rep = 0; rep < 2; rep++) {
         HIPCHK(hipEventRecord(a, c.stream));
-        if (kind == 0) hipLaunchKernelGGL(k_bench_mul<FrParams>, dim3(blocks), dim3(threads), 0, c.stream, out.as<uint32_t>(), iters);
-        else hipLaunchKernelGGL(k_bench_mul<FpParams>, dim3(blocks), dim3(threads), 0, c.stream, out.as<uint32_t>(), iters);
+        if (kind == 0) hipLaunchKernelGGL(k_bench_mul_fr, dim3(blocks), dim3(threads), 0, c.stream, out.as<uint32_t>(), iters);
+        else hipLaunchKernelGGL(k_bench_mul_fp, dim3(blocks), dim3(threads), 0, c.stream, out.as<uint32_t>(), iters);
         HIPCHK(hipEventRecord(b, c.stream));
         HIPCHK(hipStreamSynchronize(c.stream));
     }
