@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
-    ap.add_argument("--inflight", type=int, default=6, help="proofs kept in flight on one GPU (1 = strictly serial)")
+    ap.add_argument("--inflight", type=int, default=12, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,7 +130,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    depth = max(1, min(args.inflight, 8))
+    depth = max(1, min(args.inflight, 14))      # the chip runs 16 hardware queues side by side; keep two spare
     if world > 1:
         depth = min(depth, 3)      # sharded proofs: the host runs an all-gather + combine per proof
 

@@ -42,7 +42,7 @@ struct Slot {
         if (host) (void)hipHostFree(host);
     }
 };
-static constexpr uint32_t MAX_SLOTS = 8;
+static constexpr uint32_t MAX_SLOTS = 16;
 
 struct Groth16Key {
     uint32_t n = 0, m = 0, n_mid = 0;
@@ -109,7 +109,7 @@ static int key_lookup(uint64_t handle, Groth16Key** out) {
 }
 
 static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
-    if (idx >= MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "slot index out of range (max 8 proofs in flight)");
+    if (idx >= MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "slot index out of range (max 16 proofs in flight)");
     if (!k.slots[idx]) {
         auto sl = std::make_unique<Slot>();
         ZKCHK(frstage_scratch_alloc(k.fr, sl->fs));
@@ -124,7 +124,12 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
         ZKCHK(msm_workspace_alloc(sl->wsC, k.g1));
         ZKCHK(msm_workspace_alloc(sl->wsB, k.g2));
         HIPCHK(hipStreamCreateWithFlags(&sl->s0, hipStreamNonBlocking));
-        if (getenv("ZK_SERIAL_STREAMS")) {       // profiling aid: un-overlapped kernel durations
+        // One stream per proof by default: the chip runs at most 16 hardware queues side by side and
+        // falls off a cliff beyond (24 streams x 1 ms of 1-workgroup kernels: 72 ms, scripts/proto/concurrency.hip),
+        // so queues are better spent on MORE PROOFS in flight than on the three MSMs of one proof
+        // (2^16: 3.9 ms/proof with 8 x 3 streams, 2.9 ms with 15 x 1).  ZK_SLOT_STREAMS=3 restores the fork.
+        const char* ss = getenv("ZK_SLOT_STREAMS");
+        if (getenv("ZK_SERIAL_STREAMS") || !ss || atoi(ss) < 3) {
             sl->s1 = sl->s2 = sl->s0;
             sl->serial = true;
         } else {
@@ -267,7 +272,7 @@ int zk_groth16_pk_free(uint64_t handle) {
 int zk_groth16_reserve_slots(uint64_t handle, uint32_t count) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    if (count > MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_reserve_slots: at most 8 slots");
+    if (count > MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_reserve_slots: at most 16 slots");
     for (uint32_t i = 0; i < count; i++) {
         Slot* sl;
         ZKCHK(slot_get(*k, i, &sl));
