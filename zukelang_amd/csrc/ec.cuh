@@ -183,6 +183,17 @@ template <class F> FF_INLINE Xyzz<F> xyzz_mul_u32(const Xyzz<F>& p, uint32_t k) 
     return acc;
 }
 
+// same with the group operations expanded in place (field products stay out of line): for kernels whose
+// points live in registers from load to store
+template <class F> FF_INLINE Xyzz<F> xyzz_mul_u32_inl(const Xyzz<F>& p, uint32_t k) {
+    Xyzz<F> acc = xyzz_inf<F>();
+    for (int b = 31 - __builtin_clz(k | 1); b >= 0; b--) {
+        acc = xyzz_dbl_impl(acc);
+        if ((k >> b) & 1) xyzz_add_impl(acc, p);
+    }
+    return acc;
+}
+
 // ---- memory layout: affine points are stored as consecutive Montgomery coordinates
 //      (G1: x | y = 96 B; G2: x.c0 | x.c1 | y.c0 | y.c1 = 192 B), XYZZ as x | y | zz | zzz.
 //      Memory always holds fully reduced coordinates as 12 dense 32-bit words (48 B).
@@ -217,6 +228,73 @@ template <class F> FF_INLINE void xyzz_store(void* p, const Xyzz<F>& a) {
     store_f(c + B, a.y);
     store_f(c + 2 * B, a.zz);
     store_f(c + 3 * B, a.zzz);
+}
+
+// ---- internal ("raw") layout of intermediate XYZZ points (bucket sums and everything downstream of them):
+//      every Fp component as its 14 register limbs in a 16-word slot (64 B, 128-bit accesses), lazily reduced
+//      exactly as in registers.  Writing and reading back is a plain copy: no reduction, no repacking.
+//      G1: x | y | zz | zzz = 256 B;  G2: x.c0 | x.c1 | y.c0 | ... = 512 B.  Zero-filled memory is the identity.
+template <class F> struct RawLayout;
+template <> struct RawLayout<Fp> { static constexpr int ELEM = 64, XYZZ = 256, LANES = 1; };
+template <> struct RawLayout<Fp2> { static constexpr int ELEM = 128, XYZZ = 512, LANES = 1; };
+template <> struct RawLayout<Fp2H> { static constexpr int ELEM = 128, XYZZ = 512, LANES = 2; };
+FF_INLINE Fp fp_load_raw(const void* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    Fp r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w;
+    r.v[12] = d.x; r.v[13] = d.y;
+    return r;
+}
+FF_INLINE void fp_store_raw(void* p, const Fp& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+    q[2] = make_uint4(a.v[8], a.v[9], a.v[10], a.v[11]);
+    q[3] = make_uint4(a.v[12], a.v[13], 0u, 0u);
+}
+FF_INLINE Fp load_raw_f(const Fp*, const void* p) { return fp_load_raw(p); }
+FF_INLINE Fp2 load_raw_f(const Fp2*, const void* p) { return {fp_load_raw(p), fp_load_raw((const char*)p + 64)}; }
+FF_INLINE Fp2H load_raw_f(const Fp2H*, const void* p) { return {fp_load_raw((const char*)p + 64 * pair_comp())}; }
+FF_INLINE void store_raw_f(void* p, const Fp& a) { fp_store_raw(p, a); }
+FF_INLINE void store_raw_f(void* p, const Fp2& a) {
+    fp_store_raw(p, a.c0);
+    fp_store_raw((char*)p + 64, a.c1);
+}
+FF_INLINE void store_raw_f(void* p, const Fp2H& a) { fp_store_raw((char*)p + 64 * pair_comp(), a.v); }
+template <class F> FF_INLINE Xyzz<F> xyzz_load_raw(const void* p) {
+    constexpr int B = RawLayout<F>::ELEM;
+    const char* c = (const char*)p;
+    return {load_raw_f((const F*)nullptr, c), load_raw_f((const F*)nullptr, c + B), load_raw_f((const F*)nullptr, c + 2 * B),
+            load_raw_f((const F*)nullptr, c + 3 * B)};
+}
+template <class F> FF_INLINE void xyzz_store_raw(void* p, const Xyzz<F>& a) {
+    constexpr int B = RawLayout<F>::ELEM;
+    char* c = (char*)p;
+    store_raw_f(c, a.x);
+    store_raw_f(c + B, a.y);
+    store_raw_f(c + 2 * B, a.zz);
+    store_raw_f(c + 3 * B, a.zzz);
+}
+// the 4 x 14 limbs one lane holds of a point (a whole G1 point, or one Fp2 component of a G2 point)
+static constexpr int LANE_POINT_WORDS = 4 * FPL;
+FF_INLINE void xyzz_to_words(uint32_t* w, const Xyzz<Fp>& a) {
+#pragma unroll
+    for (int i = 0; i < FPL; i++) { w[i] = a.x.v[i]; w[FPL + i] = a.y.v[i]; w[2 * FPL + i] = a.zz.v[i]; w[3 * FPL + i] = a.zzz.v[i]; }
+}
+FF_INLINE void xyzz_from_words(Xyzz<Fp>& a, const uint32_t* w) {
+#pragma unroll
+    for (int i = 0; i < FPL; i++) { a.x.v[i] = w[i]; a.y.v[i] = w[FPL + i]; a.zz.v[i] = w[2 * FPL + i]; a.zzz.v[i] = w[3 * FPL + i]; }
+}
+FF_INLINE void xyzz_to_words(uint32_t* w, const Xyzz<Fp2H>& a) {
+#pragma unroll
+    for (int i = 0; i < FPL; i++) { w[i] = a.x.v.v[i]; w[FPL + i] = a.y.v.v[i]; w[2 * FPL + i] = a.zz.v.v[i]; w[3 * FPL + i] = a.zzz.v.v[i]; }
+}
+FF_INLINE void xyzz_from_words(Xyzz<Fp2H>& a, const uint32_t* w) {
+#pragma unroll
+    for (int i = 0; i < FPL; i++) { a.x.v.v[i] = w[i]; a.y.v.v[i] = w[FPL + i]; a.zz.v.v[i] = w[2 * FPL + i]; a.zzz.v.v[i] = w[3 * FPL + i]; }
 }
 
 }  // namespace zk

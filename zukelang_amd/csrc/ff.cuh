@@ -476,13 +476,28 @@ __device__ __noinline__ static FpRaw fp_sqr_call(FP_ARGS(a)) {
     fp_sqr_limbs(r.v, x);
     return r;
 }
+// A translation unit that defines ZK_FP_INLINE_MUL before including this header gets the products
+// expanded in place (the G1 bucket-accumulation loop: no call boundary, so the loads of the next point
+// stay in flight across the whole mixed addition).
 template <int A, int B> FF_INLINE FpB<2> fe_mul(const FpB<A>& a, const FpB<B>& b) {
     static_assert((long long)A * B <= FP_MUL_BUDGET, "operand bounds exceed the Montgomery headroom");
+#ifdef ZK_FP_INLINE_MUL
+    FpB<2> r;
+    fp_mul_limbs(r.v, a.v, b.v);
+    return r;
+#else
     return fp_from_raw<2>(fp_mul_call(FP_PASS(a.v), FP_PASS(b.v)));
+#endif
 }
 template <int A> FF_INLINE FpB<2> fe_sqr(const FpB<A>& a) {
     static_assert((long long)A * A <= FP_MUL_BUDGET, "operand bound exceeds the Montgomery headroom");
+#ifdef ZK_FP_INLINE_MUL
+    FpB<2> r;
+    fp_sqr_limbs(r.v, a.v);
+    return r;
+#else
     return fp_from_raw<2>(fp_sqr_call(FP_PASS(a.v)));
+#endif
 }
 template <int A, int B> FF_INLINE FpB<2> fe_mul_inline(const FpB<A>& a, const FpB<B>& b) {
     static_assert((long long)A * B <= FP_MUL_BUDGET, "operand bounds exceed the Montgomery headroom");

@@ -42,6 +42,9 @@ int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine,
 int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b);
 // d_scalars: n canonical (non-Montgomery) Fr, 32 B each, on device.  d_result: one XYZZ point.
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_result_xyzz, hipStream_t s);
+// step 4 of msm_run (msm_acc_g1.hip / msm_acc_g2.hip)
+int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, const uint32_t* offsets, const uint32_t* sorted, uint32_t nb,
+                          uint32_t chunk, void* buckets, void* head, void* tail, hipStream_t s);
 // XYZZ (device) -> uncompressed bytes (host); count points
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s);
 // same, asynchronous: device XYZZ -> device bytes (no allocation, no synchronization)

@@ -251,199 +251,159 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
     if (t == 1023) offsets[nb] = part[1023];
 }
 
-// ------------------------------------------------------------------ accumulate
-template <class F>
-__global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __restrict__ table, const uint32_t* __restrict__ offsets,
-                                                        const uint32_t* __restrict__ sorted, uint32_t nb, uint32_t chunk,
-                                                        uint8_t* __restrict__ buckets, uint8_t* __restrict__ head,
-                                                        uint8_t* __restrict__ tail) {
-    constexpr int AB = FieldOps<F>::WORDS * 8, XB = FieldOps<F>::WORDS * 16;
-    constexpr bool PAIR = std::is_same<F, Fp2H>::value;      // G2: two lanes per chunk, one Fp2 component each
-    const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);
-    const uint32_t N = offsets[nb];
-    uint64_t start64 = t * chunk;
-    if (start64 >= N) return;
-    uint32_t pos = (uint32_t)start64;
-    const uint32_t end = min(pos + chunk, N);
-    // largest kb with offsets[kb] <= pos (then offsets[kb+1] > pos, so the bucket is non-empty)
-    uint32_t lo = 0, hi = nb;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (offsets[mid] <= pos) lo = mid; else hi = mid;
-    }
-    uint32_t kb = lo;
-    // Flat loop: one mixed addition per lane per iteration whatever the run boundaries are (a loop
-    // nest over runs would make the wave pay the longest run of every lane in turn).  A lane
-    // crossing into the next bucket stores its running sum first -- a short divergent epilogue.
-    uint32_t bstart = offsets[kb], bend = offsets[kb + 1];
-    uint32_t seg_start = pos;
-    bool first = true;
-    Xyzz<F> acc = xyzz_inf<F>();
-    for (; pos < end; pos++) {
-        if (pos == bend) {                              // run finished inside the chunk
-            const bool complete = seg_start == bstart;
-            uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
-            xyzz_store<F>(dst, acc);
-            first = false;
-            acc = xyzz_inf<F>();
-            do { kb++; bstart = bend; bend = offsets[kb + 1]; } while (bend == bstart);   // skip empty buckets
-            seg_start = pos;
-        }
-        uint32_t v = sorted[pos];
-        Aff<F> p = aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
-        if (v >> 31) p.y = fe_neg(fp_assume<1>(p.y));      // table entries are fully reduced: -y = 2p - y
-        // The mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk (through the
-        // out-of-line call it round-trips through scratch: measured 1.5 GB of HBM-side traffic per G1
-        // launch against 25 MB algorithmic).  G2 runs here as F = Fp2H, one Fp2 component per lane of a
-        // pair, which gives it the register footprint of G1; a whole Fp2 accumulator per lane needs > 512
-        // registers inlined and 2.3 GB of scratch traffic per launch out of line.
-        if constexpr (std::is_same<F, Fp2>::value) xyzz_madd(acc, p);
-        else xyzz_madd_impl(acc, p);
-    }
-    {
-        const bool complete = (seg_start == bstart) && (end == bend);
-        uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
-        xyzz_store<F>(dst, acc);
-    }
-}
+// ------------------------------------------------------------------ accumulate: msm_acc.hip
 // A run cut by chunk borders left one partial sum per chunk.  Usually that is a handful per bucket
 // (one lane adds them); a bucket that swallowed a large share of the digits (boolean-heavy witnesses,
 // or a top window whose digit is only 0 / 1) leaves thousands: those go to a worklist and get a whole
 // workgroup each (strided lane sums + LDS tree), so the longest chain is count/256 + 8 instead of count.
+//
+// Everything from here to k_msm_final works on the RAW point layout (ec.cuh) with the group operations
+// expanded in place: a point travels registers -> memory -> registers without reduction or repacking and
+// the kernels use no scratch memory.  T is Fp (G1, one lane per point) or Fp2H (G2, a lane PAIR per
+// point: half the registers and two instead of three dependent base-field products per Fp2 product --
+// these kernels are chains of dependent additions run by a few waves, so latency is what they cost).
+template <class T> struct Lanes { static constexpr uint32_t N = RawLayout<T>::LANES; };
 static constexpr uint32_t FIXUP_SERIAL_MAX = 16;
-template <class F>
+template <class T>
 __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t chunk,
                                                    uint8_t* __restrict__ buckets, const uint8_t* __restrict__ head,
                                                    const uint8_t* __restrict__ tail, uint32_t* __restrict__ worklist) {
-    constexpr int XB = FieldOps<F>::WORDS * 16;
-    const uint32_t kb = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int XB = RawLayout<T>::XYZZ;
+    const uint32_t kb = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<T>::N;
     if (kb >= nb) return;
     const uint32_t s = offsets[kb], e = offsets[kb + 1];
-    if (e == s) return;                                 // empty: the bucket array was zero-filled = identity
+    if (e == s) return;                                 // empty bucket: nobody reads its slot
     const uint32_t t0 = s / chunk, t1 = (e - 1) / chunk;
     if (t0 == t1) return;                               // whole run inside one chunk: written directly
     if (t1 - t0 > FIXUP_SERIAL_MAX) {
-        worklist[1 + atomicAdd(&worklist[0], 1u)] = kb;
+        if ((threadIdx.x & (Lanes<T>::N - 1)) == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = kb;
         return;
     }
-    Xyzz<F> acc = xyzz_load<F>((s == t0 * chunk ? head : tail) + (uint64_t)XB * t0);
+    Xyzz<T> acc = xyzz_load_raw<T>((s == t0 * chunk ? head : tail) + (uint64_t)XB * t0);
     for (uint32_t t = t0 + 1; t <= t1; t++) {
-        Xyzz<F> q = xyzz_load<F>(head + (uint64_t)XB * t);
-        xyzz_add(acc, q);
+        const Xyzz<T> q = xyzz_load_raw<T>(head + (uint64_t)XB * t);
+        xyzz_add_impl(acc, q);
     }
-    xyzz_store<F>(buckets + (uint64_t)XB * kb, acc);
+    xyzz_store_raw<T>(buckets + (uint64_t)XB * kb, acc);
 }
-template <class F, int NT> FF_INLINE void block_tree_sum(Xyzz<F>& acc, uint32_t (*lds)[NT]);
-template <class F>
+// sum of the accumulators of the NT / lanes points of a workgroup, result in point 0
+template <class T, int NT> FF_INLINE void block_tree_sum(Xyzz<T>& acc, uint32_t (*lds)[NT]) {
+    constexpr uint32_t LP = Lanes<T>::N;
+    const uint32_t t = threadIdx.x, pi = t / LP;
+    uint32_t tmp[LANE_POINT_WORDS];
+    for (uint32_t d = NT / LP / 2; d >= 1; d >>= 1) {
+        __syncthreads();
+        if (pi >= d && pi < 2 * d) {
+            xyzz_to_words(tmp, acc);
+#pragma unroll
+            for (int l = 0; l < LANE_POINT_WORDS; l++) lds[l][t] = tmp[l];
+        }
+        __syncthreads();
+        if (pi < d) {
+#pragma unroll
+            for (int l = 0; l < LANE_POINT_WORDS; l++) tmp[l] = lds[l][t + d * LP];
+            Xyzz<T> q;
+            xyzz_from_words(q, tmp);
+            xyzz_add_impl(acc, q);
+        }
+    }
+}
+template <class T>
 __global__ __launch_bounds__(256) void k_msm_fixup_big(const uint32_t* __restrict__ offsets, uint32_t chunk,
                                                        uint8_t* __restrict__ buckets, const uint8_t* __restrict__ head,
                                                        const uint8_t* __restrict__ tail, const uint32_t* __restrict__ worklist) {
-    constexpr int XB = FieldOps<F>::WORDS * 16, XW = FieldOps<F>::WORDS * 4;
-    __shared__ uint32_t lds[XW][256];
+    constexpr int XB = RawLayout<T>::XYZZ;
+    constexpr uint32_t LP = Lanes<T>::N, NP = 256 / LP;
+    __shared__ uint32_t lds[LANE_POINT_WORDS][256];
     const uint32_t count = worklist[0];
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {        // block-uniform loop
         const uint32_t kb = worklist[1 + i];
         const uint32_t s = offsets[kb], e = offsets[kb + 1];
         const uint32_t t0 = s / chunk, t1 = (e - 1) / chunk;
-        Xyzz<F> acc = xyzz_inf<F>();
-        for (uint32_t t = t0 + threadIdx.x; t <= t1; t += 256) {
+        Xyzz<T> acc = xyzz_inf<T>();
+        for (uint32_t t = t0 + threadIdx.x / LP; t <= t1; t += NP) {
             const uint8_t* src = (t == t0 && s != t0 * chunk) ? tail : head;
-            Xyzz<F> q = xyzz_load<F>(src + (uint64_t)XB * t);
-            xyzz_add(acc, q);
+            const Xyzz<T> q = xyzz_load_raw<T>(src + (uint64_t)XB * t);
+            xyzz_add_impl(acc, q);
         }
-        block_tree_sum<F, 256>(acc, lds);
-        if (threadIdx.x == 0) xyzz_store<F>(buckets + (uint64_t)XB * kb, acc);
+        block_tree_sum<T, 256>(acc, lds);
+        if (threadIdx.x < LP) xyzz_store_raw<T>(buckets + (uint64_t)XB * kb, acc);
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------ bucket reduction: R = sum_w w * B_w, w = b + 1
 // A lone wave issues one instruction every ~4 cycles, so a chain of dependent EC additions costs
-// ~20 us per link whatever the chip is doing: the reduction must be SHALLOW, not merely parallel.
+// ~15 us per link whatever the chip is doing: the reduction must be SHALLOW, not merely parallel.
 // Write w = hi * 2^lb + lo.  Then R = sum_lo lo * S0[lo] + 2^lb * sum_hi hi * S1[hi] with the digit
 // sums S0[d] = sum of buckets whose low digit is d, S1[d] = those whose high digit is d:
-//   digit_sums    one wave per (digit, value): strided loads + LDS tree          depth ~ 2 + 6
+//   digit_sums    64 points per (digit, value): strided loads + LDS tree         depth ~ 2 + 6
 //   digit_weight  d * S[d] by double-and-add (d < 2^lb), LDS tree over d         depth ~ 2 lb + 8
 //   final         2^lb * V1 + V0 (and Horner over windows in classic mode)        depth ~ lb + 1
 // ~40 links instead of the ~100+ of per-lane running sums, and 2x the bucket reads (cheap).
-template <class F, int NT> FF_INLINE void block_tree_sum(Xyzz<F>& acc, uint32_t (*lds)[NT]) {
-    constexpr int XW = FieldOps<F>::WORDS * 4;
-    const uint32_t t = threadIdx.x;
-    __attribute__((aligned(16))) uint32_t tmp[XW];
-    for (uint32_t d = NT / 2; d >= 1; d >>= 1) {
-        __syncthreads();
-        if (t >= d && t < 2 * d) {
-            xyzz_store<F>(tmp, acc);
-#pragma unroll
-            for (int l = 0; l < XW; l++) lds[l][t] = tmp[l];
-        }
-        __syncthreads();
-        if (t < d) {
-#pragma unroll
-            for (int l = 0; l < XW; l++) tmp[l] = lds[l][t + d];
-            Xyzz<F> q = xyzz_load<F>(tmp);
-            xyzz_add(acc, q);
-        }
-    }
-}
+// Empty buckets are recognised from the sort's offsets, so the bucket array is never cleared.
 struct DigitPlan {
     uint32_t nbw, lb, nd0, nd1;
 };
-template <class F>
-__global__ __launch_bounds__(64) void k_msm_digit_sums(const uint8_t* __restrict__ buckets, DigitPlan p, uint8_t* __restrict__ S) {
-    constexpr int XB = FieldOps<F>::WORDS * 16, XW = FieldOps<F>::WORDS * 4;
-    __shared__ uint32_t lds[XW][64];
-    const uint32_t b = blockIdx.x, win = blockIdx.y, t = threadIdx.x;
-    const uint8_t* bw = buckets + (uint64_t)XB * win * p.nbw;
+template <class T>
+__global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(const uint8_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
+                                                                       DigitPlan p, uint8_t* __restrict__ S) {
+    constexpr int XB = RawLayout<T>::XYZZ;
+    constexpr uint32_t LP = Lanes<T>::N;
+    __shared__ uint32_t lds[LANE_POINT_WORDS][64 * LP];
+    const uint32_t b = blockIdx.x, win = blockIdx.y, pt = threadIdx.x / LP;
+    const uint64_t base = (uint64_t)win * p.nbw;
     const bool low = b < p.nd0;
     const uint32_t d = low ? b : b - p.nd0;
     const uint32_t cnt = low ? p.nd1 : p.nd0;
-    Xyzz<F> acc = xyzz_inf<F>();
+    Xyzz<T> acc = xyzz_inf<T>();
     if (d != 0) {                                   // weight 0 never contributes
-        for (uint32_t e = t; e < cnt; e += 64) {
-            uint32_t w = low ? (e << p.lb) + d : (d << p.lb) + e;
-            if (w >= 1 && w <= p.nbw) {
-                Xyzz<F> q = xyzz_load<F>(bw + (uint64_t)XB * (w - 1));
-                xyzz_add(acc, q);
+        for (uint32_t e = pt; e < cnt; e += 64) {
+            const uint32_t w = low ? (e << p.lb) + d : (d << p.lb) + e;
+            if (w >= 1 && w <= p.nbw && offsets[base + w] != offsets[base + w - 1]) {
+                const Xyzz<T> q = xyzz_load_raw<T>(buckets + (uint64_t)XB * (base + w - 1));
+                xyzz_add_impl(acc, q);
             }
         }
     }
-    block_tree_sum<F, 64>(acc, lds);
-    if (t == 0) xyzz_store<F>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
+    block_tree_sum<T, 64 * LP>(acc, lds);
+    if (threadIdx.x < LP) xyzz_store_raw<T>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
 }
 // V[win][k] = sum_d d * S[win][k][d]
-template <class F>
-__global__ __launch_bounds__(256) void k_msm_digit_weight(const uint8_t* __restrict__ S, DigitPlan p, uint8_t* __restrict__ V) {
-    constexpr int XB = FieldOps<F>::WORDS * 16, XW = FieldOps<F>::WORDS * 4;
-    __shared__ uint32_t lds[XW][256];
-    const uint32_t k = blockIdx.x, win = blockIdx.y, t = threadIdx.x;
+template <class T>
+__global__ __launch_bounds__(256 * Lanes<T>::N) void k_msm_digit_weight(const uint8_t* __restrict__ S, DigitPlan p, uint8_t* __restrict__ V) {
+    constexpr int XB = RawLayout<T>::XYZZ;
+    constexpr uint32_t LP = Lanes<T>::N;
+    __shared__ uint32_t lds[LANE_POINT_WORDS][256 * LP];
+    const uint32_t k = blockIdx.x, win = blockIdx.y, pt = threadIdx.x / LP;
     const uint32_t cnt = k == 0 ? p.nd0 : p.nd1;
     const uint8_t* base = S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + (k == 0 ? 0 : p.nd0));
-    Xyzz<F> acc = xyzz_inf<F>();
-    for (uint32_t d = t; d < cnt; d += 256) {
+    Xyzz<T> acc = xyzz_inf<T>();
+    for (uint32_t d = pt; d < cnt; d += 256) {
         if (!d) continue;
-        Xyzz<F> q = xyzz_load<F>(base + (uint64_t)XB * d);
-        Xyzz<F> m = xyzz_mul_u32(q, d);
-        xyzz_add(acc, m);
+        const Xyzz<T> q = xyzz_load_raw<T>(base + (uint64_t)XB * d);
+        const Xyzz<T> m = xyzz_mul_u32_inl(q, d);
+        xyzz_add_impl(acc, m);
     }
-    block_tree_sum<F, 256>(acc, lds);
-    if (t == 0) xyzz_store<F>(V + (uint64_t)XB * (2 * win + k), acc);
+    block_tree_sum<T, 256 * LP>(acc, lds);
+    if (threadIdx.x < LP) xyzz_store_raw<T>(V + (uint64_t)XB * (2 * win + k), acc);
 }
-// W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one lane)
-template <class F> __global__ __launch_bounds__(64) void k_msm_final(const uint8_t* __restrict__ V, uint32_t nw, uint32_t c, uint32_t lb, uint8_t* __restrict__ out) {
-    constexpr int XB = FieldOps<F>::WORDS * 16;
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    Xyzz<F> acc = xyzz_inf<F>();
+// W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one point).
+// The result leaves in the DENSE, fully reduced layout (it is an output of the library).
+template <class T> __global__ __launch_bounds__(64) void k_msm_final(const uint8_t* __restrict__ V, uint32_t nw, uint32_t c, uint32_t lb, uint8_t* __restrict__ out) {
+    constexpr int XB = RawLayout<T>::XYZZ;
+    if (blockIdx.x != 0 || threadIdx.x >= Lanes<T>::N) return;
+    Xyzz<T> acc = xyzz_inf<T>();
     for (uint32_t j = nw; j-- > 0;) {
         if (j != nw - 1)
-            for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl(acc);
-        Xyzz<F> hi = xyzz_load<F>(V + (uint64_t)XB * (2 * j + 1));
-        for (uint32_t k = 0; k < lb; k++) hi = xyzz_dbl(hi);
-        xyzz_add(acc, hi);
-        Xyzz<F> lo = xyzz_load<F>(V + (uint64_t)XB * (2 * j));
-        xyzz_add(acc, lo);
+            for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl_impl(acc);
+        Xyzz<T> hi = xyzz_load_raw<T>(V + (uint64_t)XB * (2 * j + 1));
+        for (uint32_t k = 0; k < lb; k++) hi = xyzz_dbl_impl(hi);
+        xyzz_add_impl(acc, hi);
+        const Xyzz<T> lo = xyzz_load_raw<T>(V + (uint64_t)XB * (2 * j));
+        xyzz_add_impl(acc, lo);
     }
-    xyzz_store<F>(out, acc);
+    xyzz_store<T>(out, acc);
 }
 template <class F> __global__ void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
     constexpr int XB = FieldOps<F>::WORDS * 16;
@@ -613,7 +573,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     if (chunk < 8) chunk = 8;
     w.chunk = chunk;
     w.nthreads = (maxN + chunk - 1) / chunk;
-    const size_t XB = xyzz_bytes(b.curve);
+    const size_t XB = b.curve == CURVE_G1 ? RawLayout<Fp>::XYZZ : RawLayout<Fp2>::XYZZ;      // intermediate points: raw layout
     ZKCHK(w.counts.alloc(4 * (size_t)(w.nbuckets + 1)));
     ZKCHK(w.offsets.alloc(4 * (size_t)(w.nbuckets + 1)));
     ZKCHK(w.cursor.alloc(4 * (size_t)(w.nbuckets + 1)));
@@ -638,7 +598,8 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     return ZK_OK;
 }
 
-template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
+// F: the curve's coordinate field; T: how the reduction kernels hold a point (Fp, or Fp2H lane pairs for G2)
+template <class F, class T> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
     const uint32_t nbw = 1u << (b.c - 1);
     const uint32_t nwin = b.precomp ? 1 : b.nw;
     DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -655,7 +616,6 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
             if (!add && !cy) break;
         }
     }
-    const size_t XB = xyzz_bytes(b.curve);
     {
         ScopedTimer t("msm_sort", s);
         if (w.sort_wgs) {
@@ -671,35 +631,32 @@ template <class F> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, cons
             hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
             hipLaunchKernelGGL(k_msm_scatter, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.cursor.as<uint32_t>(), w.sorted.as<uint32_t>());
         }
-        HIPCHK(hipMemsetAsync(w.buckets.p, 0, XB * w.nbuckets, s));
     }
     {
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2", s, 1);
-        if constexpr (std::is_same<F, Fp2>::value)
-            hipLaunchKernelGGL(k_msm_accumulate<Fp2H>, grid_for(2 * w.nthreads, 128), dim3(128), 0, s, b.table.as<uint8_t>(), w.offsets.as<uint32_t>(),
-                               w.sorted.as<uint32_t>(), w.nbuckets, w.chunk, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
-        else
-            hipLaunchKernelGGL(k_msm_accumulate<F>, grid_for(w.nthreads, 128), dim3(128), 0, s, b.table.as<uint8_t>(), w.offsets.as<uint32_t>(),
-                               w.sorted.as<uint32_t>(), w.nbuckets, w.chunk, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>());
+        ZKCHK(msm_accumulate_launch(b.curve, w.nthreads, b.table.p, w.offsets.as<uint32_t>(), w.sorted.as<uint32_t>(), w.nbuckets, w.chunk,
+                                    w.buckets.p, w.head.p, w.tail.p, s));
     }
     {
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
+        constexpr uint32_t LP = Lanes<T>::N;
         HIPCHK(hipMemsetAsync(w.worklist.p, 0, 4, s));
-        hipLaunchKernelGGL(k_msm_fixup<F>, grid_for(w.nbuckets, 128), dim3(128), 0, s, w.offsets.as<uint32_t>(), w.nbuckets, w.chunk,
+        hipLaunchKernelGGL(k_msm_fixup<T>, grid_for((uint64_t)w.nbuckets * LP, 128), dim3(128), 0, s, w.offsets.as<uint32_t>(), w.nbuckets, w.chunk,
                            w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), w.worklist.as<uint32_t>());
-        hipLaunchKernelGGL(k_msm_fixup_big<F>, dim3(w.nbuckets < 256 ? w.nbuckets : 256), dim3(256), 0, s, w.offsets.as<uint32_t>(), w.chunk,
+        hipLaunchKernelGGL(k_msm_fixup_big<T>, dim3(w.nbuckets < 256 ? w.nbuckets : 256), dim3(256), 0, s, w.offsets.as<uint32_t>(), w.chunk,
                            w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), (const uint32_t*)w.worklist.as<uint32_t>());
         const DigitPlan dp = digit_plan(b.c);
-        hipLaunchKernelGGL(k_msm_digit_sums<F>, dim3(dp.nd0 + dp.nd1, nwin), dim3(64), 0, s, w.buckets.as<uint8_t>(), dp, w.red.as<uint8_t>());
-        hipLaunchKernelGGL(k_msm_digit_weight<F>, dim3(2, nwin), dim3(256), 0, s, w.red.as<uint8_t>(), dp, w.wsum.as<uint8_t>());
-        hipLaunchKernelGGL(k_msm_final<F>, dim3(1), dim3(64), 0, s, w.wsum.as<uint8_t>(), nwin, b.c, dp.lb, (uint8_t*)d_out);
+        hipLaunchKernelGGL(k_msm_digit_sums<T>, dim3(dp.nd0 + dp.nd1, nwin), dim3(64 * LP), 0, s, w.buckets.as<uint8_t>(), (const uint32_t*)w.offsets.as<uint32_t>(), dp,
+                           w.red.as<uint8_t>());
+        hipLaunchKernelGGL(k_msm_digit_weight<T>, dim3(2, nwin), dim3(256 * LP), 0, s, w.red.as<uint8_t>(), dp, w.wsum.as<uint8_t>());
+        hipLaunchKernelGGL(k_msm_final<T>, dim3(1), dim3(64), 0, s, w.wsum.as<uint8_t>(), nwin, b.c, dp.lb, (uint8_t*)d_out);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
     if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.cap_points < b.n) ZK_FAIL(ZK_ERR_ARG, "msm: workspace does not match bases");
-    return b.curve == CURVE_G1 ? msm_run_t<Fp>(b, w, d_scalars, d_out, s) : msm_run_t<Fp2>(b, w, d_scalars, d_out, s);
+    return b.curve == CURVE_G1 ? msm_run_t<Fp, Fp>(b, w, d_scalars, d_out, s) : msm_run_t<Fp2, Fp2H>(b, w, d_scalars, d_out, s);
 }
 int xyzz_sum_columns(Curve curve, void* d_out, const void* d_parts, uint32_t count, uint32_t npoints, hipStream_t s) {
     if (curve == CURVE_G1) hipLaunchKernelGGL(k_xyzz_sum_columns<Fp>, grid_for(npoints, 64), dim3(64), 0, s, (uint8_t*)d_out, (const uint8_t*)d_parts, count, npoints);

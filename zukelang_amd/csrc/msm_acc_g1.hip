@@ -1,0 +1,16 @@
+// G1 bucket accumulation with the field products expanded in place: no call boundary inside the mixed
+// addition, so the gather of the next table entry stays in flight across it (the compiler must drain
+// outstanding loads at every call).  ~40 KB of straight-line code per mixed addition: it fits the
+// 64 KB instruction cache shared by a CU pair.
+#define ZK_FP_INLINE_MUL 1
+#include "msm_acc.cuh"
+
+namespace zk {
+int msm_accumulate_launch_g1(uint64_t nthreads, const void* table, const uint32_t* offsets, const uint32_t* sorted, uint32_t nb, uint32_t chunk,
+                             void* buckets, void* head, void* tail, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm_accumulate<Fp>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, s, (const uint8_t*)table, offsets, sorted, nb, chunk,
+                       (uint8_t*)buckets, (uint8_t*)head, (uint8_t*)tail);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+}  // namespace zk
