@@ -78,7 +78,7 @@ template <class F> FF_INLINE Xyzz<F> xyzz_dbl_impl(const Xyzz<F>& p) {
     const auto X2 = fe_sqr(p.x);
     const auto M = fe_add(fe_dbl(X2), X2);
     const auto X3 = fe_sub(fe_sqr(M), fe_dbl(S));
-    const auto Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
+    const auto Y3 = fe_mul_sub(M, fe_sub(S, X3), W, p.y);
     return {X3, Y3, fe_mul(V, p.zz), fe_mul(W, p.zzz)};
 }
 // mdbl-2008-s-1: doubling of an affine point
@@ -91,7 +91,7 @@ template <class F> FF_INLINE Xyzz<F> xyzz_dbl_aff(const Aff<F>& p) {
     const auto X2 = fe_sqr(p.x);
     const auto M = fe_add(fe_dbl(X2), X2);
     const auto X3 = fe_sub(fe_sqr(M), fe_dbl(S));
-    const auto Y3 = fe_sub(fe_mul(M, fe_sub(S, X3)), fe_mul(W, p.y));
+    const auto Y3 = fe_mul_sub(M, fe_sub(S, X3), W, p.y);
     return {X3, Y3, V, W};
 }
 // madd-2008-s: acc += q (q affine)
@@ -114,7 +114,7 @@ template <class F> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) 
     const auto PPP = fe_mul(P, PP);
     const auto Q = fe_mul(acc.x, PP);
     const auto X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    const auto Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(acc.y, PPP));
+    const auto Y3 = fe_mul_sub(R, fe_sub(Q, X3), acc.y, PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = fe_mul(acc.zz, PP);
@@ -142,7 +142,7 @@ template <class F> FF_INLINE void xyzz_add_impl(Xyzz<F>& acc, const Xyzz<F>& q) 
     const auto PPP = fe_mul(P, PP);
     const auto Q = fe_mul(U1, PP);
     const auto X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    const auto Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(S1, PPP));
+    const auto Y3 = fe_mul_sub(R, fe_sub(Q, X3), S1, PPP);
     acc.x = X3;
     acc.y = Y3;
     acc.zz = fe_mul(fe_mul(acc.zz, q.zz), PP);

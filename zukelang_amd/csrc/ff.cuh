@@ -711,20 +711,72 @@ template <int A, int B> FF_INLINE Fp2HB<A + fp_ks(B)> fe_sub(const Fp2HB<A>& a, 
 template <int A, int B> FF_INLINE bool fe_eq(const Fp2HB<A>& a, const Fp2HB<B>& b) { return fe_is_zero(fe_sub(a, b)); }
 template <int A> FF_INLINE Fp2HB<fp_ks(A)> fe_neg(const Fp2HB<A>& a) { return {fe_neg(a.v)}; }
 template <int A> FF_INLINE Fp2HB<2 * A> fe_dbl(const Fp2HB<A>& a) { return {fe_dbl(a.v)}; }
-// c0 lane: a0 b0 - a1 b1     c1 lane: a0 b1 + a1 b0     (one instruction stream: the c0 lane adds 4p - m2)
-template <int A, int B> FF_INLINE Fp2HB<6> fe_mul(const Fp2HB<A>& a, const Fp2HB<B>& b) {
-    const bool c1 = pair_comp() != 0;
-    const FpB<A> ao = pair_swap(a.v);
-    const FpB<B> bo = pair_swap(b.v);
-    const FpB<A> a0 = fp_select(c1, a.v, ao), a1 = fp_select(c1, ao, a.v);
-    const FpB<2> m1 = fe_mul(a0, b.v);      // c0 lane: a0 b0   c1 lane: a0 b1
-    const FpB<2> m2 = fe_mul(a1, bo);       // c0 lane: a1 b1   c1 lane: a1 b0
-    constexpr int KI = fp_ki(4);
-    FpB<6> r;
+// Fp2 product on a lane pair as ONE fused double product per lane, (x1 y1 + x2 y2) / R with a single
+// Montgomery reduction (28 + 14 partial products per column still fit 64 bits):
+//   c0 lane: a0 b0 + (256p - a1) b1          c1 lane: a0 b1 + a1 b0
+// 588 multiply-adds per lane instead of two full products (784) plus a combining add/sub, and the result
+// is < 2p.  The partner's operands arrive by DPP inside the function, so the call still passes 28 registers.
+FF_INLINE void fp_mul2_limbs(uint32_t* __restrict__ r, const uint32_t* __restrict__ x1, const uint32_t* __restrict__ y1,
+                             const uint32_t* __restrict__ x2, const uint32_t* __restrict__ y2) {
+    uint64_t acc = 0;
+    uint32_t m[FPL];
 #pragma unroll
-    for (int i = 0; i < FPL; i++) r.v[i] = m1.v[i] + (c1 ? m2.v[i] : FP29_KP[KI][i] - m2.v[i]);
-    fp_carry(r.v);
+    for (int k = 0; k < FPL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)x1[i] * y1[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)x2[i] * y2[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * FP29_MOD[k - i];
+        m[k] = ((uint32_t)acc * FP29_NINV) & FP29_MASK;
+        acc += (uint64_t)m[k] * FP29_MOD[0];
+        acc >>= FP29_W;
+    }
+#pragma unroll
+    for (int k = FPL; k < 2 * FPL - 1; k++) {
+#pragma unroll
+        for (int i = k - FPL + 1; i < FPL; i++) acc += (uint64_t)x1[i] * y1[k - i];
+#pragma unroll
+        for (int i = k - FPL + 1; i < FPL; i++) acc += (uint64_t)x2[i] * y2[k - i];
+#pragma unroll
+        for (int i = k - FPL + 1; i < FPL; i++) acc += (uint64_t)m[i] * FP29_MOD[k - i];
+        r[k - FPL] = (uint32_t)acc & FP29_MASK;
+        acc >>= FP29_W;
+    }
+    r[FPL - 1] = (uint32_t)acc;
+}
+static constexpr int FP2H_NEG_K = 256;        // the c0 lane negates a1 as 256p - a1
+FF_INLINE void fp2h_mul_body(uint32_t* __restrict__ r, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b) {
+    const bool c1 = pair_comp() != 0;
+    constexpr int KI = fp_ki(FP2H_NEG_K);
+    uint32_t x1[FPL], x2[FPL], bo[FPL];
+#pragma unroll
+    for (int i = 0; i < FPL; i++) {
+        const uint32_t ao = (uint32_t)__builtin_amdgcn_mov_dpp((int)a[i], 0xB1, 0xF, 0xF, true);
+        bo[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)b[i], 0xB1, 0xF, 0xF, true);
+        x1[i] = c1 ? ao : a[i];
+        x2[i] = c1 ? a[i] : FP29_KP[KI][i] - ao;
+    }
+    fp_carry(x2);
+    fp_mul2_limbs(r, x1, b, x2, bo);
+}
+__device__ __noinline__ static FpRaw fp2h_mul_call(FP_ARGS(a), FP_ARGS(b)) {
+    FP_UNPACK_ARGS(x, a)
+    FP_UNPACK_ARGS(y, b)
+    FpRaw r;
+    fp2h_mul_body(r.v, x, y);
+    return r;
+}
+template <int A, int B> FF_INLINE Fp2HB<2> fe_mul(const Fp2HB<A>& a, const Fp2HB<B>& b) {
+    static_assert(A < FP2H_NEG_K, "operand bound too large for the in-product negation");
+    static_assert(((long long)A + FP2H_NEG_K) * B <= FP_MUL_BUDGET, "operand bounds exceed the Montgomery headroom");
+#ifdef ZK_FP_INLINE_MUL
+    FpB<2> r;
+    fp2h_mul_body(r.v, a.v.v, b.v.v);
     return {r};
+#else
+    return {fp_from_raw<2>(fp2h_mul_call(FP_PASS(a.v.v), FP_PASS(b.v.v)))};
+#endif
 }
 // c0 lane: (a0 + a1)(a0 - a1)     c1 lane: 2 a0 a1
 template <int A> FF_INLINE Fp2HB<4> fe_sqr(const Fp2HB<A>& a) {
@@ -748,5 +800,30 @@ template <int A> FF_INLINE Fp2HB<4> fe_sqr(const Fp2HB<A>& a) {
     fp_carry(r.v);
     return {r};
 }
+
+// a b - c d.  For Fp as ONE fused double product a b + (K p - c) d (one Montgomery reduction instead of
+// two and no subtraction afterwards); for the extension types as the plain composition.
+__device__ __noinline__ static FpRaw fp_mul2_call(FP_ARGS(a), FP_ARGS(b), const uint32_t* __restrict__ cd) {
+    FP_UNPACK_ARGS(x, a)
+    FP_UNPACK_ARGS(y, b)
+    FpRaw r;
+    fp_mul2_limbs(r.v, x, y, cd, cd + FPL);
+    return r;
+}
+template <int A, int B, int C, int D> FF_INLINE FpB<2> fe_mul_sub(const FpB<A>& a, const FpB<B>& b, const FpB<C>& c, const FpB<D>& d) {
+    static_assert((long long)A * B + (long long)fp_ks(C) * D <= FP_MUL_BUDGET, "operand bounds exceed the Montgomery headroom");
+    const auto nc = fe_neg(c);
+#ifdef ZK_FP_INLINE_MUL
+    FpB<2> r;
+    fp_mul2_limbs(r.v, a.v, b.v, nc.v, d.v);
+    return r;
+#else
+    uint32_t cd[2 * FPL];
+#pragma unroll
+    for (int i = 0; i < FPL; i++) { cd[i] = nc.v[i]; cd[FPL + i] = d.v[i]; }
+    return fp_from_raw<2>(fp_mul2_call(FP_PASS(a.v), FP_PASS(b.v), cd));
+#endif
+}
+template <class X, class Y, class Z, class W> FF_INLINE auto fe_mul_sub(const X& a, const Y& b, const Z& c, const W& d) { return fe_sub(fe_mul(a, b), fe_mul(c, d)); }
 
 }  // namespace zk

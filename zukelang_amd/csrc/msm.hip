@@ -570,7 +570,8 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     // >= 2 waves per SIMD when there is enough work; chunks of at least 8 entries
     uint64_t target_threads = 256 * 1024;
     uint32_t chunk = (uint32_t)((maxN + target_threads - 1) / target_threads);
-    if (chunk < 8) chunk = 8;
+    static const uint32_t chunk_min = getenv("ZK_MSM_CHUNK_MIN") ? (uint32_t)atoi(getenv("ZK_MSM_CHUNK_MIN")) : 8;   // tuning knob
+    if (chunk < chunk_min) chunk = chunk_min;
     w.chunk = chunk;
     w.nthreads = (maxN + chunk - 1) / chunk;
     const size_t XB = b.curve == CURVE_G1 ? RawLayout<Fp>::XYZZ : RawLayout<Fp2>::XYZZ;      // intermediate points: raw layout
