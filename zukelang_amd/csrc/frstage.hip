@@ -59,37 +59,61 @@ __global__ void k_scale_pad(uint32_t* out, const uint32_t* in, const uint32_t* t
     }
     fe_store<FrParams>(out + 8 * i, x);
 }
-// tree level fused in LDS (node length 2^log_len <= tile): d[node] <- lo + P_left * hi
-__global__ __launch_bounds__(NTT_THREADS) void k_tree_level_fused(uint32_t* __restrict__ d, const uint32_t* __restrict__ pntt,
-                                                                 const uint32_t* __restrict__ tw_fwd, const uint32_t* __restrict__ tw_inv,
-                                                                 uint32_t log_len, uint32_t log_T, uint64_t tab_mask) {
-    __shared__ uint32_t lds[8][NTT_T];
+// Tree levels 1..levels (node length <= tile) in ONE kernel: the tile stays in LDS across the levels,
+// per level  node <- lo + P_left * hi  = {hi zero-padded -> NTT -> * table -> iNTT -> + lo}.
+// HBM sees the coefficients once in and once out (plus the per-level tables) instead of once per level.
+__global__ __launch_bounds__(NTT_THREADS) void k_tree_levels_fused(uint32_t* __restrict__ d, const uint32_t* __restrict__ pntt,
+                                                                  const uint32_t* __restrict__ tw_fwd, const uint32_t* __restrict__ tw_inv,
+                                                                  uint32_t levels, uint32_t log_T, uint64_t n2) {
+    __shared__ uint32_t lds[8][NTT_T];       // transform workspace
+    __shared__ uint32_t cur[8][NTT_T];       // the tile's coefficients between levels
     const uint32_t T = 1u << log_T;
     const uint64_t base = (uint64_t)blockIdx.x << log_T;
-    const uint32_t half = 1u << (log_len - 1), lm = (half << 1) - 1;
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x = fe_zero<FrParams>();
-        if ((e & lm) < half) x = fe_load<FrParams>(d + 8 * (base + e + half));
+        Fr x = fe_load<FrParams>(d + 8 * (base + e));
 #pragma unroll
-        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+        for (int l = 0; l < 8; l++) cur[l][e] = x.v[l];
     }
     __syncthreads();
-    lds_ntt_stages<false>(lds, tw_fwd, T, log_len, 0, 0, 0, false);
+    for (uint32_t lv = 1; lv <= levels; lv++) {
+        const uint32_t half = 1u << (lv - 1), lm = (half << 1) - 1;
+        const uint32_t* tab = pntt + 8 * (uint64_t)(lv - 1) * n2;
+        for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+            const bool low = (e & lm) < half;
+#pragma unroll
+            for (int l = 0; l < 8; l++) lds[l][e] = low ? cur[l][e + half] : 0u;
+        }
+        __syncthreads();
+        lds_ntt_stages<false>(lds, tw_fwd, T, lv, 0, 0, 0, false);
+        for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+            Fr x;
+#pragma unroll
+            for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
+            x = fe_mul(x, fe_load<FrParams>(tab + 8 * ((base + e) & (n2 - 1))));
+#pragma unroll
+            for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+        }
+        __syncthreads();
+        lds_ntt_stages<true>(lds, tw_inv, T, lv, 0, 0, 0, false);
+        for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
+            Fr x;
+#pragma unroll
+            for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
+            if ((e & lm) < half) {
+                Fr lo;
+#pragma unroll
+                for (int l = 0; l < 8; l++) lo.v[l] = cur[l][e];
+                x = fe_add(x, lo);
+            }
+#pragma unroll
+            for (int l = 0; l < 8; l++) cur[l][e] = x.v[l];
+        }
+        __syncthreads();
+    }
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
         Fr x;
 #pragma unroll
-        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
-        x = fe_mul(x, fe_load<FrParams>(pntt + 8 * ((base + e) & tab_mask)));
-#pragma unroll
-        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
-    }
-    __syncthreads();
-    lds_ntt_stages<true>(lds, tw_inv, T, log_len, 0, 0, 0, false);
-    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x;
-#pragma unroll
-        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
-        if ((e & lm) < half) x = fe_add(x, fe_load<FrParams>(d + 8 * (base + e)));
+        for (int l = 0; l < 8; l++) x.v[l] = cur[l][e];
         fe_store<FrParams>(d + 8 * (base + e), x);
     }
 }
@@ -246,16 +270,14 @@ static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t leve
     const uint32_t log_T = log_total < (uint32_t)NTT_LOG_T ? log_total : NTT_LOG_T;
     ZKCHK(ntt_ensure_twiddles(levels));
     ScopedTimer t("fr_tree", s);
-    for (uint32_t l = 1; l <= levels; l++) {
+    const uint32_t fused = levels < log_T ? levels : log_T;
+    hipLaunchKernelGGL(k_tree_levels_fused, dim3((unsigned)(total >> log_T)), dim3(NTT_THREADS), 0, s, (uint32_t*)d, (const uint32_t*)FRP(f.pntt),
+                       (const uint32_t*)c.tw_fwd, (const uint32_t*)c.tw_inv, fused, log_T, (uint64_t)f.n2);
+    for (uint32_t l = fused + 1; l <= levels; l++) {
         const uint32_t* tab = FRP(f.pntt) + 8 * (uint64_t)(l - 1) * f.n2;
-        if (l <= log_T) {
-            hipLaunchKernelGGL(k_tree_level_fused, dim3((unsigned)(total >> log_T)), dim3(NTT_THREADS), 0, s, (uint32_t*)d, tab,
-                               (const uint32_t*)c.tw_fwd, (const uint32_t*)c.tw_inv, l, log_T, (uint64_t)f.n2 - 1);
-        } else {
-            // upper halves (zero padded) -> NTT -> * P_left -> iNTT -> + lower halves, with the padding folded
-            // into the first pass, the product into the middle kernel and the addition into the last pass
-            ZKCHK(ntt_mul_table(tmp, total, l, tab, (uint64_t)f.n2 - 1, false, d, d, s));
-        }
+        // upper halves (zero padded) -> NTT -> * P_left -> iNTT -> + lower halves, with the padding folded
+        // into the first pass, the product into the middle kernel and the addition into the last pass
+        ZKCHK(ntt_mul_table(tmp, total, l, tab, (uint64_t)f.n2 - 1, false, d, d, s));
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
