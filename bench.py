@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
+    ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
     ap.add_argument("--inflight", type=int, default=12, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
     args = ap.parse_args()
 
@@ -153,6 +154,20 @@ def main():
 
     run(0, args.warmup)
     sync()
+    # A box that has been idle starts in a low-power state and needs seconds of load before its clocks
+    # settle (first bench of a fresh box: 8.4 ms/proof against 2.6 ms once warm).  Untimed: keep proving
+    # until three consecutive batches are within 5 % of the best one, at most --settle seconds.
+    t_settle = time.perf_counter()
+    best, stable = None, 0
+    batches = 0
+    while args.settle > 0 and (batches < 6 if dist is not None else (time.perf_counter() - t_settle < args.settle and stable < 3)):
+        batches += 1          # N > 1: a fixed count, every rank must run the same number of (collective) proofs
+        t0 = time.perf_counter()
+        run(0, depth)
+        sync()
+        bt = time.perf_counter() - t0
+        stable = stable + 1 if best is not None and bt <= 1.05 * best else 0
+        best = bt if best is None else min(best, bt)
     # the dominant kernels (MSM accumulate) are bracketed by HIP events on their own streams DURING the
     # timed region (level 1: two recycled event records per launch; nothing synchronises)
     _lib.check(L.zk_profile_reset())

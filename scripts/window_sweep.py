@@ -15,7 +15,7 @@ print("%4s %12s %10s  %s" % ("c", "constr/s", "ms/proof", "kernel ms per proof (
 for c in cs:
     env = dict(os.environ, ZK_MSM_WINDOW=str(c))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", str(log_n), "--steps", "6", "--warmup", "2",
-                          "--inflight", "3", "--no-cpu-baseline"], env=env, capture_output=True, text=True, cwd=ROOT)
+                          "--inflight", "6", "--no-cpu-baseline"], env=env, capture_output=True, text=True, cwd=ROOT)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(c, "FAILED", out.stderr[-300:])
