@@ -3,10 +3,12 @@
 
 A step = one Groth16 prove of the synthetic iterated-cubic R1CS with the
 proving key, the circuit and the witness already resident in HBM.  N = 1: n = 2^16 constraints
-(BASELINE.json configs[1]).  N > 1: one proof of n = 2^16 * N constraints whose three
-multi-scalar products are sharded by base points over the ranks (one process per GPU), with
-one all-gather of the 768-byte partial sums per proof over RCCL (EC addition is not an RCCL
-reduction operator) and a local EC reduction; per-GPU MSM work is fixed => "weak" scaling.
+(BASELINE.json configs[1]).  N > 1: proofs of n = 2^16 * N constraints whose three
+multi-scalar products are sharded by base points over the ranks (one process per GPU).  Proofs go in
+groups of N: rank j runs the Fr stage of the j-th proof of a group, one all-to-all per scalar vector over
+RCCL hands every rank its slice of every proof's scalars, the 768-byte partial sums of the group travel in
+one all-gather (EC addition is not an RCCL reduction operator) and are added on the GPU; per-GPU work per
+proof is fixed => "weak" scaling.
 
 Prints ONE JSON line on rank 0 (contract: see the round brief).
 """
@@ -83,6 +85,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
+    ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (the simpler, slower scheme)")
     ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
     ap.add_argument("--inflight", type=int, default=12, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
     args = ap.parse_args()
@@ -135,10 +138,20 @@ def main():
     if world > 1:
         depth = min(depth, 8)      # sharded proofs: the host also runs an all-gather + combine per proof
 
-    prover.reserve_slots(depth)          # setup, not warm-up: slots are otherwise created at first use
+    prover.reserve_slots(depth if world == 1 or args.replicated_fr else 1)          # setup, not warm-up: slots are otherwise created at first use
+
+    group = None
+    if world > 1 and not args.replicated_fr:
+        from zukelang_amd.groth16 import GroupProver
+        group = GroupProver(prover)
 
     def run(first, count):
-        """count proofs, `depth` of them in flight: proof i goes to slot i % depth."""
+        """count proofs.  One GPU: `depth` of them in flight, proof i on slot i % depth.  N > 1: groups of N
+        (distributed Fr stage), each rank finishing the proofs it owns."""
+        if group is not None:
+            got = group.prove_many([rs[(first + i) % len(rs)] for i in range(count)], combine_all=False)
+            mine = [g for g in got if g is not None]
+            return mine[-1] if mine else None
         last = None
         for i in range(count):
             if depth == 1:
@@ -254,8 +267,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "groth16_prove, iterated-cubic R1CS (u -> u^3+u+3), BLS12-381, key+circuit+witness resident in HBM",
-                       "constraints": n, "variables": cs.m, "proofs_in_flight": depth, "constraints_per_gpu": 1 << args.log_n,
-                       "sharding": "MSM base points over ranks; all-gather of 768 B partial sums + local EC reduce" if world > 1 else "single GPU",
+                       "constraints": n, "variables": cs.m, "proofs_in_flight": group.batch if group is not None else depth, "constraints_per_gpu": 1 << args.log_n,
+                       "sharding": ("MSM base points over ranks; Fr stage of proof j of each group of N on rank j + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
+                                    if group is not None else "MSM base points over ranks, Fr stage replicated; all-gather of 768 B partial sums + local EC reduce") if world > 1 else "single GPU",
                        "rehearsal_ranks_share_gpus": rehearsal,
                        "prove_algorithmic_bytes_per_constraint": 928,
                        "prove_hbm_frac": 928.0 * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world},

@@ -142,6 +142,25 @@ int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t 
  * the host while the GPU is already working on the partial sums of the next ones */
 int zk_groth16_prove_partial_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot);
 int zk_groth16_prove_partial_wait(uint64_t handle, uint32_t slot, uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]);
+/* Distributed Fr stage (the form bench.py uses at N > 1).  Proofs are handled in groups of N: rank j runs the
+ * Fr stage of the j-th proof of the group ONCE (instead of every rank running it for every proof) and leaves the
+ * three scalar vectors over the FULL pools (p1, p1 and p2 canonical Fr elements, see zk_groth16_pool_layout) in
+ * caller-owned device buffers; the host framework exchanges the slices (one all-to-all over RCCL / xGMI: rank g
+ * receives [lo_g, hi_g) of every proof of the group); zk_groth16_msm_partial_async then runs the three MSMs of
+ * one proof over this rank's slice from such a device buffer, and zk_groth16_prove_partial_wait returns its
+ * 768-byte partial sums for the all-gather + zk_groth16_combine as above.  Replaces the same reference code
+ * (groth16.ml:123-161); QAP.eval (QAP.ml:120-135) is the first half, the apply_powers folds the second.
+ * The device pointers are plain HBM addresses (hipMalloc / a framework tensor's data pointer). */
+int zk_groth16_pool_layout(uint64_t handle, uint64_t* p1, uint64_t* p2, uint64_t* lo1, uint64_t* hi1, uint64_t* lo2, uint64_t* hi2);
+int zk_groth16_scalars_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot,
+                             void* d_scal_a /* p1 * 32 B */, void* d_scal_c /* p1 * 32 B */, void* d_scal_b /* p2 * 32 B */);
+int zk_groth16_scalars_wait(uint64_t handle, uint32_t slot);    /* ZK_ERR_REMAINDER / ZK_ERR_SCALAR_RANGE as zk_groth16_prove */
+int zk_groth16_msm_partial_async(uint64_t handle, uint32_t slot, const void* d_scal_a_slice /* (hi1-lo1) * 32 B */,
+                                 const void* d_scal_c_slice, const void* d_scal_b_slice /* (hi2-lo2) * 32 B */);
+/* plain device memory for callers without a framework allocator */
+int zk_device_malloc(size_t bytes, void** dptr);
+int zk_device_free(void* dptr);
+int zk_device_memcpy(void* dst, const void* src, size_t bytes);   /* any direction, synchronous */
 int zk_groth16_combine(const uint8_t* partials /* world * 768 */, uint32_t world, uint8_t proof[384]);
 
 /* ---- protocol seam: Pinocchio.Make(C).{NonZK,ZK}.prove (src/pinocchio/pinocchio.ml:536-538,559-561) ----

@@ -1,0 +1,60 @@
+"""One rank's share of the N-GPU job, timed on one GPU: what does a group of N proofs cost rank 0?
+ distributed Fr stage: 1 Fr stage (n = 2^16 N) + N sharded MSM triples (+ a device-to-device copy standing in for the all-to-all)
+ replicated Fr stage : N x (Fr stage + sharded MSM triple)
+Projected job throughput = N proofs * n / group time (every rank does the same amount of work)."""
+import ctypes as C, os, sys, time
+sys.path.insert(0, "/root/repo")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+import numpy as np
+from zukelang_amd import _lib, r1cs as RC
+from zukelang_amd.groth16 import Groth16, shard_bounds, fr_bytes, _p
+L = _lib.lib(); _lib.check(L.zk_init(0))
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+logn = 16
+n = (1 << logn) * W
+cs, w = RC.iterated_cubic(n, next(RC.fr_stream(1)))
+st = RC.fr_stream(2); rng = lambda: next(st)
+pk, _ = Groth16.keygen(rng, cs)
+G = max(1, min(12 // W, 15 // (W + 1)))          # groups per round, as GroupProver
+B = G * W
+pr = Groth16(cs, pk, 0, W); pr.set_witness(w); pr.reserve_slots(B + G)
+v = [C.c_uint64() for _ in range(6)]
+_lib.check(L.zk_groth16_pool_layout(pr.handle, *[C.byref(x) for x in v]))
+p1, p2, lo1, hi1, lo2, hi2 = (int(x.value) for x in v)
+def dmalloc(b):
+    p = C.c_void_p(); _lib.check(L.zk_device_malloc(C.c_size_t(b), C.byref(p))); return p.value
+full = [[dmalloc(32 * p1), dmalloc(32 * p1), dmalloc(32 * p2)] for _ in range(G)]
+l1, l2 = 32 * (hi1 - lo1), 32 * (hi2 - lo2)
+recv = [[dmalloc(W * l1), dmalloc(W * l1), dmalloc(W * l2)] for _ in range(G)]
+part = np.zeros(768, dtype=np.uint8)
+def group(distributed):
+    rb, sb = fr_bytes([rng()]), fr_bytes([rng()])
+    if distributed:
+        for k in range(G):
+            _lib.check(L.zk_groth16_scalars_async(pr.handle, None, _p(rb), _p(sb), C.c_uint32(B + k), C.c_void_p(full[k][0]), C.c_void_p(full[k][1]), C.c_void_p(full[k][2])))
+        for k in range(G):
+            _lib.check(L.zk_groth16_scalars_wait(pr.handle, C.c_uint32(B + k)))
+        for k in range(G):
+            for j in range(W):      # stand-in for the all-to-all: W slices land in recv
+                _lib.check(L.zk_device_memcpy(C.c_void_p(recv[k][0] + j * l1), C.c_void_p(full[k][0] + 32 * lo1), C.c_size_t(l1)))
+                _lib.check(L.zk_device_memcpy(C.c_void_p(recv[k][1] + j * l1), C.c_void_p(full[k][1] + 32 * lo1), C.c_size_t(l1)))
+                _lib.check(L.zk_device_memcpy(C.c_void_p(recv[k][2] + j * l2), C.c_void_p(full[k][2] + 32 * lo2), C.c_size_t(l2)))
+        for t in range(B):
+            k, j = divmod(t, W)
+            _lib.check(L.zk_groth16_msm_partial_async(pr.handle, C.c_uint32(t), C.c_void_p(recv[k][0] + j * l1), C.c_void_p(recv[k][1] + j * l1), C.c_void_p(recv[k][2] + j * l2)))
+        for t in range(B):
+            _lib.check(L.zk_groth16_prove_partial_wait(pr.handle, C.c_uint32(t), _p(part)))
+    else:
+        for t in range(B):
+            _lib.check(L.zk_groth16_prove_partial_async(pr.handle, None, _p(rb), _p(sb), C.c_uint32(t)))
+        for t in range(B):
+            _lib.check(L.zk_groth16_prove_partial_wait(pr.handle, C.c_uint32(t), _p(part)))
+for mode in (True, False):
+    for _ in range(3): group(mode)
+    _lib.check(L.zk_sync())
+    t0 = time.perf_counter(); REPS = 5
+    for _ in range(REPS): group(mode)
+    _lib.check(L.zk_sync())
+    dt = (time.perf_counter() - t0) / REPS
+    print("N=%d n=2^%d %s Fr stage: %.2f ms per round of %d proofs = %.2f ms/proof -> projected %.1f M constraints/s on %d GPUs"
+          % (W, logn + (W.bit_length() - 1), "distributed" if mode else "replicated ", dt * 1e3, B, dt * 1e3 / B, B * n / dt / 1e6, W), flush=True)

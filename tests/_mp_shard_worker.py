@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+import numpy as np  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import oracle_lib as O  # noqa: E402
@@ -51,7 +52,6 @@ def main():
         _, A = O.g1_msm_naive(pk1[96 * lo1:96 * hi1], frs(sa[lo1:hi1]))
         _, Cc = O.g1_msm_naive(pk1[96 * lo1:96 * hi1], frs(sc[lo1:hi1]))
         _, B = O.g2_msm_naive(pk2[192 * lo2:192 * hi2], frs(sb[lo2:hi2]))
-        import numpy as np
         gathered = bytes(all_gather_bytes(np.frombuffer(A + Cc + B, dtype=np.uint8), world))
         blk = 96 + 96 + 192
         inf1, inf2 = bytes([0x40]) + bytes(95), bytes([0x40]) + bytes(191)
@@ -60,6 +60,34 @@ def main():
             part = gathered[blk * j:blk * (j + 1)]
             a = O.g1_add(a, part[:96]); c = O.g1_add(c, part[96:192]); b = O.g2_add(b, part[192:])
         assert (a, b, c) == expect, "rank %d: sharded sum differs from the single-rank proof" % rank
+        # distributed Fr stage (GroupProver's data flow with the oracle as the engine): rank j builds the scalar
+        # vectors of proof j only, exchange_slices hands every rank its slice of every proof's vectors,
+        # partial sums of all `world` proofs travel in one all-gather
+        from zukelang_amd.groth16 import exchange_slices
+        rs = [(next(st), next(st)) for _ in range(world)]
+        rj, sj = rs[rank]
+        va, vc, vb = msm_scalar_vectors(n, RC.fr_ints(v), RC.fr_ints(ww), RC.fr_ints(h), w, cs.mid, rj, sj)
+        b1 = [shard_bounds(p1, g, world) for g in range(world)]
+        b2 = [shard_bounds(p2, g, world) for g in range(world)]
+        mine = []
+        for vec, bounds in ((va, b1), (vc, b1), (vb, b2)):
+            got = exchange_slices(np.frombuffer(frs(vec), dtype=np.uint8), bounds, rank, world)
+            mine.append(bytes(got.numpy()))
+        l1, l2 = 32 * (hi1 - lo1), 32 * (hi2 - lo2)
+        parts = b""
+        for j in range(world):
+            _, A = O.g1_msm_naive(pk1[96 * lo1:96 * hi1], mine[0][l1 * j:l1 * (j + 1)])
+            _, Cc = O.g1_msm_naive(pk1[96 * lo1:96 * hi1], mine[1][l1 * j:l1 * (j + 1)])
+            _, B = O.g2_msm_naive(pk2[192 * lo2:192 * hi2], mine[2][l2 * j:l2 * (j + 1)])
+            parts += A + Cc + B
+        gathered = bytes(all_gather_bytes(np.frombuffer(parts, dtype=np.uint8), world))
+        for j in range(world):
+            a, c, b = inf1, inf1, inf2
+            for g in range(world):
+                part = gathered[blk * (world * g + j):blk * (world * g + j + 1)]
+                a = O.g1_add(a, part[:96]); c = O.g1_add(c, part[96:192]); b = O.g2_add(b, part[192:])
+            ej = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rs[j][0]), P.fr_to_bytes(rs[j][1]))
+            assert (a, b, c) == ej, "rank %d: distributed-Fr group proof %d differs" % (rank, j)
     else:
         from zukelang_amd import _lib
         from zukelang_amd.groth16 import Groth16
@@ -77,6 +105,19 @@ def main():
         for slot in range(3):
             p2 = prover.prove_wait(slot)
             assert (p2.a, p2.b, p2.c) == expect, "rank %d slot %d: pipelined sharded proof differs" % (rank, slot)
+        # distributed Fr stage: proofs in groups of `world`, rank j runs the Fr stage of the j-th proof only
+        from zukelang_amd.groth16 import GroupProver
+        rs = [(r, s)] + [(next(st), next(st)) for _ in range(2 * world)]          # 2 full groups + 1 proof
+        gp = GroupProver(prover, groups=2 if world == 2 else 1)      # rounds of 4 (two groups) resp. 3 proofs: the last round is partial
+        got = gp.prove_many(rs)
+        assert len(got) == len(rs)
+        assert (got[0].a, got[0].b, got[0].c) == expect, "rank %d: group proof 0 differs" % rank
+        for (rr, ss), pr in zip(rs[1:], got[1:]):
+            e2 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
+            assert (pr.a, pr.b, pr.c) == e2, "rank %d: a group proof differs" % rank
+        own = gp.prove_many(rs[:world], combine_all=False)
+        assert [i for i, x in enumerate(own) if x is not None] == [rank]
+        assert (own[rank].a, own[rank].b, own[rank].c) == tuple(getattr(got[rank], f) for f in "abc")
         prover.close()
     dist.barrier()
     if rank == 0:

@@ -16,6 +16,8 @@ EXPORTS = [
     "zk_g1_powers", "zk_g2_powers", "zk_g1_compress", "zk_g2_compress",
     "zk_groth16_pk_upload", "zk_groth16_pk_free", "zk_groth16_prove", "zk_groth16_reserve_slots", "zk_groth16_prove_async", "zk_groth16_prove_wait", "zk_groth16_set_witness", "zk_groth16_qap_eval",
     "zk_groth16_pk_upload_sharded", "zk_groth16_prove_partial", "zk_groth16_prove_partial_async", "zk_groth16_prove_partial_wait", "zk_groth16_combine",
+    "zk_groth16_pool_layout", "zk_groth16_scalars_async", "zk_groth16_scalars_wait", "zk_groth16_msm_partial_async",
+    "zk_device_malloc", "zk_device_free", "zk_device_memcpy",
     "zk_pinocchio_pk_upload", "zk_pinocchio_pk_free", "zk_pinocchio_prove",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_get", "zk_profile_names", "zk_sync",
     "zk_bench_field_mul",

@@ -185,10 +185,10 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     return ZK_OK;
 }
 
-// Enqueues one proof on the slot's streams and returns without waiting:
-// Fr stage -> scalar vectors -> {C on s0, B on s1, A on s2} -> affine bytes -> pinned host buffer.
-static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, bool raw) {
-    if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call zk_groth16_prove_wait first");
+// First half of a proof: Fr stage -> the three scalar vectors (canonical Fr, FULL pool lengths p1, p1, p2)
+// written to dA / dC / dB (device memory; the slot's own buffers in the single-call path).
+static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, void* dA, void* dC, void* dB) {
+    if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call the matching _wait first");
     const void* wit = k.wit_resident.p;
     if (sol) {
         HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, sl.s0));
@@ -200,10 +200,17 @@ static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint
     ZKCHK(frstage_eval(k.fr, sl.fs, wit, sl.s0));
     const uint32_t* v = sl.fs.d.as<uint32_t>();
     const uint32_t* w = v + 8 * (uint64_t)k.fr.n2;
-    hipLaunchKernelGGL(k_groth16_scalars, g1d(k.p1), dim3(256), 0, sl.s0, sl.scalA.as<uint32_t>(), sl.scalC.as<uint32_t>(), sl.scalB.as<uint32_t>(), v, w,
+    hipLaunchKernelGGL(k_groth16_scalars, g1d(k.p1), dim3(256), 0, sl.s0, (uint32_t*)dA, (uint32_t*)dC, (uint32_t*)dB, v, w,
                        (const uint32_t*)sl.fs.h.as<uint32_t>(), (const uint32_t*)sl.fs.wit.as<uint32_t>(), (const uint32_t*)k.mid_idx.as<uint32_t>(),
                        (const uint32_t*)sl.rs.as<uint32_t>(), k.n, k.n_mid);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sl.host + 384, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, sl.s0));
+    return ZK_OK;
+}
+// Second half: the three MSMs over this rank's slice of the pools.  dA / dC / dB point at the scalars of
+// that slice ((hi1-lo1), (hi1-lo1), (hi2-lo2) elements).  {C on s0, B on s1, A on s2} -> affine bytes (or raw
+// XYZZ partial sums) -> pinned host buffer.
+static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC, const void* dB, bool raw) {
     char* res = sl.results.as<char>();
     char* out = sl.out_dev.as<char>();
     const size_t g1b = xyzz_bytes(CURVE_G1);
@@ -211,18 +218,23 @@ static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint
     HIPCHK(hipStreamWaitEvent(sl.s1, sl.fork, 0));
     HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
     // B (G2, the longest chain) first
-    ZKCHK(msm_run(k.g2, sl.wsB, sl.scalB.as<char>() + 32 * k.lo2, res + 2 * g1b, sl.s1));
+    ZKCHK(msm_run(k.g2, sl.wsB, dB, res + 2 * g1b, sl.s1));
     if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, res + 2 * g1b, 1, out + 96, sl.s1));
     HIPCHK(hipEventRecord(sl.join1, sl.s1));
-    ZKCHK(msm_run(k.g1, sl.wsC, sl.scalC.as<char>() + 32 * k.lo1, res + g1b, sl.s0));
+    ZKCHK(msm_run(k.g1, sl.wsC, dC, res + g1b, sl.s0));
     if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + g1b, 1, out + 288, sl.s0));
-    ZKCHK(msm_run(k.g1, sl.wsA, sl.scalA.as<char>() + 32 * k.lo1, res, sl.s2));
+    ZKCHK(msm_run(k.g1, sl.wsA, dA, res, sl.s2));
     if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res, 1, out, sl.s2));
     HIPCHK(hipEventRecord(sl.join2, sl.s2));
     HIPCHK(hipStreamWaitEvent(sl.s0, sl.join1, 0));
     HIPCHK(hipStreamWaitEvent(sl.s0, sl.join2, 0));
     if (!raw) HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 384, hipMemcpyDeviceToHost, sl.s0));
-    HIPCHK(hipMemcpyAsync(sl.host + 384, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, sl.s0));
+    return ZK_OK;
+}
+// Enqueues one whole proof on the slot's streams and returns without waiting.
+static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, bool raw) {
+    ZKCHK(scalars_enqueue(k, sl, sol, r, s, sl.scalA.p, sl.scalC.p, sl.scalB.p));
+    ZKCHK(msms_enqueue(k, sl, sl.scalA.as<char>() + 32 * k.lo1, sl.scalC.as<char>() + 32 * k.lo1, sl.scalB.as<char>() + 32 * k.lo2, raw));
     HIPCHK(hipEventRecord(sl.done, sl.s0));
     sl.busy = true;
     return ZK_OK;
@@ -339,6 +351,65 @@ int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t 
                              uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]) {
     ZKCHK(zk_groth16_prove_partial_async(handle, sol, r, s, 0));
     return zk_groth16_prove_partial_wait(handle, 0, partial);
+}
+// ---- distributed Fr stage: the two halves of a proof as separate calls on caller-owned device buffers
+int zk_groth16_pool_layout(uint64_t handle, uint64_t* p1, uint64_t* p2, uint64_t* lo1, uint64_t* hi1, uint64_t* lo2, uint64_t* hi2) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (p1) *p1 = k->p1;
+    if (p2) *p2 = k->p2;
+    if (lo1) *lo1 = k->lo1;
+    if (hi1) *hi1 = k->hi1;
+    if (lo2) *lo2 = k->lo2;
+    if (hi2) *hi2 = k->hi2;
+    return ZK_OK;
+}
+int zk_groth16_scalars_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot,
+                             void* d_scal_a, void* d_scal_c, void* d_scal_b) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (!r || !s || !d_scal_a || !d_scal_c || !d_scal_b) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_scalars_async: null argument");
+    Slot* sl;
+    ZKCHK(slot_get(*k, slot, &sl));
+    ZKCHK(scalars_enqueue(*k, *sl, sol, r, s, d_scal_a, d_scal_c, d_scal_b));
+    HIPCHK(hipEventRecord(sl->done, sl->s0));
+    sl->busy = true;
+    return ZK_OK;
+}
+int zk_groth16_scalars_wait(uint64_t handle, uint32_t slot) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_scalars_wait: slot never used");
+    return prove_finish(*k->slots[slot]);
+}
+int zk_groth16_msm_partial_async(uint64_t handle, uint32_t slot, const void* d_scal_a_slice, const void* d_scal_c_slice, const void* d_scal_b_slice) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (!d_scal_a_slice || !d_scal_c_slice || !d_scal_b_slice) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_msm_partial_async: null argument");
+    Slot* sl;
+    ZKCHK(slot_get(*k, slot, &sl));
+    if (sl->busy) ZK_FAIL(ZK_ERR_ARG, "slot still has work in flight: call the matching _wait first");
+    memset(sl->host + 384, 0, 4);      // the remainder / range flags belong to the Fr stage, which ran elsewhere (zk_groth16_scalars_wait)
+    ZKCHK(msms_enqueue(*k, *sl, d_scal_a_slice, d_scal_c_slice, d_scal_b_slice, true));
+    HIPCHK(hipMemcpyAsync(sl->host_partial, sl->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost, sl->s0));
+    HIPCHK(hipEventRecord(sl->done, sl->s0));
+    sl->busy = true;
+    return ZK_OK;
+}
+int zk_device_malloc(size_t bytes, void** dptr) {
+    ZKCHK(ensure_init());
+    if (!dptr) ZK_FAIL(ZK_ERR_ARG, "zk_device_malloc: null");
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 1));
+    return ZK_OK;
+}
+int zk_device_free(void* dptr) {
+    if (dptr) HIPCHK(hipFree(dptr));
+    return ZK_OK;
+}
+int zk_device_memcpy(void* dst, const void* src, size_t bytes) {
+    ZKCHK(ensure_init());
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+    return ZK_OK;
 }
 int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[384]) {
     if (!partials || !proof || world == 0) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_combine: bad argument");

@@ -109,6 +109,31 @@ def all_gather_bytes(part, world):
     return np.ascontiguousarray(torch.cat(out).cpu().numpy())
 
 
+def exchange_slices(full, bounds, rank, world, out=None):
+    """The exchange step of the distributed Fr stage: every rank holds the scalar vector of ONE proof
+    over the whole base pool (`full`: uint8, 32 B per element) and needs slice [lo_rank, hi_rank) of EVERY
+    rank's vector.  Returns `world` blocks of this rank's slice length, in rank order.
+    RCCL (backend nccl): one all-to-all with per-destination splits, device to device over xGMI.
+    gloo (CPU tests, single-GPU rehearsal): every rank gathers every vector and keeps its slice."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = bounds[rank]
+    mine = 32 * (hi - lo)
+    if dist.get_backend() == "nccl":
+        if out is None:
+            out = torch.empty(world * mine, dtype=torch.uint8, device=full.device)
+        dist.all_to_all_single(out, full, [mine] * world, [32 * (b - a) for a, b in bounds])
+        return out
+    t = full.detach().cpu() if isinstance(full, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(full, dtype=np.uint8).copy())
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    cat = torch.cat([o[32 * lo:32 * hi] for o in outs])
+    if out is None:
+        return cat
+    out.copy_(cat)
+    return out
+
+
 def msm_scalar_vectors(n, v, w, h, wit, mid, r, s):
     """Host mirror (Python ints) of the library's k_groth16_scalars: the three scalar vectors laid
     over the key pools g1 = a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid and g2 = b2 | d2 | ti2[n+2]:
@@ -297,3 +322,104 @@ class Groth16:
     @staticmethod
     def verify(input_output, vkey, proof):
         raise NotImplementedError("Groth16.verify needs the pairing (groth16.ml:163-173): scope row f1, not on the accelerated path")
+
+
+
+class GroupProver:
+    """N > 1 with a DISTRIBUTED Fr stage.  Proofs are handled in rounds of G groups of `world` proofs: rank j
+    runs QAP.eval (QAP.ml:120-135) and builds the three scalar vectors only for the proofs it owns (the j-th
+    of every group); one all-to-all per vector and group hands rank g its slice [lo_g, hi_g) of every proof's
+    scalars; every rank then runs the point-sharded MSMs (groth16.ml:116-161) of all G * world proofs of the
+    round over its slice (that many proofs in flight, one slot each), the 768-byte partial sums of the round
+    travel in one all-gather, and zk_groth16_combine finishes each proof.  Per proof and rank that is 1/world
+    of an Fr stage plus one sharded MSM triple -- with the replicated Fr stage of prove_async / prove_wait on
+    a sharded key it is a whole Fr stage.  The next round's Fr stages are enqueued before this round's MSMs
+    are waited for."""
+
+    MAX_SLOTS = 16
+
+    def __init__(self, prover, groups=None):
+        import torch
+        self.torch = torch
+        self.p = prover
+        self.world, self.rank = prover.world, prover.rank
+        W = self.world
+        self.G = groups if groups else max(1, min(12 // W, (self.MAX_SLOTS - 1) // (W + 1)))
+        if self.G * (W + 1) > self.MAX_SLOTS:
+            raise ValueError("GroupProver: groups * (world + 1) must not exceed %d slots" % self.MAX_SLOTS)
+        L = _lib.lib()
+        v = [C.c_uint64() for _ in range(6)]
+        _lib.check(L.zk_groth16_pool_layout(prover.handle, *[C.byref(x) for x in v]))
+        self.p1, self.p2, self.lo1, self.hi1, self.lo2, self.hi2 = (int(x.value) for x in v)
+        self.bounds1 = [shard_bounds(self.p1, g, W) for g in range(W)]
+        self.bounds2 = [shard_bounds(self.p2, g, W) for g in range(W)]
+        assert self.bounds1[self.rank] == (self.lo1, self.hi1) and self.bounds2[self.rank] == (self.lo2, self.hi2)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.len1, self.len2 = 32 * (self.hi1 - self.lo1), 32 * (self.hi2 - self.lo2)
+        # per group of the round: the owner's full vectors A, C, B and the received slices [world][slice]
+        self.full = [[torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p2, **u8)] for _ in range(self.G)]
+        self.recv = [[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.G)]
+        self.batch = self.G * W                   # proofs per round; MSM slots 0..batch-1, Fr slots batch..batch+G-1
+        prover.reserve_slots(self.batch + self.G)
+        torch.cuda.current_stream().synchronize()
+
+    def _launch_fr(self, rnd):
+        """rnd: list of (r, s), at most `batch`; this rank owns rnd[k * world + rank].  Returns the groups launched."""
+        launched = []
+        for k in range(self.G):
+            t = k * self.world + self.rank
+            if t >= len(rnd):
+                break
+            rb, sb = fr_bytes([rnd[t][0]]), fr_bytes([rnd[t][1]])
+            f = self.full[k]
+            _lib.check(_lib.lib().zk_groth16_scalars_async(self.p.handle, None, _p(rb), _p(sb), C.c_uint32(self.batch + k),
+                                                           C.c_void_p(f[0].data_ptr()), C.c_void_p(f[1].data_ptr()), C.c_void_p(f[2].data_ptr())))
+            launched.append(k)
+        return launched
+
+    def _finish_fr_and_exchange(self, launched, count):
+        for k in launched:
+            rc = _lib.lib().zk_groth16_scalars_wait(self.p.handle, C.c_uint32(self.batch + k))
+            if rc == ZK_ERR_REMAINDER:
+                raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
+            _lib.check(rc)
+        for k in range((count + self.world - 1) // self.world):       # every rank takes part in every group's exchange
+            for i, bounds in ((0, self.bounds1), (1, self.bounds1), (2, self.bounds2)):
+                exchange_slices(self.full[k][i], bounds, self.rank, self.world, out=self.recv[k][i])
+        self.torch.cuda.current_stream().synchronize()        # the slices have landed before the library's streams read them
+
+    def prove_many(self, rs_list, combine_all=True):
+        """All ranks call this with the same list of (r, s); the witness is the resident one (set_witness).
+        Returns the proofs in order -- all of them on every rank, or with combine_all=False only the ones
+        this rank owns (index % world == rank; None elsewhere): each proof then costs ONE combine in the job
+        instead of one per rank."""
+        L = _lib.lib()
+        W = self.world
+        rounds = [rs_list[i:i + self.batch] for i in range(0, len(rs_list), self.batch)]
+        proofs = []
+        launched = self._launch_fr(rounds[0]) if rounds else []
+        for ri, rnd in enumerate(rounds):
+            cnt = len(rnd)
+            self._finish_fr_and_exchange(launched, cnt)
+            if ri + 1 < len(rounds):
+                launched = self._launch_fr(rounds[ri + 1])      # overlaps with this round's MSMs
+            for t in range(cnt):
+                k, j = divmod(t, W)
+                rv = self.recv[k]
+                _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(t), C.c_void_p(rv[0].data_ptr() + j * self.len1),
+                                                          C.c_void_p(rv[1].data_ptr() + j * self.len1), C.c_void_p(rv[2].data_ptr() + j * self.len2)))
+            parts = np.zeros((self.batch, 768), dtype=np.uint8)
+            for t in range(cnt):
+                _lib.check(L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(t), _p(parts[t])))
+            gathered = all_gather_bytes(parts.reshape(-1), W).reshape(W, self.batch, 768)        # [rank][proof]
+            for t in range(cnt):
+                if not combine_all and t % W != self.rank:
+                    proofs.append(None)
+                    continue
+                out = np.zeros(384, dtype=np.uint8)
+                blk = np.ascontiguousarray(gathered[:, t, :]).reshape(-1)
+                _lib.check(L.zk_groth16_combine(_p(blk), C.c_uint32(W), _p(out)))
+                b = bytes(out)
+                proofs.append(Proof(b[:96], b[96:288], b[288:]))
+        return proofs
