@@ -178,6 +178,13 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
 int zk_pinocchio_pk_free(uint64_t handle);
 int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32],
                        const uint8_t dy[32], uint8_t proof[960]);
+/* Pipelined form, as for Groth16: up to 16 proofs in flight on one key, each on its own `slot`;
+ * sol == NULL uses the witness made resident by zk_pinocchio_set_witness.  zk_pinocchio_prove == _async + _wait on slot 0. */
+int zk_pinocchio_reserve_slots(uint64_t handle, uint32_t count);
+int zk_pinocchio_set_witness(uint64_t handle, const uint8_t* sol);
+int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32],
+                             const uint8_t dy[32], uint32_t slot);
+int zk_pinocchio_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[960]);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------
  * With profiling on, kernel families are bracketed by HIP events on the stream they run on;

@@ -45,6 +45,14 @@ def test_pinocchio_zk_and_nonzk_match_oracle(maker, literal):
         assert rc == 0 and proof.to_bytes() == ref
         io = [w[k] for k in range(cs.m) if not cs.mid[k]]
         assert O.pinocchio_verify(bytes(vk.g1), bytes(vk.g2), io, proof.to_bytes())
+    # pipelined form: resident witness, three proofs in flight with different blinding, collected in order
+    prover.set_witness(w)
+    ds = [[next(st) for _ in range(3)] for _ in range(3)]
+    for slot, d in enumerate(ds):
+        prover.prove_async(*d, slot)
+    for slot, d in enumerate(ds):
+        got = prover.prove_wait(slot)
+        assert got.to_bytes() == O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), toxic, *(P.fr_to_bytes(x) for x in d))
     prover.close()
     nz = PIN.NonZK(cs, pk)
     p0 = nz.prove(None, w)

@@ -26,20 +26,31 @@ namespace zk {
 
 static constexpr int PIN_G1 = 6, PIN_G2 = 2;
 
+// Everything one proof in flight needs: the pipelined form keeps several of them busy on one key
+// (one stream each -- see groth16.hip for why not three).
+struct PinSlot {
+    FrScratch fs;
+    MsmWorkspace ws1[PIN_G1], ws2[PIN_G2];
+    DevBuf scal1[PIN_G1], scal2[PIN_G2];
+    DevBuf wit_raw, deltas, results, out_dev;
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t* host = nullptr;          // pinned: proof 960 B | flags 4 B | deltas 96 B
+    bool busy = false;
+    ~PinSlot() {
+        if (st) (void)hipStreamDestroy(st);
+        if (done) (void)hipEventDestroy(done);
+        if (host) (void)hipHostFree(host);
+    }
+};
+static constexpr uint32_t PIN_MAX_SLOTS = 16;
 struct PinKey {
     uint32_t n = 0, m = 0, n_mid = 0;
     FrStage fr;
-    FrScratch fs;
     MsmBases g1[PIN_G1], g2[PIN_G2];
-    MsmWorkspace ws1[PIN_G1], ws2[PIN_G2];
-    DevBuf scal1[PIN_G1], scal2[PIN_G2];
-    DevBuf mid_idx, wit_raw, deltas, results, out_dev, flag_dev;
-    hipStream_t st[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-    ~PinKey() {
-        for (auto s : st) if (s) (void)hipStreamDestroy(s);
-        if (fork) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join[0]); (void)hipEventDestroy(join[1]); }
-    }
+    DevBuf mid_idx, wit_resident;
+    bool have_witness = false;
+    std::unique_ptr<PinSlot> slots[PIN_MAX_SLOTS];
 };
 static std::map<uint64_t, std::unique_ptr<PinKey>>& g_pin = *new std::map<uint64_t, std::unique_ptr<PinKey>>;   // never destroyed (see ntt.hip)
 static uint64_t g_pin_next = 0x5000000001ull;
@@ -118,7 +129,6 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     if (pk_g1_points != 5 * nm + (n + 1) + 2 * (uint64_t)m + 7) ZK_FAIL(ZK_ERR_DOMAIN, "pinocchio pk_upload: G1 key length");
     if (pk_g2_points != 2 * nm + (n + 1) + 2) ZK_FAIL(ZK_ERR_DOMAIN, "pinocchio pk_upload: G2 key length");
     ZKCHK(frstage_init(k.fr, n, m, L, R, O, c.stream));
-    ZKCHK(frstage_scratch_alloc(k.fr, k.fs));
     // slices of the flattened key (pinocchio.ml:37-60; layout in include/zkmi355x.h)
     const uint8_t *VV = pk_g1, *YY = VV + 96 * nm, *VAV = YY + 96 * nm, *YAY = VAV + 96 * nm, *BV = YAY + 96 * nm,
                   *SI = BV + 96 * nm, *VALL = SI + 96 * (uint64_t)(n + 1), *WALL = VALL + 96 * (uint64_t)m, *ONES = WALL + 96 * (uint64_t)m;
@@ -142,18 +152,9 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     };
     ZKCHK(pool2(0, WW, ONES2));
     ZKCHK(pool2(1, WAW, ONES2 + 192));
-    for (int i = 0; i < PIN_G1; i++) { ZKCHK(msm_workspace_alloc(k.ws1[i], k.g1[i])); ZKCHK(k.scal1[i].alloc(32 * k.g1[i].n)); }
-    for (int i = 0; i < PIN_G2; i++) { ZKCHK(msm_workspace_alloc(k.ws2[i], k.g2[i])); ZKCHK(k.scal2[i].alloc(32 * k.g2[i].n)); }
     ZKCHK(k.mid_idx.alloc(4 * nm));
     HIPCHK(hipMemcpyAsync(k.mid_idx.p, mids.data(), 4 * nm, hipMemcpyHostToDevice, c.stream));
-    ZKCHK(k.wit_raw.alloc(32 * (size_t)m));
-    ZKCHK(k.deltas.alloc(96));
-    ZKCHK(k.results.alloc(PIN_G1 * xyzz_bytes(CURVE_G1) + PIN_G2 * xyzz_bytes(CURVE_G2)));
-    ZKCHK(k.out_dev.alloc(960));
-    for (auto& s : k.st) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&k.fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&k.join[0], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&k.join[1], hipEventDisableTiming));
+    ZKCHK(k.wit_resident.alloc(32 * (size_t)m));
     HIPCHK(hipStreamSynchronize(c.stream));
     *handle = g_pin_next++;
     g_pin[*handle] = std::move(key);
@@ -166,57 +167,114 @@ int zk_pinocchio_pk_free(uint64_t handle) {
     g_pin.erase(it);
     return ZK_OK;
 }
-int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32], const uint8_t dy[32],
-                       uint8_t proof[960]) {
+static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
+    if (idx >= PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "pinocchio: slot index out of range (max 16 proofs in flight)");
+    if (!k.slots[idx]) {
+        auto sl = std::make_unique<PinSlot>();
+        ZKCHK(frstage_scratch_alloc(k.fr, sl->fs));
+        for (int i = 0; i < PIN_G1; i++) { ZKCHK(msm_workspace_alloc(sl->ws1[i], k.g1[i])); ZKCHK(sl->scal1[i].alloc(32 * k.g1[i].n)); }
+        for (int i = 0; i < PIN_G2; i++) { ZKCHK(msm_workspace_alloc(sl->ws2[i], k.g2[i])); ZKCHK(sl->scal2[i].alloc(32 * k.g2[i].n)); }
+        ZKCHK(sl->wit_raw.alloc(32 * (size_t)k.m));
+        ZKCHK(sl->deltas.alloc(96));
+        ZKCHK(sl->results.alloc(PIN_G1 * xyzz_bytes(CURVE_G1) + PIN_G2 * xyzz_bytes(CURVE_G2)));
+        ZKCHK(sl->out_dev.alloc(960));
+        HIPCHK(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+        HIPCHK(hipHostMalloc((void**)&sl->host, 1088, hipHostMallocDefault));
+        k.slots[idx] = std::move(sl);
+    }
+    *out = k.slots[idx].get();
+    return ZK_OK;
+}
+int zk_pinocchio_reserve_slots(uint64_t handle, uint32_t count) {
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    if (count > PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_reserve_slots: at most 16 slots");
+    for (uint32_t i = 0; i < count; i++) {
+        PinSlot* sl;
+        ZKCHK(pin_slot_get(*kp, i, &sl));
+    }
+    return ZK_OK;
+}
+int zk_pinocchio_set_witness(uint64_t handle, const uint8_t* sol) {
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_set_witness: null");
+    Ctx& c = ctx();
+    (void)hipDeviceSynchronize();      // no proof may still be reading the previous witness
+    HIPCHK(hipMemcpyAsync(kp->wit_resident.p, sol, 32 * (size_t)kp->m, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    kp->have_witness = true;
+    return ZK_OK;
+}
+// Enqueues one proof on the slot's stream and returns without waiting:
+// Fr stage -> the eight scalar vectors -> eight MSMs -> affine bytes -> pinned host buffer.
+int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32], const uint8_t dy[32], uint32_t slot) {
     PinKey* kp;
     ZKCHK(pin_lookup(handle, &kp));
     PinKey& k = *kp;
-    if (!sol || !dv || !dw || !dy || !proof) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove: null argument");
-    hipStream_t s0 = k.st[0];
-    uint8_t d3[96];
-    memcpy(d3, dv, 32); memcpy(d3 + 32, dw, 32); memcpy(d3 + 64, dy, 32);
-    HIPCHK(hipMemcpyAsync(k.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, s0));
-    HIPCHK(hipMemcpyAsync(k.deltas.p, d3, 96, hipMemcpyHostToDevice, s0));
-    HIPCHK(hipStreamSynchronize(s0));                 // d3 is a stack buffer
-    ZKCHK(frstage_eval(k.fr, k.fs, k.wit_raw.p, s0));
+    if (!dv || !dw || !dy) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_async: null argument");
+    PinSlot* slp;
+    ZKCHK(pin_slot_get(k, slot, &slp));
+    PinSlot& sl = *slp;
+    if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call zk_pinocchio_prove_wait first");
+    hipStream_t s0 = sl.st;
+    const void* wit = k.wit_resident.p;
+    if (sol) {
+        HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, s0));
+        wit = sl.wit_raw.p;
+    } else if (!k.have_witness) ZK_FAIL(ZK_ERR_ARG, "no witness: pass sol or call zk_pinocchio_set_witness first");
+    memcpy(sl.host + 992, dv, 32); memcpy(sl.host + 1024, dw, 32); memcpy(sl.host + 1056, dy, 32);
+    HIPCHK(hipMemcpyAsync(sl.deltas.p, sl.host + 992, 96, hipMemcpyHostToDevice, s0));
+    ZKCHK(frstage_eval(k.fr, sl.fs, wit, s0));
     PinScalPtrs ptrs;
-    for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = k.scal1[i].as<uint32_t>();
-    for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = k.scal2[i].as<uint32_t>();
+    for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = sl.scal1[i].as<uint32_t>();
+    for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = sl.scal2[i].as<uint32_t>();
     const uint64_t ph = (uint64_t)k.n + 1 + 2 * (uint64_t)k.m;
-    hipLaunchKernelGGL(k_pinocchio_scalars, g1d(ph), dim3(256), 0, s0, ptrs, (const uint32_t*)k.fs.h.as<uint32_t>(),
-                       (const uint32_t*)k.fr.z.as<uint32_t>(), (const uint32_t*)k.fs.wit.as<uint32_t>(),
-                       (const uint32_t*)k.mid_idx.as<uint32_t>(), (const uint32_t*)k.deltas.as<uint32_t>(), k.n, k.m, k.n_mid);
+    hipLaunchKernelGGL(k_pinocchio_scalars, g1d(ph), dim3(256), 0, s0, ptrs, (const uint32_t*)sl.fs.h.as<uint32_t>(),
+                       (const uint32_t*)k.fr.z.as<uint32_t>(), (const uint32_t*)sl.fs.wit.as<uint32_t>(),
+                       (const uint32_t*)k.mid_idx.as<uint32_t>(), (const uint32_t*)sl.deltas.as<uint32_t>(), k.n, k.m, k.n_mid);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(k.fork, s0));
-    HIPCHK(hipStreamWaitEvent(k.st[1], k.fork, 0));
-    HIPCHK(hipStreamWaitEvent(k.st[2], k.fork, 0));
-    char* res = k.results.as<char>();
-    char* out = k.out_dev.as<char>();
+    char* res = sl.results.as<char>();
+    char* out = sl.out_dev.as<char>();
     const size_t x1 = xyzz_bytes(CURVE_G1), x2 = xyzz_bytes(CURVE_G2);
     // proof byte offsets: vv 0 | ww 96 | yy 288 | h 384 | vavv 480 | waww 576 | yayy 768 | bvwy 864
     const size_t off1[PIN_G1] = {0, 288, 480, 768, 864, 384};
     const size_t off2[PIN_G2] = {96, 576};
-    // G2 products on stream 1, the big h' product on stream 0, the five mid-sized G1 products on stream 2
     for (int i = 0; i < PIN_G2; i++) {
-        ZKCHK(msm_run(k.g2[i], k.ws2[i], k.scal2[i].p, res + PIN_G1 * x1 + i * x2, k.st[1]));
-        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, res + PIN_G1 * x1 + i * x2, 1, out + off2[i], k.st[1]));
+        ZKCHK(msm_run(k.g2[i], sl.ws2[i], sl.scal2[i].p, res + PIN_G1 * x1 + i * x2, s0));
+        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, res + PIN_G1 * x1 + i * x2, 1, out + off2[i], s0));
     }
-    HIPCHK(hipEventRecord(k.join[0], k.st[1]));
-    ZKCHK(msm_run(k.g1[5], k.ws1[5], k.scal1[5].p, res + 5 * x1, s0));
-    ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + 5 * x1, 1, out + off1[5], s0));
-    for (int i = 0; i < 5; i++) {
-        ZKCHK(msm_run(k.g1[i], k.ws1[i], k.scal1[i].p, res + i * x1, k.st[2]));
-        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + i * x1, 1, out + off1[i], k.st[2]));
+    for (int i = 0; i < PIN_G1; i++) {
+        ZKCHK(msm_run(k.g1[i], sl.ws1[i], sl.scal1[i].p, res + i * x1, s0));
+        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + i * x1, 1, out + off1[i], s0));
     }
-    HIPCHK(hipEventRecord(k.join[1], k.st[2]));
-    HIPCHK(hipStreamWaitEvent(s0, k.join[0], 0));
-    HIPCHK(hipStreamWaitEvent(s0, k.join[1], 0));
-    int hf = 0;
-    HIPCHK(hipMemcpyAsync(proof, k.out_dev.p, 960, hipMemcpyDeviceToHost, s0));
-    HIPCHK(hipMemcpyAsync(&hf, k.fs.flag.p, 4, hipMemcpyDeviceToHost, s0));
-    HIPCHK(hipStreamSynchronize(s0));
+    HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 960, hipMemcpyDeviceToHost, s0));
+    HIPCHK(hipMemcpyAsync(sl.host + 960, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, s0));
+    HIPCHK(hipEventRecord(sl.done, s0));
+    sl.busy = true;
+    return ZK_OK;
+}
+int zk_pinocchio_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[960]) {
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    if (!proof) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_wait: null proof");
+    if (slot >= PIN_MAX_SLOTS || !kp->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_wait: slot never used");
+    PinSlot& sl = *kp->slots[slot];
+    if (!sl.busy) ZK_FAIL(ZK_ERR_ARG, "no proof in flight on this slot");
+    HIPCHK(hipEventSynchronize(sl.done));
+    sl.busy = false;
+    int hf;
+    memcpy(&hf, sl.host + 960, 4);
     if (hf & 2) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "witness value >= r");
     if (hf & 1) ZK_FAIL(ZK_ERR_REMAINDER, "p mod Z != 0");
+    memcpy(proof, sl.host, 960);
     return ZK_OK;
+}
+int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32], const uint8_t dy[32],
+                       uint8_t proof[960]) {
+    if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove: null argument");
+    ZKCHK(zk_pinocchio_prove_async(handle, sol, dv, dw, dy, 0));
+    return zk_pinocchio_prove_wait(handle, 0, proof);
 }
 }

@@ -126,6 +126,35 @@ class _Prover:
         return Proof(b[:96], b[96:288], b[288:384], b[384:480], b[480:576], b[576:768], b[768:864], b[864:960])
 
 
+    # ---- pipelined form (several proofs in flight on one key, witness resident in HBM)
+    @staticmethod
+    def _proof_of(out):
+        b = bytes(out)
+        return Proof(b[:96], b[96:288], b[288:384], b[384:480], b[480:576], b[576:768], b[768:864], b[864:960])
+
+    def set_witness(self, sol):
+        w = np.ascontiguousarray(sol, dtype=np.uint8).reshape(-1) if isinstance(sol, np.ndarray) else (
+            np.frombuffer(bytes(sol), dtype=np.uint8) if isinstance(sol, (bytes, bytearray)) else fr_bytes(sol))
+        if len(w) != 32 * self.circuit.m:
+            raise AssertionError("Variable not found")          # var.ml:75-77
+        _lib.check(_lib.lib().zk_pinocchio_set_witness(self.handle, _p(w)))
+
+    def reserve_slots(self, count):
+        _lib.check(_lib.lib().zk_pinocchio_reserve_slots(self.handle, C.c_uint32(count)))
+
+    def prove_async(self, dv, dw, dy, slot):
+        d = [fr_bytes([x]) for x in (dv, dw, dy)]
+        _lib.check(_lib.lib().zk_pinocchio_prove_async(self.handle, None, _p(d[0]), _p(d[1]), _p(d[2]), C.c_uint32(slot)))
+
+    def prove_wait(self, slot):
+        out = np.zeros(960, dtype=np.uint8)
+        rc = _lib.lib().zk_pinocchio_prove_wait(self.handle, C.c_uint32(slot), _p(out))
+        if rc == ZK_ERR_REMAINDER:
+            raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
+        _lib.check(rc)
+        return self._proof_of(out)
+
+
 class ZK(_Prover):
     keygen = staticmethod(keygen)
 
