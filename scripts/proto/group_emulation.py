@@ -15,7 +15,7 @@ n = (1 << logn) * W
 cs, w = RC.iterated_cubic(n, next(RC.fr_stream(1)))
 st = RC.fr_stream(2); rng = lambda: next(st)
 pk, _ = Groth16.keygen(rng, cs)
-G = max(1, min(12 // W, 15 // (W + 1)))          # groups per round, as GroupProver
+G = max(1, 12 // (W + 1))          # groups per round, as GroupProver
 B = G * W
 pr = Groth16(cs, pk, 0, W); pr.set_witness(w); pr.reserve_slots(B + G)
 v = [C.c_uint64() for _ in range(6)]

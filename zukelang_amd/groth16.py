@@ -344,7 +344,8 @@ class GroupProver:
         self.p = prover
         self.world, self.rank = prover.world, prover.rank
         W = self.world
-        self.G = groups if groups else max(1, min(12 // W, (self.MAX_SLOTS - 1) // (W + 1)))
+        # slots = G * (W + 1) streams; the chip runs 16 hardware queues side by side and RCCL / the framework need a few
+        self.G = groups if groups else max(1, 12 // (W + 1))
         if self.G * (W + 1) > self.MAX_SLOTS:
             raise ValueError("GroupProver: groups * (world + 1) must not exceed %d slots" % self.MAX_SLOTS)
         L = _lib.lib()
