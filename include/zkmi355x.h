@@ -186,6 +186,25 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
                              const uint8_t dy[32], uint32_t slot);
 int zk_pinocchio_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[960]);
 
+/* ---- verify surface (scope row f1): Curve.S.Pairing.pairing (src/lib/zk/curve.mli:46-54) ---------------
+ * Host code (a handful of pairings per proof, as in the reference, where they are calls into its external
+ * library): Groth16 verify = 3 pairings (groth16.ml:163-173), Pinocchio Verify.f = 13 (pinocchio.ml:254-420).
+ * zk_pairing_product: gt_out = prod_i e(P_i, Q_i) with one final exponentiation; points uncompressed as
+ * everywhere else, checked for curve and subgroup membership.  GT encoding: the 12 Fp coefficients of the tower
+ * Fp12 = Fp6[w]/(w^2 - v), Fp6 = Fp2[v]/(v^3 - (1+u)) in the order c0.c0.a, c0.c0.b, c0.c1.a, ..., c1.c2.b,
+ * 48 B big-endian each (the reference's GT bytes are defined by its external library: parity unpinned there,
+ * compared as field elements here).  zk_pairing_check: *is_one = (product == 1). */
+int zk_pairing_product(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, uint8_t gt_out[576]);
+int zk_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, int* is_one);
+/* Groth16.verify (groth16.ml:163-173): *ok = [ e(A,B) == ab * e(sum_k io_k * ltgm_io_k, gm) * e(C, d) ];
+ * ab = e(alpha, beta) in the GT encoding above, io_scalars the public coefficients in the key's variable order. */
+int zk_groth16_verify(const uint8_t ab[576], const uint8_t* ltgm_io /* n_io * 96 */, const uint8_t* io_scalars /* n_io * 32 */,
+                      size_t n_io, const uint8_t gm[192], const uint8_t d[192], const uint8_t proof[384], int* ok);
+/* Pinocchio Verify.f (pinocchio.ml:254-420), verification key (pinocchio.ml:62-75) flattened:
+ *   vk_g1 = one | aw | bgm | vv_io[n_io] | yy_io[n_io]      vk_g2 = one2 | av | ay | gm2 | bgm2 | yt | ww_io[n_io] */
+int zk_pinocchio_verify(const uint8_t* vk_g1, const uint8_t* vk_g2, const uint8_t* io_scalars, size_t n_io,
+                        const uint8_t proof[960], int* ok);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------------
  * With profiling on, kernel families are bracketed by HIP events on the stream they run on;
  * zk_profile_get returns the summed milliseconds and launch count since the last reset. */

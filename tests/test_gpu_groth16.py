@@ -31,7 +31,11 @@ def seeded_rng(seed):
 
 
 def pairing_verify(cs, w, pk, vk, proof):
-    """groth16.ml:163-173 with the oracle's pairing."""
+    """groth16.ml:163-173 with the oracle's pairing -- and the product's own Groth16.verify must agree,
+    accept the proof, and reject it for a wrong public input."""
+    io_vals = [w[k] for k in range(cs.m) if not cs.mid[k]]
+    assert Groth16.verify(io_vals, vk, proof)
+    assert not Groth16.verify([io_vals[0]] + [(x + 1) % RC.FR_MODULUS for x in io_vals[1:]], vk, proof)
     A, B, Cc = P.g1_from_bytes(proof.a), P.g2_from_bytes(proof.b), P.g1_from_bytes(proof.c)
     alpha1, beta2 = P.g1_from_bytes(bytes(pk.g1[:96])), P.g2_from_bytes(bytes(pk.g2[:192]))
     gm, dl = P.g2_from_bytes(vk.gm), P.g2_from_bytes(vk.d)
@@ -165,7 +169,8 @@ def test_full_size_trapdoor_and_verify(log_n):
     ta, tb, tc = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
     assert (proof.a, proof.b, proof.c) == (ta, tb, tc)
     from zukelang_amd.groth16 import VKey
+    from zukelang_amd.curve import Pairing
     vk = VKey(O.g1_generator(), G1.of_Fr(eio), O.g2_generator(), O.g2_mul(O.g2_generator(), P.fr_to_bytes(toxic[2])),
-              O.g2_mul(O.g2_generator(), P.fr_to_bytes(toxic[3])))
+              O.g2_mul(O.g2_generator(), P.fr_to_bytes(toxic[3])), Pairing.pairing(bytes(pk.g1[:96]), bytes(pk.g2[:192])))
     assert pairing_verify(cs, w, pk, vk, proof)
     prover.close()

@@ -45,6 +45,8 @@ def test_pinocchio_zk_and_nonzk_match_oracle(maker, literal):
         assert rc == 0 and proof.to_bytes() == ref
         io = [w[k] for k in range(cs.m) if not cs.mid[k]]
         assert O.pinocchio_verify(bytes(vk.g1), bytes(vk.g2), io, proof.to_bytes())
+        assert PIN.ZK.verify(io, vk, proof)                       # the product's own verifier (host pairing)
+        assert not PIN.ZK.verify([(x + 1) % RC.FR_MODULUS for x in io], vk, proof)
     # pipelined form: resident witness, three proofs in flight with different blinding, collected in order
     prover.set_witness(w)
     ds = [[next(st) for _ in range(3)] for _ in range(3)]

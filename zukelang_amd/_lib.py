@@ -20,6 +20,7 @@ EXPORTS = [
     "zk_device_malloc", "zk_device_free", "zk_device_memcpy",
     "zk_pinocchio_pk_upload", "zk_pinocchio_pk_free", "zk_pinocchio_prove",
     "zk_pinocchio_reserve_slots", "zk_pinocchio_set_witness", "zk_pinocchio_prove_async", "zk_pinocchio_prove_wait",
+    "zk_pairing_product", "zk_pairing_check", "zk_groth16_verify", "zk_pinocchio_verify",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_get", "zk_profile_names", "zk_sync",
     "zk_bench_field_mul",
 ]

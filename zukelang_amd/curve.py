@@ -133,3 +133,29 @@ class G1(_Group):
 class G2(_Group):
     POINT_BYTES, COMPRESSED_BYTES = 192, 96
     _msm, _of_fr, _powers, _compress = "zk_msm_g2", "zk_g2_of_fr", "zk_g2_powers", "zk_g2_compress"
+
+
+class GT:
+    """Target group element as the 12 Fp coefficients of the tower (576 B, include/zkmi355x.h); the reference's
+    GT bytes (curve.ml:217-219) come from its external library, so elements are compared, not serialised alike."""
+    BYTES = 576
+
+
+class Pairing:
+    """Curve.S.Pairing (src/lib/zk/curve.mli:46-54) on the host: a handful of pairings per verification."""
+
+    @staticmethod
+    def product(g1_points, g2_points):
+        """prod_i e(P_i, Q_i) with one final exponentiation -> GT bytes."""
+        g1, g2 = bytes(g1_points), bytes(g2_points)
+        n = len(g1) // 96
+        if len(g1) != 96 * n or len(g2) != 192 * n:
+            raise ValueError("pairing product: need as many G1 as G2 points")
+        out = C.create_string_buffer(GT.BYTES)
+        _lib.check(_lib.lib().zk_pairing_product(g1, g2, C.c_size_t(n), out))
+        return out.raw
+
+    @staticmethod
+    def pairing(p, q):
+        return Pairing.product(bytes(p), bytes(q))
+

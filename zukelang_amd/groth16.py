@@ -13,8 +13,8 @@ alpha, beta, gamma, delta, tau in that order (groth16.ml:51-55) and prove draws 
 (groth16.ml:124-125), exactly like `Fr.gen rng` in the reference.
 
 An unsatisfied witness raises AssertionError like `assert (Polynomial.is_zero rem)` (QAP.ml:134).
-`verify` (3 pairings, groth16.ml:163-173) is the next row of the scope table and is
-not part of the accelerated path.
+`verify` (3 pairings, groth16.ml:163-173; scope row f1) runs on the host in the library's own pairing
+(csrc/pairing_host.hip), as the reference's does in its external library.
 """
 import ctypes as C
 from dataclasses import dataclass
@@ -22,7 +22,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from .curve import G1, G2
+from .curve import G1, G2, Pairing
 from .r1cs import FR_MODULUS, R1CS, fr_bytes
 
 ZK_ERR_REMAINDER = -4
@@ -51,12 +51,13 @@ class PKey:
 
 @dataclass
 class VKey:
-    """groth16.ml:36-43 without `ab` (a GT element: needs the pairing)."""
+    """groth16.ml:36-43.  `ab` = e(alpha, beta) as a GT element (576 B, see curve.GT)."""
     one1: bytes
     ltgm_io: np.ndarray     # [L_k(tau)/gamma]_1 for k in io, Var order
     one2: bytes
     gm: bytes
     d: bytes
+    ab: bytes = b""
 
 
 @dataclass
@@ -192,7 +193,8 @@ class Groth16:
         exio = [Lk[k] * ginv % P for k in range(m) if not circuit.mid[k]]
         pk = PKey(G1.of_Fr(fr_bytes(ex1)), G2.of_Fr(fr_bytes(ex2)))
         vk = VKey(bytes(G1.of_Fr(fr_bytes([1]))), G1.of_Fr(fr_bytes(exio)), bytes(G2.of_Fr(fr_bytes([1]))),
-                  bytes(G2.of_Fr(fr_bytes([gm]))), bytes(G2.of_Fr(fr_bytes([d]))))
+                  bytes(G2.of_Fr(fr_bytes([gm]))), bytes(G2.of_Fr(fr_bytes([d]))),
+                  Pairing.pairing(bytes(pk.g1[:96]), bytes(pk.g2[:192])))        # ab = e(alpha, beta), groth16.ml:103
         return pk, vk
 
     def __init__(self, circuit: R1CS, pkey: PKey, rank=0, world=1):
@@ -321,7 +323,19 @@ class Groth16:
 
     @staticmethod
     def verify(input_output, vkey, proof):
-        raise NotImplementedError("Groth16.verify needs the pairing (groth16.ml:163-173): scope row f1, not on the accelerated path")
+        """Groth16.verify (groth16.ml:163-173): e(A, B) = ab * e(sum_k w_k [L_k(tau)/gamma]_1, gamma) * e(C, delta).
+        input_output: the public coefficients in the key's variable order (ints or 32-byte LE blocks).
+        Host work (three pairings), as in the reference."""
+        io = input_output if isinstance(input_output, (bytes, bytearray, np.ndarray)) else fr_bytes(list(input_output))
+        io = np.ascontiguousarray(np.frombuffer(bytes(io), dtype=np.uint8))
+        lt = np.ascontiguousarray(vkey.ltgm_io, dtype=np.uint8).reshape(-1)
+        n_io = len(lt) // 96
+        if len(io) != 32 * n_io:
+            raise AssertionError("Variable not found")          # var.ml:75-77 / curve.ml:96-100: domains must agree
+        ok = C.c_int(0)
+        _lib.check(_lib.lib().zk_groth16_verify(bytes(vkey.ab), _p(lt) if n_io else None, _p(io) if n_io else None, C.c_size_t(n_io),
+                                                bytes(vkey.gm), bytes(vkey.d), bytes(proof.a) + bytes(proof.b) + bytes(proof.c), C.byref(ok)))
+        return bool(ok.value)
 
 
 

@@ -155,8 +155,24 @@ class _Prover:
         return self._proof_of(out)
 
 
+def verify(input_output, vkey: VKey, proof: Proof):
+    """Verify.f (pinocchio.ml:254-420): the four knowledge-of-coefficient checks and the divisibility check,
+    13 pairings on the host.  input_output: the public coefficients c_k in the key's variable order."""
+    io = input_output if isinstance(input_output, (bytes, bytearray, np.ndarray)) else fr_bytes(list(input_output))
+    io = np.ascontiguousarray(np.frombuffer(bytes(io), dtype=np.uint8))
+    n_io = len(io) // 32
+    g1 = np.ascontiguousarray(vkey.g1, dtype=np.uint8).reshape(-1)
+    g2 = np.ascontiguousarray(vkey.g2, dtype=np.uint8).reshape(-1)
+    if len(g1) != 96 * (3 + 2 * n_io) or len(g2) != 192 * (6 + n_io):
+        raise AssertionError("Variable not found")          # domains of the key maps and of the public inputs must agree
+    ok = C.c_int(0)
+    _lib.check(_lib.lib().zk_pinocchio_verify(_p(g1), _p(g2), _p(io) if n_io else None, C.c_size_t(n_io), proof.to_bytes(), C.byref(ok)))
+    return bool(ok.value)
+
+
 class ZK(_Prover):
     keygen = staticmethod(keygen)
+    verify = staticmethod(verify)
 
     def prove(self, rng, sol):
         dv = rng() % FR_MODULUS     # pinocchio.ml:428-430: dv, dw, dy in this order
@@ -167,6 +183,7 @@ class ZK(_Prover):
 
 class NonZK(_Prover):
     keygen = staticmethod(keygen)
+    verify = staticmethod(verify)
 
     def prove(self, _rng, sol):
         return self.prove_with(sol, 0, 0, 0)
