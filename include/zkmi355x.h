@@ -77,6 +77,9 @@ int zk_g2_powers(uint32_t d, const uint8_t s[32], uint8_t* out /* (d+1)*192 */);
 
 /* to_compressed_bytes (curve.ml:199,208) of one uncompressed point. */
 int zk_g1_compress(const uint8_t in[96], uint8_t out[48]);
+/* of_compressed_bytes_exn (curve.ml:199-212): square root, sign from the flag, curve + subgroup checks (host code) */
+int zk_g1_decompress(const uint8_t in[48], uint8_t out[96]);
+int zk_g2_decompress(const uint8_t in[96], uint8_t out[192]);
 int zk_g2_compress(const uint8_t in[192], uint8_t out[96]);
 
 /* ---- protocol seam: Groth16.Make(C).prove (src/groth16/groth16.ml:235-237) -------------------

@@ -1,0 +1,55 @@
+"""Wire format (scope row f3): byte-level JSON strings as Yojson writes them, compressed points in and out
+(the decompression is host code: no GPU), and the record layouts of groth16.ml:24-43,110-114."""
+import numpy as np
+
+from oracle import pyref as P
+from zukelang_amd import wire
+from zukelang_amd.groth16 import Proof, VKey
+
+
+def test_json_strings_are_bytes_with_yojson_escapes():
+    raw = bytes(range(256))
+    s = wire.json_bytes_string(raw)
+    assert s[:1] == b'"' and s[-1:] == b'"'
+    assert b"\\u0000" in s and b"\\b" in s and b"\\t" in s and b"\\n" in s and b"\\f" in s and b"\\r" in s
+    assert b'\\"' in s and b"\\\\" in s and b"\\u007f" in s
+    assert bytes([0x80, 0x81]) in s and bytes([0xFF]) in s            # high bytes travel raw, not as UTF-8
+    assert wire.loads(s) == raw
+    v = {"a": raw, "l": [1, -2, [b"x", 3]], "e": {}, "z": []}
+    assert wire.loads(wire.dumps(v)) == {"a": raw, "l": [1, -2, [b"x", 3]], "e": {}, "z": []}
+    assert wire.fr_of_json(wire.fr_to_json(P.R - 1)) == P.R - 1 and wire.fr_to_json(5) == b'"5"'
+
+
+def test_decompression_inverts_compression_for_both_groups():
+    for k in (1, 2, 0xDEADBEEF, P.R - 1):
+        p1, p2 = P.pt_mul(P.G1, k), P.pt_mul(P.G2, k + 7)
+        assert wire.g1_of_json(P.g1_compress(p1)) == P.g1_to_bytes(p1)
+        assert wire.g2_of_json(P.g2_compress(p2)) == P.g2_to_bytes(p2)
+        assert wire.g1_of_json(P.g1_compress(P.pt_neg(p1))) == P.g1_to_bytes(P.pt_neg(p1))
+        assert wire.g2_of_json(P.g2_compress(P.pt_neg(p2))) == P.g2_to_bytes(P.pt_neg(p2))
+    assert wire.g1_of_json(P.g1_compress(None)) == P.g1_to_bytes(None)
+    assert wire.g2_of_json(P.g2_compress(None)) == P.g2_to_bytes(None)
+
+
+def test_groth16_records_round_trip():
+    pt1 = lambda k: P.g1_to_bytes(P.pt_mul(P.G1, k))
+    pt2 = lambda k: P.g2_to_bytes(P.pt_mul(P.G2, k))
+    proof = Proof(pt1(3), pt2(4), pt1(5))
+    js = wire.groth16_proof_to_json(proof)
+    assert js.startswith(b'{"a":"') and b'","b":"' in js and b'","c":"' in js
+    back = wire.groth16_proof_of_json(js)
+    assert (back.a, back.b, back.c) == (proof.a, proof.b, proof.c)
+    io_vars = [("ONE", 1), ("v", 6)]
+    vk = VKey(pt1(1), np.frombuffer(pt1(8) + pt1(9), dtype=np.uint8), pt2(1), pt2(10), pt2(11), bytes(range(64)) * 9)
+    vk2, vars2 = wire.groth16_vkey_of_json(wire.groth16_vkey_to_json(vk, io_vars))
+    assert vars2 == io_vars and bytes(vk2.ltgm_io) == bytes(vk.ltgm_io) and (vk2.one1, vk2.one2, vk2.gm, vk2.d, vk2.ab) == (vk.one1, vk.one2, vk.gm, vk.d, vk.ab)
+    n, mids = 3, [("input", 3), ("c", 4), ("c", 5)]
+    from zukelang_amd.groth16 import PKey
+    g1 = b"".join(pt1(20 + i) for i in range(3 + (n + 2) + (n - 1) + len(mids)))
+    g2 = b"".join(pt2(50 + i) for i in range(2 + n + 2))
+    pk = PKey(np.frombuffer(g1, dtype=np.uint8), np.frombuffer(g2, dtype=np.uint8))
+    js = wire.groth16_pkey_to_json(pk, n, mids)
+    keys = [k for k in wire.loads(js)]
+    assert keys == ["a", "d1", "ti1", "ltd_mid", "tiztd", "b1", "b2", "d2", "ti2"]          # groth16.ml:24-34 declaration order
+    pk2, mids2 = wire.groth16_pkey_of_json(js)
+    assert mids2 == mids and bytes(pk2.g1) == g1 and bytes(pk2.g2) == g2

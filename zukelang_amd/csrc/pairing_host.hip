@@ -274,6 +274,39 @@ static int g2_decode(G2& out, const uint8_t* b) {
     return ZK_OK;
 }
 
+// ---- square roots (p = 3 mod 4) for of_compressed_bytes_exn (curve.ml:199-212)
+static bool fp_sqrt(Fp& out, const Fp& a) {
+    out = fp_pow(a, HP_PP1D4, 6);
+    return fp_eq(fp_sqr(out), a);
+}
+static bool f2_sqrt(Fp2& out, const Fp2& a) {
+    if (fp_is_zero(a.b)) {
+        Fp r;
+        if (fp_sqrt(r, a.a)) { out = f2(r, fp_zero()); return true; }
+        if (fp_sqrt(r, fp_neg(a.a))) { out = f2(fp_zero(), r); return true; }      // (r u)^2 = -r^2
+        return false;
+    }
+    Fp s;
+    if (!fp_sqrt(s, fp_add(fp_sqr(a.a), fp_sqr(a.b)))) return false;                 // the norm of a square is a square
+    const Fp half = fp_inv(fp_from_u64(2));
+    Fp x0;
+    if (!fp_sqrt(x0, fp_mul(fp_add(a.a, s), half)) && !fp_sqrt(x0, fp_mul(fp_sub(a.a, s), half))) return false;
+    const Fp x1 = fp_mul(a.b, fp_inv(fp_add(x0, x0)));
+    out = f2(x0, x1);
+    return f2_eq(f2_mul(out, out), a);
+}
+// canonical integer of a > (p - 1) / 2 ?
+static bool fp_is_large(const Fp& a) {
+    Fp one = fp_zero();
+    one.l[0] = 1;
+    const Fp r = fp_mul(a, one);
+    for (int i = 5; i >= 0; i--) {
+        if (r.l[i] > HP_PM1D2[i]) return true;
+        if (r.l[i] < HP_PM1D2[i]) return false;
+    }
+    return false;
+}
+
 // Miller loop f_{|x|,Q}(P) over E(Fp12) with the untwisted Q, conjugated at the end (x < 0)
 static Fp12 miller_loop(const G1& p, const G2& q) {
     if (p.inf || q.inf) return f12_one();
@@ -368,6 +401,47 @@ int zk_pairing_check(const uint8_t* g1_points, const uint8_t* g2_points, size_t 
     return ZK_OK;
 }
 
+// of_compressed_bytes_exn (curve.ml:199-212): ZCash compressed -> uncompressed, with curve and subgroup checks
+int zk_g1_decompress(const uint8_t in[48], uint8_t out[96]) {
+    if (!in || !out) ZK_FAIL(ZK_ERR_ARG, "zk_g1_decompress: null");
+    if (!(in[0] & 0x80)) ZK_FAIL(ZK_ERR_ARG, "zk_g1_decompress: compression flag not set");
+    memset(out, 0, 96);
+    if (in[0] & 0x40) { out[0] = 0x40; return ZK_OK; }
+    uint8_t xb[48];
+    memcpy(xb, in, 48);
+    xb[0] &= 0x1f;
+    hp::G1 p;
+    p.inf = false;
+    if (!hp::fp_from_be(p.x, xb)) ZK_FAIL(ZK_ERR_ARG, "zk_g1_decompress: x >= p");
+    if (!hp::fp_sqrt(p.y, hp::fp_add(hp::fp_mul(hp::fp_sqr(p.x), p.x), hp::fp_from_u64(4)))) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g1_decompress: x is not on the curve");
+    if (hp::fp_is_large(p.y) != ((in[0] & 0x20) != 0)) p.y = hp::fp_neg(p.y);
+    if (!hp::pt_mul<hp::G1, hp::Fp>(p, HP_R, 4).inf) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g1_decompress: not in the prime-order subgroup");
+    hp::fp_to_be(out, p.x);
+    hp::fp_to_be(out + 48, p.y);
+    return ZK_OK;
+}
+int zk_g2_decompress(const uint8_t in[96], uint8_t out[192]) {
+    if (!in || !out) ZK_FAIL(ZK_ERR_ARG, "zk_g2_decompress: null");
+    if (!(in[0] & 0x80)) ZK_FAIL(ZK_ERR_ARG, "zk_g2_decompress: compression flag not set");
+    memset(out, 0, 192);
+    if (in[0] & 0x40) { out[0] = 0x40; return ZK_OK; }
+    uint8_t xb[96];
+    memcpy(xb, in, 96);
+    xb[0] &= 0x1f;
+    hp::G2 p;
+    p.inf = false;
+    if (!hp::fp_from_be(p.x.b, xb) || !hp::fp_from_be(p.x.a, xb + 48)) ZK_FAIL(ZK_ERR_ARG, "zk_g2_decompress: coordinate >= p");
+    const hp::Fp four = hp::fp_from_u64(4);
+    if (!hp::f2_sqrt(p.y, hp::f2_add(hp::f2_mul(hp::f2_mul(p.x, p.x), p.x), hp::f2(four, four)))) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g2_decompress: x is not on the curve");
+    const bool large = hp::fp_is_zero(p.y.b) ? hp::fp_is_large(p.y.a) : hp::fp_is_large(p.y.b);
+    if (large != ((in[0] & 0x20) != 0)) p.y = hp::f2_neg(p.y);
+    if (!hp::pt_mul<hp::G2, hp::Fp2>(p, HP_R, 4).inf) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g2_decompress: not in the prime-order subgroup");
+    hp::fp_to_be(out, p.x.b);
+    hp::fp_to_be(out + 48, p.x.a);
+    hp::fp_to_be(out + 96, p.y.b);
+    hp::fp_to_be(out + 144, p.y.a);
+    return ZK_OK;
+}
 // groth16.ml:163-173:  e(A, B) = ab * e(sum_k w_k ltgm_io_k, gm) * e(C, d)
 int zk_groth16_verify(const uint8_t ab[576], const uint8_t* ltgm_io, const uint8_t* io_scalars, size_t n_io, const uint8_t gm[192],
                       const uint8_t d[192], const uint8_t proof[384], int* ok) {

@@ -1,0 +1,224 @@
+"""Wire / on-disk format of proofs and keys (scope row f3): the JSON the reference derives with
+ppx_yojson_conv (`[@@deriving yojson]` on groth16.ml:24-43,110-114 and pinocchio.ml:37-75,195-208).
+
+What those derivers produce, restated (none of it can be run here -- parity unpinned):
+  record            {"field": value, ...} in declaration order
+  'a list           [v, ...]
+  'a Var.Map.t      [[[name, id], v], ...]  bindings in key order (var.ml:33-40,66-68; var = string * int)
+  Fr.t              decimal string of the integer (curve.ml:139-140 via Z.to_string, misc.ml:33-37)
+  G1.t / G2.t       JSON string holding the RAW 48 / 96 compressed bytes (curve.ml:199-212)
+  GT.t              JSON string of the external library's bytes (curve.ml:217-219) -- not reproducible
+                    here; this module writes the 576-byte coefficient encoding of include/zkmi355x.h
+A JSON string of raw bytes is not UTF-8.  Yojson.Safe.to_string writes bytes >= 0x80 as they are and
+escapes only '"', '\\', the control characters (\\b \\f \\n \\r \\t, the rest as \\u00XX) and 0x7f: the
+writer and parser below work on BYTES and reproduce exactly that.
+"""
+import ctypes as C
+
+from . import _lib
+from .curve import G1, G2
+
+_ESC = {0x22: b'\\"', 0x5C: b"\\\\", 0x08: b"\\b", 0x0C: b"\\f", 0x0A: b"\\n", 0x0D: b"\\r", 0x09: b"\\t"}
+_UNESC = {ord("b"): 8, ord("f"): 12, ord("n"): 10, ord("r"): 13, ord("t"): 9, 0x22: 0x22, 0x5C: 0x5C, ord("/"): ord("/")}
+
+
+def json_bytes_string(b):
+    """`String s of Yojson with s = raw bytes."""
+    out = bytearray(b'"')
+    for c in bytes(b):
+        if c in _ESC:
+            out += _ESC[c]
+        elif c < 0x20 or c == 0x7F:
+            out += b"\\u00%02x" % c
+        else:
+            out.append(c)
+    out += b'"'
+    return bytes(out)
+
+
+def dumps(v):
+    """Python value -> JSON bytes: dict (insertion order) / list / tuple / int / bytes (raw string) / str."""
+    if isinstance(v, dict):
+        return b"{" + b",".join(json_bytes_string(k.encode()) + b":" + dumps(x) for k, x in v.items()) + b"}"
+    if isinstance(v, (list, tuple)):
+        return b"[" + b",".join(dumps(x) for x in v) + b"]"
+    if isinstance(v, bool):
+        return b"true" if v else b"false"
+    if isinstance(v, int):
+        return str(v).encode()
+    if isinstance(v, str):
+        return json_bytes_string(v.encode())
+    return json_bytes_string(bytes(v))
+
+
+def loads(data):
+    """JSON bytes -> dict / list / int / bytes (every string comes back as bytes)."""
+    data = bytes(data)
+    pos = 0
+
+    def ws():
+        nonlocal pos
+        while pos < len(data) and data[pos] in b" \t\r\n":
+            pos += 1
+
+    def value():
+        nonlocal pos
+        ws()
+        c = data[pos]
+        if c == 0x7B:       # {
+            pos += 1
+            out = {}
+            ws()
+            if data[pos] == 0x7D:
+                pos += 1
+                return out
+            while True:
+                ws()
+                k = string().decode()
+                ws()
+                assert data[pos] == 0x3A
+                pos += 1
+                out[k] = value()
+                ws()
+                pos += 1
+                if data[pos - 1] == 0x7D:
+                    return out
+                assert data[pos - 1] == 0x2C
+        if c == 0x5B:       # [
+            pos += 1
+            out = []
+            ws()
+            if data[pos] == 0x5D:
+                pos += 1
+                return out
+            while True:
+                out.append(value())
+                ws()
+                pos += 1
+                if data[pos - 1] == 0x5D:
+                    return out
+                assert data[pos - 1] == 0x2C
+        if c == 0x22:
+            return string()
+        start = pos
+        while pos < len(data) and data[pos] in b"+-0123456789":
+            pos += 1
+        return int(data[start:pos])
+
+    def string():
+        nonlocal pos
+        assert data[pos] == 0x22
+        pos += 1
+        out = bytearray()
+        while data[pos] != 0x22:
+            c = data[pos]
+            if c == 0x5C:
+                e = data[pos + 1]
+                if e == ord("u"):
+                    out.append(int(data[pos + 2:pos + 6], 16) & 0xFF)
+                    pos += 6
+                else:
+                    out.append(_UNESC[e])
+                    pos += 2
+            else:
+                out.append(c)
+                pos += 1
+        pos += 1
+        return bytes(out)
+
+    v = value()
+    ws()
+    assert pos == len(data), "trailing bytes after the JSON value"
+    return v
+
+
+def _decompress(fn, comp, n_out):
+    out = C.create_string_buffer(n_out)
+    _lib.check(fn(bytes(comp), out))
+    return out.raw
+
+
+def g1_of_json(b):
+    return _decompress(_lib.lib().zk_g1_decompress, b, 96)
+
+
+def g2_of_json(b):
+    return _decompress(_lib.lib().zk_g2_decompress, b, 192)
+
+
+# ---- Groth16 (groth16.ml:110-114, 36-43, 24-34)
+def groth16_proof_to_json(proof):
+    return dumps({"a": G1.to_compressed_bytes(proof.a), "b": G2.to_compressed_bytes(proof.b), "c": G1.to_compressed_bytes(proof.c)})
+
+
+def groth16_proof_of_json(data):
+    from .groth16 import Proof
+    d = loads(data)
+    return Proof(g1_of_json(d["a"]), g2_of_json(d["b"]), g1_of_json(d["c"]))
+
+
+def groth16_vkey_to_json(vk, io_vars):
+    """io_vars: the (name, id) of the public variables in key order (Var.Map order = the order of vk.ltgm_io)."""
+    lt = bytes(vk.ltgm_io)
+    assert len(lt) == 96 * len(io_vars)
+    return dumps({"one1": G1.to_compressed_bytes(vk.one1),
+                  "ltgm_io": [[[name, vid], G1.to_compressed_bytes(lt[96 * i:96 * i + 96])] for i, (name, vid) in enumerate(io_vars)],
+                  "one2": G2.to_compressed_bytes(vk.one2), "gm": G2.to_compressed_bytes(vk.gm), "d": G2.to_compressed_bytes(vk.d),
+                  "ab": bytes(vk.ab)})
+
+
+def groth16_vkey_of_json(data):
+    from .groth16 import VKey
+    import numpy as np
+    d = loads(data)
+    io_vars = [(b[0][0].decode(), b[0][1]) for b in d["ltgm_io"]]
+    lt = b"".join(g1_of_json(b[1]) for b in d["ltgm_io"])
+    vk = VKey(g1_of_json(d["one1"]), np.frombuffer(lt, dtype=np.uint8), g2_of_json(d["one2"]), g2_of_json(d["gm"]), g2_of_json(d["d"]), d["ab"])
+    return vk, io_vars
+
+
+def groth16_pkey_to_json(pk, n, mid_vars):
+    """Record fields in the reference's declaration order (groth16.ml:24-34): a, d1, ti1, ltd_mid, tiztd, b1, b2, d2, ti2."""
+    g1, g2 = bytes(pk.g1), bytes(pk.g2)
+    p1 = lambda i: G1.to_compressed_bytes(g1[96 * i:96 * i + 96])
+    p2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
+    o_ti, o_tz = 3, 3 + (n + 2)
+    o_lt = o_tz + (n - 1)
+    assert len(g1) == 96 * (o_lt + len(mid_vars)) and len(g2) == 192 * (2 + n + 2)
+    return dumps({"a": p1(0), "d1": p1(1), "ti1": [p1(o_ti + i) for i in range(n + 2)],
+                  "ltd_mid": [[[name, vid], p1(o_lt + i)] for i, (name, vid) in enumerate(mid_vars)],
+                  "tiztd": [p1(o_tz + i) for i in range(n - 1)], "b1": p1(2), "b2": p2(0), "d2": p2(1),
+                  "ti2": [p2(2 + i) for i in range(n + 2)]})
+
+
+def groth16_pkey_of_json(data):
+    from .groth16 import PKey
+    import numpy as np
+    d = loads(data)
+    g1 = [g1_of_json(d["a"]), g1_of_json(d["d1"]), g1_of_json(d["b1"])] + [g1_of_json(x) for x in d["ti1"]] + \
+         [g1_of_json(x) for x in d["tiztd"]] + [g1_of_json(b[1]) for b in d["ltd_mid"]]
+    g2 = [g2_of_json(d["b2"]), g2_of_json(d["d2"])] + [g2_of_json(x) for x in d["ti2"]]
+    mid_vars = [(b[0][0].decode(), b[0][1]) for b in d["ltd_mid"]]
+    return PKey(np.frombuffer(b"".join(g1), dtype=np.uint8), np.frombuffer(b"".join(g2), dtype=np.uint8)), mid_vars
+
+
+# ---- Pinocchio proof (pinocchio.ml:195-208)
+_PIN_FIELDS = (("vv", 1), ("ww", 2), ("yy", 1), ("h", 1), ("vavv", 1), ("waww", 2), ("yayy", 1), ("bvwy", 1))
+
+
+def pinocchio_proof_to_json(proof):
+    return dumps({f: (G1 if g == 1 else G2).to_compressed_bytes(getattr(proof, f)) for f, g in _PIN_FIELDS})
+
+
+def pinocchio_proof_of_json(data):
+    from .pinocchio import Proof
+    d = loads(data)
+    return Proof(*[(g1_of_json if g == 1 else g2_of_json)(d[f]) for f, g in _PIN_FIELDS])
+
+
+def fr_to_json(x):
+    return dumps(str(int(x)))        # Z.yojson_of_t: the decimal string
+
+
+def fr_of_json(data):
+    return int(loads(data).decode())
