@@ -49,13 +49,14 @@ def pmc_traffic(kernel, n, world):
 
 def cpu_baseline():
     """The oracle's LITERAL restatement of groth16.ml:116-161 + QAP.ml:120-135 (per-variable
-    apply_powers, schoolbook mul / div_rem) on ONE host core, on a bounded sample: n = 64.
+    apply_powers, schoolbook mul / div_rem) on ONE host core, on a bounded sample: n = 128 (~15 s: the
+    literal algorithm is O(m n) scalar multiplications, 4x the work of n = 64).
     Also used as a checker: the GPU proof of the same sample must be byte-identical."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from zukelang_amd import r1cs as RC
     from zukelang_amd.groth16 import Groth16, PKey
-    n = 64
+    n = 128
     cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
     rng = seeded(0x5EED0002)
     toxic = [rng() for _ in range(5)]
@@ -74,7 +75,7 @@ def cpu_baseline():
         raise SystemExit("PARITY FAILURE: GPU proof differs from the oracle on the cpu_baseline sample")
     return {"value": n / dt, "unit": "constraints/s", "cores": 1, "kind": "port",
             "sample": "literal groth16.ml:116-161 + QAP.ml:120-135 (m*n single scalar-muls, schoolbook polynomials) on the "
-                      "iterated-cubic R1CS at n=64, m=66; %.2f s; GPU proof of the sample byte-identical" % dt}
+                      "iterated-cubic R1CS at n=128, m=130; %.2f s; GPU proof of the sample byte-identical" % dt}
 
 
 def main():

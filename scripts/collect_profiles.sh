@@ -15,6 +15,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python bench.py --no-cpu-baseline --inflight 1 --steps 6 --warmup 1 > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
 done
 echo "== 2^22"; timeout -k 10 900 python bench.py --log-n 22 --no-cpu-baseline --steps 6 --warmup 2 --inflight 4 > $O/bench_2^22.json 2> $O/bench_2^22.err || exit 1
-echo "== pinocchio 2^18"; timeout -k 10 600 python scripts/bench_pinocchio.py 18 5 > $O/pinocchio_2^18.json 2> $O/pinocchio.err || exit 1
-echo "== window sweep 2^20"; timeout -k 10 1100 python scripts/window_sweep.py 20 12 13 14 15 16 > $O/window_sweep_2^20.txt 2>&1 || exit 1
+echo "== pinocchio 2^18"; timeout -k 10 600 python scripts/bench_pinocchio.py 18 8 8 > $O/pinocchio_2^18.json 2> $O/pinocchio.err || exit 1
+
 echo done
