@@ -22,7 +22,7 @@ EXPORTS = [
     "zk_pinocchio_reserve_slots", "zk_pinocchio_set_witness", "zk_pinocchio_prove_async", "zk_pinocchio_prove_wait",
     "zk_pairing_product", "zk_pairing_check", "zk_groth16_verify", "zk_pinocchio_verify",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_get", "zk_profile_names", "zk_sync",
-    "zk_bench_field_mul",
+    "zk_bench_field_mul", "zk_selftest_fp",
 ]
 
 

@@ -97,6 +97,51 @@ __global__ void k_bench_mul_fp(uint32_t* out, uint32_t iters) {
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// Field-layer self-test (tests/test_gpu_field.py): every lane evaluates a battery of base-field expressions on its
+// operand pair through the SAME lazy-reduction code paths the group law uses (bounded adds / subs, products,
+// squares, fused double products, the zero test on unreduced values, inversion, full reduction, lane-pair Fp2)
+// and stores fully reduced plain integers (dense words) for comparison with host big-integer arithmetic.
+static constexpr int FP_SELFTEST_OUTS = 16;
+__global__ void k_fp_selftest(uint32_t* __restrict__ out, const uint32_t* __restrict__ a_words, const uint32_t* __restrict__ b_words, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;                      // n is even and pairs (2k, 2k+1) stay together: the lane-pair ops below are uniform
+    FpWords aw, bw;
+#pragma unroll
+    for (int l = 0; l < 12; l++) { aw.w[l] = a_words[12 * i + l]; bw.w[l] = b_words[12 * i + l]; }
+    const FpB<2> a = fp_to_mont(aw), b = fp_to_mont(bw);
+    uint32_t* o = out + (uint64_t)FP_SELFTEST_OUTS * 12 * i;
+    auto put = [&](int k, const FpWords& w) {
+#pragma unroll
+        for (int l = 0; l < 12; l++) o[12 * k + l] = w.w[l];
+    };
+    put(0, fp_from_mont(fe_add(a, b)));
+    put(1, fp_from_mont(fe_sub(a, b)));
+    put(2, fp_from_mont(fe_mul(a, b)));
+    put(3, fp_from_mont(fe_sqr(a)));
+    put(4, fp_from_mont(fe_neg(a)));
+    put(5, fp_from_mont(fe_inv(a)));
+    put(6, fp_from_mont(fe_dbl(fe_dbl(fe_dbl(a)))));                                   // 8a through three lazy doublings
+    const auto d1 = fe_sub(fe_sub(fe_sub(a, b), b), fe_add(a, a));                      // -a - 2b through a chain of growing bounds
+    put(7, fp_from_mont(d1));
+    put(8, fp_from_mont(fe_mul(d1, fe_sub(b, a))));                                     // product of two lazily reduced values
+    put(9, fp_from_mont(fe_mul_sub(a, b, fe_add(a, b), fe_sub(a, b))));                 // a b - (a + b)(a - b), fused form
+    FpWords flags;
+#pragma unroll
+    for (int l = 0; l < 12; l++) flags.w[l] = 0;
+    const auto z1 = fe_sub(fe_add(a, b), fe_add(b, a));                                 // a multiple of p that is not all-zero limbs
+    const auto z2 = fe_sub(fe_mul(a, b), fe_mul(b, a));
+    flags.w[0] = (fe_is_zero(z1) ? 1u : 0u) | (fe_is_zero(z2) ? 2u : 0u) | (fe_is_zero(a) ? 4u : 0u) | (fe_eq(fe_add(a, b), fe_add(b, a)) ? 8u : 0u) |
+                 (fe_eq(a, b) ? 16u : 0u) | (fe_is_zero(fe_sub(a, a)) ? 32u : 0u);
+    put(10, flags);
+    put(11, fp_pack(fp_canon(fe_add(fe_neg(a), a))));                                   // 0 as a reduced multiple of p
+    // lane pair (2k, 2k+1) = one Fp2 value x = a_even + a_odd u, y = b_even + b_odd u
+    const Fp2HB<2> x{a}, y{b};
+    put(12, fp_from_mont(fe_mul(x, y).v));
+    put(13, fp_from_mont(fe_sqr(x).v));
+    put(14, fp_from_mont(fe_mul(fe_sub(x, y), fe_add(x, y)).v));
+    put(15, fp_from_mont(fe_mul_inline(a, b)));
+}
+
 }  // namespace zk
 
 using namespace zk;
@@ -215,6 +260,23 @@ int zk_profile_names(char* buf, size_t buflen) {
     return ZK_OK;
 }
 
+int zk_selftest_fp(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+    if (!a || !b || !out || !n || (n & 1)) ZK_FAIL(ZK_ERR_ARG, "zk_selftest_fp: need an even number of operand pairs");
+    ZKCHK(ensure_init());
+    Ctx& c = ctx();
+    DevBuf da, db, dout;
+    ZKCHK(da.alloc(48 * n));
+    ZKCHK(db.alloc(48 * n));
+    ZKCHK(dout.alloc((size_t)FP_SELFTEST_OUTS * 48 * n));
+    HIPCHK(hipMemcpyAsync(da.p, a, 48 * n, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(db.p, b, 48 * n, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(k_fp_selftest, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, dout.as<uint32_t>(), (const uint32_t*)da.as<uint32_t>(),
+                       (const uint32_t*)db.as<uint32_t>(), (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)FP_SELFTEST_OUTS * 48 * n, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return ZK_OK;
+}
 int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s) {
     ZKCHK(ensure_init());
     Ctx& c = ctx();
