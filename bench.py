@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
+    ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
+                    "not the reference's key format -- the default and the headline use the tau-power key)")
     ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (the simpler, slower scheme)")
     ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
     ap.add_argument("--inflight", type=int, default=12, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
@@ -122,8 +124,10 @@ def main():
     n = (1 << args.log_n) * world
     cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
     rng = seeded(0x5EED0002)
-    pk, _vk = Groth16.keygen(rng, cs)
-    prover = Groth16(cs, pk, rank, world)
+    if args.lagrange_key and world > 1:
+        raise SystemExit("--lagrange-key is a single-GPU option")
+    pk, _vk = Groth16.keygen(rng, cs, lagrange=args.lagrange_key)
+    prover = Groth16(cs, pk, rank, world, lagrange=args.lagrange_key)
     prover.set_witness(w)
     rs = [(rng(), rng()) for _ in range(args.steps + args.warmup + 8)]
 
@@ -267,7 +271,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "groth16_prove, iterated-cubic R1CS (u -> u^3+u+3), BLS12-381, key+circuit+witness resident in HBM",
+            "config": {"workload": "groth16_prove, iterated-cubic R1CS (u -> u^3+u+3), BLS12-381, key+circuit+witness resident in HBM"
+                                   + (", LAGRANGE-FORM KEY EXTENSION (not the reference key format)" if args.lagrange_key else ""),
                        "constraints": n, "variables": cs.m, "proofs_in_flight": group.batch if group is not None else depth, "constraints_per_gpu": 1 << args.log_n,
                        "sharding": ("MSM base points over ranks; Fr stage of proof j of each group of N on rank j + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
                                     if group is not None else "MSM base points over ranks, Fr stage replicated; all-gather of 768 B partial sums + local EC reduce") if world > 1 else "single GPU",

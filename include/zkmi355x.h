@@ -101,6 +101,15 @@ typedef struct {
 int zk_groth16_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                          const uint8_t* mid /* m */, const uint8_t* pk_g1, size_t pk_g1_points,
                          const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
+/* Lagrange-form proving key (scope row f4 -- an EXTENSION of the key, only a keygen that knows tau can emit it;
+ * keys in the reference's format use zk_groth16_pk_upload).  The tau-power lists are replaced by
+ *   g1 = a | d1 | b1 | [l_i(tau)]_1 (n) | [lambda_t(tau) Z(tau)/delta]_1 (n-1) | ltd_mid        g2 = b2 | d2 | [l_i(tau)]_2 (n)
+ * with l_i the Lagrange basis of the QAP's points 0..n-1 (QAP.ml:84,92) and lambda_t that of n..2n-2.  The same
+ * group elements come out (proof bytes identical), but the prover needs only VALUES of v, w, h: three convolutions
+ * instead of the O(n log^2 n) basis conversion.  All prove entry points work on the handle; zk_groth16_qap_eval does not. */
+int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
+                                  const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
+                                  const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
 int zk_groth16_pk_free(uint64_t handle);
 
 /* Groth16.prove rng qap pkey sol with r, s supplied by the caller in the order the reference

@@ -85,8 +85,9 @@ int main(int argc, char** argv) {
     printf("\nr="); for (int i = 0; i < L; i++) printf("%x,", hr[i]);
     printf("\n");
     const uint32_t iters = 2000;
-    for (int occ = 1; occ <= 2; occ++) {
-        const int blocks = 256 * 8 * occ, threads = 256;
+    // throughput of the dependent product chain against waves per SIMD (256 CUs x 4 SIMDs; 256-thread blocks = 4 waves)
+    for (int wps : {1, 2, 3, 4, 6, 8, 16}) {
+        const int blocks = 256 * wps, threads = 256;
         k_bench<<<blocks, threads>>>(d, 10);
         hipDeviceSynchronize();
         hipEvent_t e0, e1;
@@ -98,7 +99,7 @@ int main(int argc, char** argv) {
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         double muls = 2.0 * iters * blocks * threads;
-        printf("blocks=%d: %.3f ms, %.2f G mul/s\n", blocks, ms, muls / ms / 1e6);
+        printf("%2d waves/SIMD: %.3f ms, %.2f G mul/s\n", wps, ms, muls / ms / 1e6);
     }
     // single wave latency
     {

@@ -174,3 +174,39 @@ def test_full_size_trapdoor_and_verify(log_n):
               O.g2_mul(O.g2_generator(), P.fr_to_bytes(toxic[3])), Pairing.pairing(bytes(pk.g1[:96]), bytes(pk.g2[:192])))
     assert pairing_verify(cs, w, pk, vk, proof)
     prover.close()
+
+
+@pytest.mark.parametrize("maker", [lambda: RC.readme_circuit(3), lambda: RC.iterated_cubic(2, 5), lambda: RC.iterated_cubic(6, 9),
+                                   lambda: RC.iterated_cubic(100, 10), lambda: RC.iterated_cubic(1000, 11), lambda: RC.iterated_cubic(1 << 16, 12)])
+def test_lagrange_form_key_gives_the_same_proofs(maker):
+    """Scope row f4: the extended key ([l_i(tau)] and shifted-domain h bases instead of tau powers) must yield
+    byte-identical proofs -- against the power-form path, and against the oracle's trapdoor evaluation."""
+    cs, w = maker()
+    rng = seeded_rng(0x5EED0009)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, vk = Groth16.keygen(lambda: next(it), cs, lagrange=True)
+    std, lag = Groth16(cs, pk), Groth16(cs, pk, lagrange=True)
+    L, R_, Oo = csrs(cs)
+    for _ in range(2):
+        r, s = rng(), rng()
+        p_std, p_lag = std.prove_rs(w, r, s), lag.prove_rs(w, r, s)
+        assert (p_lag.a, p_lag.b, p_lag.c) == (p_std.a, p_std.b, p_std.c)
+        ta, tb, tc = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+        assert (p_lag.a, p_lag.b, p_lag.c) == (ta, tb, tc)
+    io_vals = [w[k] for k in range(cs.m) if not cs.mid[k]]
+    assert Groth16.verify(io_vals, vk, p_lag)
+    # pipelined, resident witness
+    lag.set_witness(w)
+    rs = [(rng(), rng()) for _ in range(3)]
+    for slot, (r, s) in enumerate(rs):
+        lag.prove_async(None, r, s, slot)
+    for slot, (r, s) in enumerate(rs):
+        got = lag.prove_wait(slot)
+        ref = std.prove_rs(w, r, s)
+        assert (got.a, got.b, got.c) == (ref.a, ref.b, ref.c)
+    w_bad = list(w)
+    w_bad[2] = (w_bad[2] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        lag.prove_rs(w_bad, rng(), rng())
+    std.close(); lag.close()

@@ -19,6 +19,10 @@ struct FrStage {
     DevBuf pntt;                      // log_n2 levels x n2: NTT_len(P_{s,len/2}) / len per node
     DevBuf iz_ntt;                    // NTT_S of (rev Z)^-1 mod x^(n-1)
     DevBuf z;                         // Z coefficients, n + 1 (Montgomery)
+    // Lagrange-form keys only (frstage_init_lagrange): h through its VALUES on the shifted points n..2n-2
+    bool lagrange = false;
+    DevBuf g_ntt;                     // NTT_S of g[e] = 1/e (g[0] = 0): kernel of the extrapolation convolution
+    DevBuf zt;                        // Z(n + t) = (n+t)!/t!, t < n - 1
 };
 // per-proof scratch: one per proof in flight
 struct FrScratch {
@@ -31,6 +35,11 @@ int frstage_scratch_alloc(const FrStage& f, FrScratch& sc);
 // Montgomery form; *sc.flag |= 1 when some gate is violated (QAP.ml:134), |= 2 when a witness
 // value is not canonical.  Everything is enqueued on `s`; nothing synchronizes.
 int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_witness_canonical, hipStream_t s);
+
+// Lagrange-form variant (scope row f4): no basis conversion at all.  Leaves the VALUES a = L w, b = R w in
+// sc.abc[0..n), sc.abc[n..2n) and h(n + t), t < n - 1, in sc.h (Montgomery); flags as above.
+int frstage_init_lagrange(FrStage& f, hipStream_t s);     // after frstage_init
+int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_witness_canonical, hipStream_t s);
 
 // a*b via NTT on device (Montgomery in/out); out must hold na+nb-1 elements
 int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, void* d_out, hipStream_t s);

@@ -214,6 +214,65 @@ __global__ void k_inv_pow2_of(uint32_t* out, uint32_t k) {   // 2^-k
 }
 
 // ------------------------------------------------------------------ host helpers
+// ------------------------------------------------------------------ Lagrange-form keys (scope row f4)
+// With bases [l_i(tau)] instead of [tau^k] the prover needs v, w only through their VALUES a_i, b_i, and h through
+// its values on n - 1 further points j = n + t: for equally spaced points
+//   v(j) = Z(j) * sum_i (a_i c_i) / (j - i),   c_i = (-1)^(n-1-i) / (i! (n-1-i)!),   Z(j) = j! / (j-n)!
+// i.e. ONE cyclic convolution of size S = 2 n2 with the fixed kernel g[e] = 1/e per polynomial, and
+//   h(j) = (v(j) w(j) - y(j)) / Z(j) = Z(j) Sa_j Sb_j - Sc_j .
+// 3 convolutions per proof instead of the ~25 of the basis conversion.
+__global__ void k_inv_range(uint32_t* __restrict__ out, uint32_t total) {          // out[e] = 1/e, out[0] = 0; chunks of 256 per lane
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = c * FCH, hi = min((c + 1) * FCH, total);
+    if (lo >= total) return;
+    Fr run = fe_one<FrParams>();
+    for (uint32_t e = lo; e < hi; e++) {                  // prefix products into out
+        fe_store<FrParams>(out + 8 * (uint64_t)e, run);
+        if (e) run = fe_mul(run, fe_from_u32<FrParams>(e));
+    }
+    Fr inv = fe_inv(run);                                  // 1 / prod_{e in chunk, e > 0} e
+    for (uint32_t e = hi; e-- > lo;) {
+        const Fr pre = fe_load<FrParams>(out + 8 * (uint64_t)e);
+        if (e) {
+            fe_store<FrParams>(out + 8 * (uint64_t)e, fe_mul(inv, pre));
+            inv = fe_mul(inv, fe_from_u32<FrParams>(e));
+        } else fe_store<FrParams>(out + 8 * (uint64_t)e, fe_zero<FrParams>());
+    }
+}
+// zt[t] = (n+t)! / t! for t < cnt: prefix[c] = (256 c - 1)! over chunks of e; invfact[t] = 1/t!
+__global__ void k_zt(uint32_t* __restrict__ zt, const uint32_t* __restrict__ prefix, const uint32_t* __restrict__ invfact, uint32_t n, uint32_t cnt) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lo = c * FCH, hi = min((c + 1) * FCH, cnt);
+    if (lo >= cnt) return;
+    const uint32_t j0 = n + lo, ch = j0 / FCH;
+    Fr f = fe_load<FrParams>(prefix + 8 * (uint64_t)ch);   // (256 ch - 1)!  (1 for ch = 0)
+    for (uint32_t e = ch * FCH; e <= j0; e++)
+        if (e) f = fe_mul(f, fe_from_u32<FrParams>(e));     // j0!
+    for (uint32_t t = lo; t < hi; t++) {
+        fe_store<FrParams>(zt + 8 * (uint64_t)t, fe_mul(f, fe_load<FrParams>(invfact + 8 * (uint64_t)t)));
+        f = fe_mul(f, fe_from_u32<FrParams>(n + t + 1));
+    }
+}
+// out[i] = i < n ? x_i * c_i : 0   for i < total
+__global__ void k_lag_scale(uint32_t* __restrict__ out, const uint32_t* __restrict__ x, const uint32_t* __restrict__ invfact, uint32_t n, uint64_t total) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    Fr r = fe_zero<FrParams>();
+    if (i < n) {
+        r = fe_mul(fe_load<FrParams>(x + 8 * i), fe_mul(fe_load<FrParams>(invfact + 8 * i), fe_load<FrParams>(invfact + 8 * (uint64_t)(n - 1 - i))));
+        if ((n - 1 - i) & 1) r = fe_neg(r);
+    }
+    fe_store<FrParams>(out + 8 * i, r);
+}
+__global__ void k_lag_h(uint32_t* __restrict__ h, const uint32_t* __restrict__ sa, const uint32_t* __restrict__ sb, const uint32_t* __restrict__ sc,
+                        const uint32_t* __restrict__ zt, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t + 1 >= n) return;
+    const uint64_t j = (uint64_t)n + t;
+    const Fr v = fe_mul(fe_mul(fe_load<FrParams>(zt + 8 * (uint64_t)t), fe_load<FrParams>(sa + 8 * j)), fe_load<FrParams>(sb + 8 * j));
+    fe_store<FrParams>(h + 8 * (uint64_t)t, fe_sub(v, fe_load<FrParams>(sc + 8 * j)));
+}
+
 int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, void* d_out, hipStream_t s) {
     if (!na || !nb) return ZK_OK;
     uint64_t nout = na + nb - 1;
@@ -431,6 +490,56 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
         ZKCHK(ntt_mul_table(sc.bufB.p, S, f.log_S, f.iz_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
         // h[j] = hh[n-2-j], j < n-1
         hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufB), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
+int frstage_init_lagrange(FrStage& f, hipStream_t s) {
+    const uint32_t n = f.n, S = f.S;
+    ZKCHK(f.g_ntt.alloc(32 * (size_t)S));
+    ZKCHK(f.zt.alloc(32 * (size_t)(n > 1 ? n - 1 : 1)));
+    hipLaunchKernelGGL(k_inv_range, g1d((S + FCH - 1) / FCH, 64), dim3(64), 0, s, FRP(f.g_ntt), S);
+    ZKCHK(ntt_forward(f.g_ntt.p, S, f.log_S, s));
+    const uint32_t nch = (S + FCH - 1) / FCH;              // factorials up to 2 n <= S
+    DevBuf prod;
+    ZKCHK(prod.alloc(32 * (size_t)nch));
+    hipLaunchKernelGGL(k_fact_chunk_prod, g1d(nch, 64), dim3(64), 0, s, FRP(prod), S);
+    hipLaunchKernelGGL(k_fact_chunk_scan, dim3(1), dim3(64), 0, s, FRP(prod), nch);
+    hipLaunchKernelGGL(k_zt, g1d((n - 1 + FCH - 1) / FCH, 64), dim3(64), 0, s, FRP(f.zt), (const uint32_t*)FRP(prod), (const uint32_t*)FRP(f.invfact), n, n - 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    f.lagrange = true;
+    return ZK_OK;
+}
+int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipStream_t s) {
+    HIPCHK(hipGetLastError());
+    if (!f.lagrange) ZK_FAIL(ZK_ERR_ARG, "frstage_eval_lagrange: tables not initialised");
+    const uint32_t n = f.n, S = f.S;
+    uint32_t* a = FRP(sc.abc);
+    uint32_t* b = a + 8 * (uint64_t)n;
+    uint32_t* cc = b + 8 * (uint64_t)n;
+    HIPCHK(hipMemsetAsync(sc.flag.p, 0, 4, s));
+    {
+        ScopedTimer t("fr_spmv", s);
+        DevBuf& w = sc.wit;
+        hipLaunchKernelGGL(k_fr_to_mont_flag2, g1d(f.m), dim3(256), 0, s, FRP(w), (const uint32_t*)d_wit_canon, (uint64_t)f.m, sc.flag.as<int>());
+        hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.L.ptr), (const uint32_t*)FRP(f.L.col), (const uint32_t*)FRP(f.L.val), (const uint32_t*)FRP(w), a, n);
+        hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.R.ptr), (const uint32_t*)FRP(f.R.col), (const uint32_t*)FRP(f.R.val), (const uint32_t*)FRP(w), b, n);
+        hipLaunchKernelGGL(k_spmv, g1d(n), dim3(256), 0, s, (const uint32_t*)FRP(f.O.ptr), (const uint32_t*)FRP(f.O.col), (const uint32_t*)FRP(f.O.val), (const uint32_t*)FRP(w), cc, n);
+        hipLaunchKernelGGL(k_check_r1cs, g1d(n), dim3(256), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)cc, n, sc.flag.as<int>());
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ScopedTimer t("fr_extrapolate", s);
+        const uint32_t* src[3] = {a, b, cc};
+        void* dst[3] = {sc.bufA.p, sc.bufB.p, sc.tmp.p};
+        for (int k = 0; k < 3; k++) {
+            hipLaunchKernelGGL(k_lag_scale, g1d(S), dim3(256), 0, s, (uint32_t*)dst[k], src[k], (const uint32_t*)FRP(f.invfact), n, (uint64_t)S);
+            ZKCHK(ntt_mul_table(dst[k], S, f.log_S, f.g_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
+        }
+        hipLaunchKernelGGL(k_lag_h, g1d(n), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufA), (const uint32_t*)FRP(sc.bufB),
+                           (const uint32_t*)FRP(sc.tmp), (const uint32_t*)FRP(f.zt), n);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;

@@ -55,6 +55,7 @@ struct Groth16Key {
     DevBuf mid_idx;                     // variable index of the j-th mid variable
     DevBuf wit_resident;                // zk_groth16_set_witness
     bool have_witness = false;
+    bool lagrange = false;              // key holds [l_i(tau)] and the shifted-domain h bases instead of tau powers (row f4)
     std::unique_ptr<Slot> slots[MAX_SLOTS];
 };
 
@@ -69,14 +70,15 @@ static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n
 __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __restrict__ scalC, uint32_t* __restrict__ scalB,
                                   const uint32_t* __restrict__ v, const uint32_t* __restrict__ w, const uint32_t* __restrict__ h,
                                   const uint32_t* __restrict__ wit_mont, const uint32_t* __restrict__ mid_idx,
-                                  const uint32_t* __restrict__ rs, uint32_t n, uint32_t n_mid) {
+                                  const uint32_t* __restrict__ rs, uint32_t n, uint32_t n_mid, uint32_t nt) {
+    // nt = points of the tau basis: n + 2 powers tau^0..tau^(n+1) (groth16.ml:73) or n Lagrange points (row f4)
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t p1 = 3 + (uint64_t)(n + 2) + (n - 1) + n_mid;
+    const uint64_t p1 = 3 + (uint64_t)nt + (n - 1) + n_mid;
     if (i >= p1) return;
     const Fr r = fe_to_mont(fe_load<FrParams>(rs)), s = fe_to_mont(fe_load<FrParams>(rs + 8));
     const Fr zero = fe_zero<FrParams>(), one = fe_one<FrParams>();
     Fr a = zero, c = zero;
-    const uint64_t ti = 3, tz = ti + n + 2, lt = tz + (n - 1);
+    const uint64_t ti = 3, tz = ti + nt, lt = tz + (n - 1);
     if (i == 0) { a = one; c = s; }                                               // alpha
     else if (i == 1) { a = r; c = fe_mul(r, s); }                                 // delta
     else if (i == 2) { c = r; }                                                   // beta_1
@@ -91,7 +93,7 @@ __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __rest
     else c = fe_load<FrParams>(wit_mont + 8 * (uint64_t)mid_idx[i - lt]);
     fe_store<FrParams>(scalA + 8 * i, fe_from_mont(a));
     fe_store<FrParams>(scalC + 8 * i, fe_from_mont(c));
-    const uint64_t p2 = 2 + (uint64_t)(n + 2);
+    const uint64_t p2 = 2 + (uint64_t)nt;
     if (i < p2) {
         Fr b = zero;
         if (i == 0) b = one;                                                      // beta_2
@@ -150,7 +152,7 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
 
 static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
                   const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank,
-                  uint32_t world, uint64_t* handle) {
+                  uint32_t world, uint64_t* handle, bool lagrange = false) {
     if (!handle || !mid || !pk_g1 || !pk_g2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: null argument");
     if (world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "pk_upload: bad rank / world");
     ZKCHK(ensure_init());
@@ -163,11 +165,14 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
         if (mid[i]) mids.push_back(i);
     k.n_mid = (uint32_t)mids.size();
     if (n < 2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: need at least 2 constraints");
-    k.p1 = 3 + (uint64_t)(n + 2) + (n - 1) + k.n_mid;
-    k.p2 = 2 + (uint64_t)(n + 2);
-    if (pk_g1_points != k.p1) ZK_FAIL(ZK_ERR_DOMAIN, "pk_upload: G1 key length != 3 + (n+2) + (n-1) + |mids|");
-    if (pk_g2_points != k.p2) ZK_FAIL(ZK_ERR_DOMAIN, "pk_upload: G2 key length != 2 + (n+2)");
+    k.lagrange = lagrange;
+    const uint64_t nt = lagrange ? n : (uint64_t)n + 2;
+    k.p1 = 3 + nt + (n - 1) + k.n_mid;
+    k.p2 = 2 + nt;
+    if (pk_g1_points != k.p1) ZK_FAIL(ZK_ERR_DOMAIN, "pk_upload: G1 key length != 3 + (n+2 | n) + (n-1) + |mids|");
+    if (pk_g2_points != k.p2) ZK_FAIL(ZK_ERR_DOMAIN, "pk_upload: G2 key length != 2 + (n+2 | n)");
     ZKCHK(frstage_init(k.fr, n, m, L, R, O, c.stream));
+    if (lagrange) ZKCHK(frstage_init_lagrange(k.fr, c.stream));
     // contiguous pool slices per rank
     k.lo1 = k.p1 * rank / world; k.hi1 = k.p1 * (rank + 1) / world;
     k.lo2 = k.p2 * rank / world; k.hi2 = k.p2 * (rank + 1) / world;
@@ -197,12 +202,19 @@ static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const ui
     memcpy(sl.host + 392, r, 32);
     memcpy(sl.host + 424, s, 32);
     HIPCHK(hipMemcpyAsync(sl.rs.p, sl.host + 392, 64, hipMemcpyHostToDevice, sl.s0));
-    ZKCHK(frstage_eval(k.fr, sl.fs, wit, sl.s0));
-    const uint32_t* v = sl.fs.d.as<uint32_t>();
-    const uint32_t* w = v + 8 * (uint64_t)k.fr.n2;
+    const uint32_t *v, *w;
+    if (k.lagrange) {          // values a = L w, b = R w and h on the shifted points: no basis conversion
+        ZKCHK(frstage_eval_lagrange(k.fr, sl.fs, wit, sl.s0));
+        v = sl.fs.abc.as<uint32_t>();
+        w = v + 8 * (uint64_t)k.n;
+    } else {
+        ZKCHK(frstage_eval(k.fr, sl.fs, wit, sl.s0));
+        v = sl.fs.d.as<uint32_t>();
+        w = v + 8 * (uint64_t)k.fr.n2;
+    }
     hipLaunchKernelGGL(k_groth16_scalars, g1d(k.p1), dim3(256), 0, sl.s0, (uint32_t*)dA, (uint32_t*)dC, (uint32_t*)dB, v, w,
                        (const uint32_t*)sl.fs.h.as<uint32_t>(), (const uint32_t*)sl.fs.wit.as<uint32_t>(), (const uint32_t*)k.mid_idx.as<uint32_t>(),
-                       (const uint32_t*)sl.rs.as<uint32_t>(), k.n, k.n_mid);
+                       (const uint32_t*)sl.rs.as<uint32_t>(), k.n, k.n_mid, k.lagrange ? k.n : k.n + 2);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(sl.host + 384, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, sl.s0));
     return ZK_OK;
@@ -273,6 +285,10 @@ int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const 
                                  const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points,
                                  uint32_t rank, uint32_t world, uint64_t* handle) {
     return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, rank, world, handle);
+}
+int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
+                                  const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
+    return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, handle, true);
 }
 int zk_groth16_pk_free(uint64_t handle) {
     auto it = g_keys.find(handle);
@@ -436,6 +452,7 @@ int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uin
     Slot* sl;
     ZKCHK(slot_get(*k, 0, &sl));
     if (sl->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: slot 0 has a proof in flight");
+    if (k->lagrange) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: a Lagrange-form key never computes coefficient vectors");
     const void* wit = k->wit_resident.p;
     if (sol) {
         HIPCHK(hipMemcpyAsync(sl->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, sl->s0));

@@ -47,6 +47,11 @@ class PKey:
     g2 = b2 | d2 | ti2[n+2] (192 B each)"""
     g1: np.ndarray
     g2: np.ndarray
+    # Lagrange-form extension (scope row f4; keygen(..., lagrange=True)): the same key with the tau-power lists
+    # replaced by  g1 = a | d1 | b1 | [l_i(tau)]_1 (n) | [lambda_t(tau) Z(tau)/delta]_1 (n-1) | ltd_mid,
+    # g2 = b2 | d2 | [l_i(tau)]_2 (n).  None for keys in the reference's format.
+    lag_g1: np.ndarray = None
+    lag_g2: np.ndarray = None
 
 
 @dataclass
@@ -158,10 +163,11 @@ def shard_bounds(size, rank, world):
 
 class Groth16:
     @staticmethod
-    def keygen(rng, circuit: R1CS):
+    def keygen(rng, circuit: R1CS, lagrange=False):
         """Groth16 setup (groth16.ml:45-108): the exponents are host integers, the points come from the
         fixed-base kernel.  L_k(tau) is evaluated through the Lagrange basis of the integer domain
-        instead of Poly.apply on dense polynomials (same field element)."""
+        instead of Poly.apply on dense polynomials (same field element).  lagrange=True additionally emits the
+        Lagrange-form pools (PKey.lag_g1 / lag_g2): only a keygen can, it needs tau."""
         P = FR_MODULUS
         a, b, gm, d, t = (rng() % P for _ in range(5))
         n, m = circuit.n, circuit.m
@@ -192,23 +198,34 @@ class Groth16:
             ti = ti * t % P
         exio = [Lk[k] * ginv % P for k in range(m) if not circuit.mid[k]]
         pk = PKey(G1.of_Fr(fr_bytes(ex1)), G2.of_Fr(fr_bytes(ex2)))
+        if lagrange:
+            lam, _ = _lagrange_at(n - 1, (t - n) % P)           # basis of the points n..2n-2, evaluated at tau
+            lx1 = [a, d, b] + lag + [lam[i] * ztd % P for i in range(n - 1)] + [Lk[k] * dinv % P for k in range(m) if circuit.mid[k]]
+            lx2 = [b, d] + lag
+            pk.lag_g1, pk.lag_g2 = G1.of_Fr(fr_bytes(lx1)), G2.of_Fr(fr_bytes(lx2))
         vk = VKey(bytes(G1.of_Fr(fr_bytes([1]))), G1.of_Fr(fr_bytes(exio)), bytes(G2.of_Fr(fr_bytes([1]))),
                   bytes(G2.of_Fr(fr_bytes([gm]))), bytes(G2.of_Fr(fr_bytes([d]))),
                   Pairing.pairing(bytes(pk.g1[:96]), bytes(pk.g2[:192])))        # ab = e(alpha, beta), groth16.ml:103
         return pk, vk
 
-    def __init__(self, circuit: R1CS, pkey: PKey, rank=0, world=1):
-        """Uploads the proving key and the circuit once (device-resident until `close`)."""
+    def __init__(self, circuit: R1CS, pkey: PKey, rank=0, world=1, lagrange=False):
+        """Uploads the proving key and the circuit once (device-resident until `close`).  lagrange=True uploads the
+        Lagrange-form pools of an extended key instead (single GPU): same proofs, no basis conversion per proof."""
         self.circuit = circuit
         self.rank, self.world = rank, world
         self._keep = (circuit, pkey)
         L, R, O = _csr(circuit.L), _csr(circuit.R), _csr(circuit.O)
         h = C.c_uint64()
-        g1 = np.ascontiguousarray(pkey.g1, dtype=np.uint8)
-        g2 = np.ascontiguousarray(pkey.g2, dtype=np.uint8)
+        if lagrange and (pkey.lag_g1 is None or world != 1):
+            raise ValueError("lagrange=True needs a key made by keygen(..., lagrange=True) and a single GPU")
+        g1 = np.ascontiguousarray(pkey.lag_g1 if lagrange else pkey.g1, dtype=np.uint8)
+        g2 = np.ascontiguousarray(pkey.lag_g2 if lagrange else pkey.g2, dtype=np.uint8)
         mid = np.ascontiguousarray(circuit.mid, dtype=np.uint8)
         lib = _lib.lib()
-        if world == 1:
+        if lagrange:
+            rc = lib.zk_groth16_pk_upload_lagrange(C.c_uint32(circuit.n), C.c_uint32(circuit.m), C.byref(L), C.byref(R), C.byref(O), _p(mid),
+                                                   _p(g1), C.c_size_t(len(g1) // 96), _p(g2), C.c_size_t(len(g2) // 192), C.byref(h))
+        elif world == 1:
             rc = lib.zk_groth16_pk_upload(C.c_uint32(circuit.n), C.c_uint32(circuit.m), C.byref(L), C.byref(R), C.byref(O), _p(mid),
                                           _p(g1), C.c_size_t(len(g1) // 96), _p(g2), C.c_size_t(len(g2) // 192), C.byref(h))
         else:
