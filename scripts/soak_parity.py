@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU box (beyond the fixed cases of tests/): MSMs with adversarial scalar /
+point patterns against the oracle's naive fold, Groth16 proofs of random sizes against the trapdoor evaluation
+(power-form and Lagrange-form keys).  Usage: python scripts/soak_parity.py [seconds] [seed]"""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import r1cs as RC
+from zukelang_amd.curve import G1, G2
+from zukelang_amd.groth16 import Groth16
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+frb = P.fr_to_bytes
+t_end = time.time() + budget
+n_msm = n_g16 = 0
+while time.time() < t_end:
+    # ---- MSM with duplicates, negations, identity, tiny / huge / zero scalars
+    G, naive, gen, mul = rnd.choice([(G1, O.g1_msm_naive, O.g1_generator, O.g1_mul), (G2, O.g2_msm_naive, O.g2_generator, O.g2_mul)])
+    n = rnd.choice([1, 2, 3, 17, 64, 255, 256, 700, 1500])
+    B = G.POINT_BYTES
+    uniq = [mul(gen(), frb(rnd.randrange(1, P.R))) for _ in range(min(n, 6))]
+    inf = bytes([0x40]) + bytes(B - 1)
+    pts, scs = [], []
+    for i in range(n):
+        pts.append(rnd.choice(uniq + [inf]) if rnd.random() < 0.7 else mul(gen(), frb(rnd.randrange(1, 1 << 64))))
+        kind = rnd.random()
+        scs.append(0 if kind < 0.15 else 1 if kind < 0.3 else P.R - 1 if kind < 0.4 else rnd.randrange(1 << 16) if kind < 0.55 else
+                   (P.R - rnd.randrange(1, 1 << 20)) if kind < 0.7 else rnd.randrange(P.R))
+    bases, scalars = b"".join(pts), b"".join(frb(s) for s in scs)
+    rc, ref = naive(bases, scalars)
+    assert rc == 0
+    for c in (0, rnd.choice([2, 5, 9, 13, 16])):
+        got = bytes(G.apply_powers(scalars, np.frombuffer(bases, dtype=np.uint8), c))
+        assert got == ref, ("MSM mismatch", G.__name__, n, c)
+    n_msm += 1
+    # ---- Groth16 at a random size, both key forms
+    n = 2 * rnd.randrange(1, 1500)
+    cs, w = RC.iterated_cubic(n, rnd.randrange(1, P.R))
+    toxic = [rnd.randrange(1, P.R) for _ in range(5)]
+    it = iter(toxic)
+    pk, vk = Groth16.keygen(lambda: next(it), cs, lagrange=True)
+    r, s = rnd.randrange(P.R), rnd.randrange(P.R)
+    csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+    exp = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, b"".join(frb(x) for x in w), b"".join(frb(x) for x in toxic), frb(r), frb(s))
+    for lag in (False, True):
+        pr = Groth16(cs, pk, lagrange=lag)
+        p = pr.prove_rs(w, r, s)
+        assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch", n, lag)
+        pr.close()
+    n_g16 += 1
+    if (n_msm % 10) == 0:
+        print("soak: %d MSM cases, %d Groth16 cases ok" % (n_msm, n_g16), flush=True)
+print("SOAK-OK msm=%d groth16=%d" % (n_msm, n_g16))
