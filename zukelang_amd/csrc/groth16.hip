@@ -251,16 +251,6 @@ static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint
     sl.busy = true;
     return ZK_OK;
 }
-// proof bytes a | b | c from three XYZZ results laid out A, C (G1), B (G2)
-static int emit_proof(const void* d_results, uint8_t* proof) {
-    Ctx& c = ctx();
-    uint8_t g1pts[192];
-    ZKCHK(points_xyzz_to_bytes(CURVE_G1, d_results, 2, g1pts, c.stream));
-    ZKCHK(points_xyzz_to_bytes(CURVE_G2, (const char*)d_results + 2 * xyzz_bytes(CURVE_G1), 1, proof + 96, c.stream));
-    memcpy(proof, g1pts, 96);
-    memcpy(proof + 288, g1pts + 96, 96);
-    return ZK_OK;
-}
 static int prove_finish(Slot& sl) {
     if (!sl.busy) ZK_FAIL(ZK_ERR_ARG, "no proof in flight on this slot");
     HIPCHK(hipEventSynchronize(sl.done));
@@ -427,24 +417,51 @@ int zk_device_memcpy(void* dst, const void* src, size_t bytes) {
     HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
     return ZK_OK;
 }
+// Persistent buffers of zk_groth16_combine: hipMalloc / hipFree per call would synchronise the whole device
+// (hipFree does) and stall every proof in flight on the other streams.
+struct CombineBufs {
+    DevBuf parts, g1p, g2p, sum, out;
+    uint8_t* host = nullptr;      // pinned, 384 B
+    uint32_t world = 0;
+};
+static CombineBufs& g_combine = *new CombineBufs;          // never destroyed (see ntt.hip); released by zk_shutdown
+static void combine_release() {
+    g_combine.parts.release(); g_combine.g1p.release(); g_combine.g2p.release(); g_combine.sum.release(); g_combine.out.release();
+    if (g_combine.host) { (void)hipHostFree(g_combine.host); g_combine.host = nullptr; }
+    g_combine.world = 0;
+}
+static CleanupRegistrar g_combine_cleanup(combine_release);
 int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[384]) {
     if (!partials || !proof || world == 0) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_combine: bad argument");
     ZKCHK(ensure_init());
     Ctx& c = ctx();
     const size_t g1b = xyzz_bytes(CURVE_G1), g2b = xyzz_bytes(CURVE_G2), blk = 2 * g1b + g2b;
-    DevBuf parts, g1p, g2p, sum;
-    ZKCHK(parts.alloc(blk * world));
-    ZKCHK(g1p.alloc(2 * g1b * world));
-    ZKCHK(g2p.alloc(g2b * world));
-    ZKCHK(sum.alloc(blk));
-    HIPCHK(hipMemcpyAsync(parts.p, partials, blk * world, hipMemcpyHostToDevice, c.stream));
-    for (uint32_t j = 0; j < world; j++) {     // rank-major blocks -> [rank][A, C] and [rank][B]
-        HIPCHK(hipMemcpyAsync(g1p.as<char>() + 2 * g1b * j, parts.as<char>() + blk * j, 2 * g1b, hipMemcpyDeviceToDevice, c.stream));
-        HIPCHK(hipMemcpyAsync(g2p.as<char>() + g2b * j, parts.as<char>() + blk * j + 2 * g1b, g2b, hipMemcpyDeviceToDevice, c.stream));
+    CombineBufs& B = g_combine;
+    if (B.world < world) {
+        ZKCHK(B.parts.alloc(blk * world));
+        ZKCHK(B.g1p.alloc(2 * g1b * world));
+        ZKCHK(B.g2p.alloc(g2b * world));
+        ZKCHK(B.sum.alloc(blk));
+        ZKCHK(B.out.alloc(384));
+        if (!B.host) HIPCHK(hipHostMalloc((void**)&B.host, 384, hipHostMallocDefault));
+        B.world = world;
     }
-    ZKCHK(xyzz_sum_columns(CURVE_G1, sum.p, g1p.p, world, 2, c.stream));
-    ZKCHK(xyzz_sum_columns(CURVE_G2, sum.as<char>() + 2 * g1b, g2p.p, world, 1, c.stream));
-    return emit_proof(sum.p, proof);
+    HIPCHK(hipMemcpyAsync(B.parts.p, partials, blk * world, hipMemcpyHostToDevice, c.stream));
+    for (uint32_t j = 0; j < world; j++) {     // rank-major blocks -> [rank][A, C] and [rank][B]
+        HIPCHK(hipMemcpyAsync(B.g1p.as<char>() + 2 * g1b * j, B.parts.as<char>() + blk * j, 2 * g1b, hipMemcpyDeviceToDevice, c.stream));
+        HIPCHK(hipMemcpyAsync(B.g2p.as<char>() + g2b * j, B.parts.as<char>() + blk * j + 2 * g1b, g2b, hipMemcpyDeviceToDevice, c.stream));
+    }
+    ZKCHK(xyzz_sum_columns(CURVE_G1, B.sum.p, B.g1p.p, world, 2, c.stream));
+    ZKCHK(xyzz_sum_columns(CURVE_G2, B.sum.as<char>() + 2 * g1b, B.g2p.p, world, 1, c.stream));
+    // A, C (G1) -> proof[0..96), proof[288..384); B (G2) -> proof[96..288)
+    char* out = B.out.as<char>();
+    ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, B.sum.p, 1, out, c.stream));
+    ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, B.sum.as<char>() + g1b, 1, out + 288, c.stream));
+    ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, B.sum.as<char>() + 2 * g1b, 1, out + 96, c.stream));
+    HIPCHK(hipMemcpyAsync(B.host, B.out.p, 384, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    memcpy(proof, B.host, 384);
+    return ZK_OK;
 }
 int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out) {
     Groth16Key* k;
