@@ -1,23 +1,18 @@
 #!/usr/bin/env python3
 """BASELINE config 5: Pinocchio Protocol-2 ZK prove at 2^18 constraints on one MI355X (constraints/s).
-Keys come from the oracle's exponents + the fixed-base kernel (test infrastructure for the KEY only;
-the timed path is the HIP library)."""
+Keys come from the library's own keygen (host exponents + the fixed-base kernel)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle_lib as O
+sys.path.insert(0, ROOT)
 from zukelang_amd import r1cs as RC, pinocchio as PIN
-from zukelang_amd.curve import G1, G2
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n = 1 << log_n
 cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
 st = RC.fr_stream(0x5EED0003)
-tox = [next(st) for _ in range(8)]
-csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
-e1, e2, _, _ = O.pinocchio_keygen_exponents(None, cs.n, cs.m, *csr, cs.mid, bytes(RC.fr_bytes(tox)), False)
-prover = PIN.ZK(cs, PIN.PKey(G1.of_Fr(e1), G2.of_Fr(e2)))
 rng = lambda: next(st)
+pk, _vk = PIN.ZK.keygen(rng, cs)
+prover = PIN.ZK(cs, pk)
 wb = RC.fr_bytes(w)
 serial = prover.prove(rng, wb)
 t0 = time.perf_counter()

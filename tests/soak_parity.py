@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU box (beyond the fixed cases of tests/): MSMs with adversarial scalar /
 point patterns against the oracle's naive fold, Groth16 proofs of random sizes against the trapdoor evaluation
-(power-form and Lagrange-form keys).  Usage: python scripts/soak_parity.py [seconds] [seed]"""
+(power-form and Lagrange-form keys).  Test infrastructure (it uses the oracle); not collected by pytest.
+Usage: python tests/soak_parity.py [seconds] [seed]"""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))      # ROOT = repo root (this file lives in tests/)
 import numpy as np
 import oracle_lib as O
 from oracle import pyref as P
