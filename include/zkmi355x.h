@@ -119,7 +119,7 @@ int zk_groth16_pk_free(uint64_t handle);
  * Returns ZK_ERR_REMAINDER when the witness does not satisfy the gates (QAP.ml:134). */
 int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
                      uint8_t proof[384]);
-/* Pipelined form: up to 16 proofs in flight on one key, each on its own `slot` (own scratch and
+/* Pipelined form: up to 15 proofs in flight on one key, each on its own `slot` (own scratch and
  * HIP streams).  _async enqueues and returns; _wait blocks for that slot and delivers the proof.
  * The single-wave tails of one proof (bucket reduction, affine conversion) then run under the
  * bulk kernels of the next.  zk_groth16_prove == _async + _wait on slot 0. */
@@ -190,7 +190,7 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
 int zk_pinocchio_pk_free(uint64_t handle);
 int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32],
                        const uint8_t dy[32], uint8_t proof[960]);
-/* Pipelined form, as for Groth16: up to 16 proofs in flight on one key, each on its own `slot`;
+/* Pipelined form, as for Groth16: up to 15 proofs in flight on one key, each on its own `slot`;
  * sol == NULL uses the witness made resident by zk_pinocchio_set_witness.  zk_pinocchio_prove == _async + _wait on slot 0. */
 int zk_pinocchio_reserve_slots(uint64_t handle, uint32_t count);
 int zk_pinocchio_set_witness(uint64_t handle, const uint8_t* sol);

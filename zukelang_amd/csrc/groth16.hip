@@ -42,7 +42,7 @@ struct Slot {
         if (host) (void)hipHostFree(host);
     }
 };
-static constexpr uint32_t MAX_SLOTS = 16;
+static constexpr uint32_t MAX_SLOTS = 15;      // + the context stream = the 16 hardware queues the chip runs side by side
 
 struct Groth16Key {
     uint32_t n = 0, m = 0, n_mid = 0;
@@ -111,7 +111,7 @@ static int key_lookup(uint64_t handle, Groth16Key** out) {
 }
 
 static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
-    if (idx >= MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "slot index out of range (max 16 proofs in flight)");
+    if (idx >= MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "slot index out of range (max 15 proofs in flight)");
     if (!k.slots[idx]) {
         auto sl = std::make_unique<Slot>();
         ZKCHK(frstage_scratch_alloc(k.fr, sl->fs));
@@ -290,7 +290,7 @@ int zk_groth16_pk_free(uint64_t handle) {
 int zk_groth16_reserve_slots(uint64_t handle, uint32_t count) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
-    if (count > MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_reserve_slots: at most 16 slots");
+    if (count > MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_reserve_slots: at most 15 slots");
     for (uint32_t i = 0; i < count; i++) {
         Slot* sl;
         ZKCHK(slot_get(*k, i, &sl));

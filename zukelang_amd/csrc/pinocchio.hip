@@ -43,7 +43,7 @@ struct PinSlot {
         if (host) (void)hipHostFree(host);
     }
 };
-static constexpr uint32_t PIN_MAX_SLOTS = 16;
+static constexpr uint32_t PIN_MAX_SLOTS = 15;
 struct PinKey {
     uint32_t n = 0, m = 0, n_mid = 0;
     FrStage fr;
@@ -168,7 +168,7 @@ int zk_pinocchio_pk_free(uint64_t handle) {
     return ZK_OK;
 }
 static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
-    if (idx >= PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "pinocchio: slot index out of range (max 16 proofs in flight)");
+    if (idx >= PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "pinocchio: slot index out of range (max 15 proofs in flight)");
     if (!k.slots[idx]) {
         auto sl = std::make_unique<PinSlot>();
         ZKCHK(frstage_scratch_alloc(k.fr, sl->fs));
@@ -189,7 +189,7 @@ static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
 int zk_pinocchio_reserve_slots(uint64_t handle, uint32_t count) {
     PinKey* kp;
     ZKCHK(pin_lookup(handle, &kp));
-    if (count > PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_reserve_slots: at most 16 slots");
+    if (count > PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_reserve_slots: at most 15 slots");
     for (uint32_t i = 0; i < count; i++) {
         PinSlot* sl;
         ZKCHK(pin_slot_get(*kp, i, &sl));

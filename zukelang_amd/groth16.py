@@ -367,7 +367,7 @@ class GroupProver:
     a sharded key it is a whole Fr stage.  The next round's Fr stages are enqueued before this round's MSMs
     are waited for."""
 
-    MAX_SLOTS = 16
+    MAX_SLOTS = 15
 
     def __init__(self, prover, groups=None):
         import torch
