@@ -26,7 +26,7 @@ struct FrStage {
 };
 // per-proof scratch: one per proof in flight
 struct FrScratch {
-    DevBuf wit, abc, d, tmp, bufA, bufB, h, flag;
+    DevBuf wit, abc, d, tmp, bufA, h, flag;      // bufA: two convolution buffers of S elements back to back
 };
 
 int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, hipStream_t s);

@@ -59,6 +59,18 @@ __global__ void k_scale_pad(uint32_t* out, const uint32_t* in, const uint32_t* t
     }
     fe_store<FrParams>(out + 8 * i, x);
 }
+// batched form: vector k = i / out_stride, element j = i % out_stride:  out[i] = j < n_in ? in[k * in_stride + j] * (tab ? tab[j] : 1) : 0
+__global__ void k_scale_pad2(uint32_t* out, const uint32_t* in, const uint32_t* tab, uint64_t n_in, uint64_t in_stride, uint64_t out_stride, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t k = i / out_stride, j = i % out_stride;
+    Fr x = fe_zero<FrParams>();
+    if (j < n_in) {
+        x = fe_load<FrParams>(in + 8 * (k * in_stride + j));
+        if (tab) x = fe_mul(x, fe_load<FrParams>(tab + 8 * j));
+    }
+    fe_store<FrParams>(out + 8 * i, x);
+}
 // Tree levels 1..levels (node length <= tile) in ONE kernel: the tile stays in LDS across the levels,
 // per level  node <- lo + P_left * hi  = {hi zero-padded -> NTT -> * table -> iNTT -> + lo}.
 // HBM sees the coefficients once in and once out (plus the per-level tables) instead of once per level.
@@ -441,8 +453,7 @@ int frstage_scratch_alloc(const FrStage& f, FrScratch& sc) {
     ZKCHK(sc.abc.alloc(32 * (size_t)3 * f.n));
     ZKCHK(sc.d.alloc(32 * (size_t)2 * f.n2));
     ZKCHK(sc.tmp.alloc(32 * (size_t)2 * f.n2));
-    ZKCHK(sc.bufA.alloc(32 * (size_t)f.S));
-    ZKCHK(sc.bufB.alloc(32 * (size_t)f.S));
+    ZKCHK(sc.bufA.alloc(32 * (size_t)2 * f.S));          // two convolution buffers back to back: A = [0, S), B = [S, 2S)
     ZKCHK(sc.h.alloc(32 * (size_t)f.n));
     ZKCHK(sc.flag.alloc(4));
     return ZK_OK;
@@ -469,12 +480,12 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
     // ---- values -> Newton coefficients (both vectors), into d[0..n2) and d[n2..2 n2)
     {
         ScopedTimer t("fr_newton", s);
-        for (int k = 0; k < 2; k++) {
-            const uint32_t* src = k == 0 ? a : b;
-            hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), src, (const uint32_t*)FRP(f.invfact), (uint64_t)n, (uint64_t)S);
-            ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, f.e_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
-            hipLaunchKernelGGL(k_scale_pad, g1d(n2), dim3(256), 0, s, FRP(sc.d) + 8 * (uint64_t)k * n2, (const uint32_t*)FRP(sc.bufA), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)n2);
-        }
+        // both vectors as two nodes of one batched convolution
+        hipLaunchKernelGGL(k_scale_pad2, g1d(2 * (uint64_t)S), dim3(256), 0, s, FRP(sc.bufA), (const uint32_t*)a, (const uint32_t*)FRP(f.invfact), (uint64_t)n, (uint64_t)n,
+                           (uint64_t)S, 2 * (uint64_t)S);
+        ZKCHK(ntt_mul_table(sc.bufA.p, 2 * (uint64_t)S, f.log_S, f.e_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
+        hipLaunchKernelGGL(k_scale_pad2, g1d(2 * (uint64_t)n2), dim3(256), 0, s, FRP(sc.d), (const uint32_t*)FRP(sc.bufA), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S,
+                           (uint64_t)n2, 2 * (uint64_t)n2);
     }
     // ---- Newton -> monomial
     ZKCHK(tree_convert(f, sc.d.p, 2, f.log_n2, sc.tmp.p, s));
@@ -482,14 +493,14 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
     {
         ScopedTimer t("fr_quotient", s);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), (const uint32_t*)FRP(sc.d), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
-        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufB), (const uint32_t*)(FRP(sc.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
-        ZKCHK(ntt_forward(sc.bufB.p, S, f.log_S, s));
-        ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, sc.bufB.p, (uint64_t)S - 1, true, nullptr, nullptr, s));   // v*w, coefficients 0..2n-2
+        hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, (FRP(sc.bufA) + 8 * (uint64_t)S), (const uint32_t*)(FRP(sc.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
+        ZKCHK(ntt_forward((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, s));
+        ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), (uint64_t)S - 1, true, nullptr, nullptr, s));   // v*w, coefficients 0..2n-2
         // t[k] = (v w)[2n-2-k], k < n-1
-        hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufB), (const uint32_t*)FRP(sc.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
-        ZKCHK(ntt_mul_table(sc.bufB.p, S, f.log_S, f.iz_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
+        hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, (FRP(sc.bufA) + 8 * (uint64_t)S), (const uint32_t*)FRP(sc.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
+        ZKCHK(ntt_mul_table((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, f.iz_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
         // h[j] = hh[n-2-j], j < n-1
-        hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufB), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
+        hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)(FRP(sc.bufA) + 8 * (uint64_t)S), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
@@ -533,12 +544,12 @@ int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_wit_can
     {
         ScopedTimer t("fr_extrapolate", s);
         const uint32_t* src[3] = {a, b, cc};
-        void* dst[3] = {sc.bufA.p, sc.bufB.p, sc.tmp.p};
+        void* dst[3] = {sc.bufA.p, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), sc.tmp.p};
         for (int k = 0; k < 3; k++) {
             hipLaunchKernelGGL(k_lag_scale, g1d(S), dim3(256), 0, s, (uint32_t*)dst[k], src[k], (const uint32_t*)FRP(f.invfact), n, (uint64_t)S);
             ZKCHK(ntt_mul_table(dst[k], S, f.log_S, f.g_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
         }
-        hipLaunchKernelGGL(k_lag_h, g1d(n), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufA), (const uint32_t*)FRP(sc.bufB),
+        hipLaunchKernelGGL(k_lag_h, g1d(n), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufA), (const uint32_t*)(FRP(sc.bufA) + 8 * (uint64_t)S),
                            (const uint32_t*)FRP(sc.tmp), (const uint32_t*)FRP(f.zt), n);
     }
     HIPCHK(hipGetLastError());
