@@ -287,11 +287,13 @@ __global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ 
     xyzz_store_raw<T>(buckets + (uint64_t)XB * kb, acc);
 }
 // sum of the accumulators of the NT / lanes points of a workgroup, result in point 0
-template <class T, int NT> FF_INLINE void block_tree_sum(Xyzz<T>& acc, uint32_t (*lds)[NT]) {
+// (GROUP = points per independent sum, a power of two; 0 = the whole workgroup: result in point 0 of every group)
+template <class T, int NT, int GROUP = 0> FF_INLINE void block_tree_sum(Xyzz<T>& acc, uint32_t (*lds)[NT]) {
     constexpr uint32_t LP = Lanes<T>::N;
-    const uint32_t t = threadIdx.x, pi = t / LP;
+    constexpr uint32_t GP = GROUP ? GROUP : NT / LP;
+    const uint32_t t = threadIdx.x, pi = (t / LP) & (GP - 1);
     uint32_t tmp[LANE_POINT_WORDS];
-    for (uint32_t d = NT / LP / 2; d >= 1; d >>= 1) {
+    for (uint32_t d = GP / 2; d >= 1; d >>= 1) {
         __syncthreads();
         if (pi >= d && pi < 2 * d) {
             xyzz_to_words(tmp, acc);
@@ -345,20 +347,26 @@ __global__ __launch_bounds__(256) void k_msm_fixup_big(const uint32_t* __restric
 struct DigitPlan {
     uint32_t nbw, lb, nd0, nd1;
 };
+// 16 points per digit value, four values per 64-point workgroup: every lane sums cnt/16 buckets serially, then a
+// 4-level tree.  (One value per workgroup -- 2-4 buckets per lane, 6 levels -- finishes sooner but keeps four times
+// as many waves busy for two thirds of that time; with a dozen proofs in flight SIMD time is what counts.)
+static constexpr uint32_t DS_GROUP = 16, DS_PER_WG = 64 / DS_GROUP;
 template <class T>
 __global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(const uint8_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
                                                                        DigitPlan p, uint8_t* __restrict__ S) {
     constexpr int XB = RawLayout<T>::XYZZ;
     constexpr uint32_t LP = Lanes<T>::N;
     __shared__ uint32_t lds[LANE_POINT_WORDS][64 * LP];
-    const uint32_t b = blockIdx.x, win = blockIdx.y, pt = threadIdx.x / LP;
+    const uint32_t win = blockIdx.y, pt = threadIdx.x / LP, sub = pt / DS_GROUP, lane = pt % DS_GROUP;
+    const uint32_t b = blockIdx.x * DS_PER_WG + sub;
+    const bool valid = b < p.nd0 + p.nd1;
     const uint64_t base = (uint64_t)win * p.nbw;
     const bool low = b < p.nd0;
     const uint32_t d = low ? b : b - p.nd0;
     const uint32_t cnt = low ? p.nd1 : p.nd0;
     Xyzz<T> acc = xyzz_inf<T>();
-    if (d != 0) {                                   // weight 0 never contributes
-        for (uint32_t e = pt; e < cnt; e += 64) {
+    if (valid && d != 0) {                          // weight 0 never contributes
+        for (uint32_t e = lane; e < cnt; e += DS_GROUP) {
             const uint32_t w = low ? (e << p.lb) + d : (d << p.lb) + e;
             if (w >= 1 && w <= p.nbw && offsets[base + w] != offsets[base + w - 1]) {
                 const Xyzz<T> q = xyzz_load_raw<T>(buckets + (uint64_t)XB * (base + w - 1));
@@ -366,8 +374,8 @@ __global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(const uint8
             }
         }
     }
-    block_tree_sum<T, 64 * LP>(acc, lds);
-    if (threadIdx.x < LP) xyzz_store_raw<T>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
+    block_tree_sum<T, 64 * LP, DS_GROUP>(acc, lds);
+    if (valid && lane == 0) xyzz_store_raw<T>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
 }
 // V[win][k] = sum_d d * S[win][k][d]
 template <class T>
@@ -647,7 +655,7 @@ template <class F, class T> static int msm_run_t(const MsmBases& b, MsmWorkspace
         hipLaunchKernelGGL(k_msm_fixup_big<T>, dim3(w.nbuckets < 256 ? w.nbuckets : 256), dim3(256), 0, s, w.offsets.as<uint32_t>(), w.chunk,
                            w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), (const uint32_t*)w.worklist.as<uint32_t>());
         const DigitPlan dp = digit_plan(b.c);
-        hipLaunchKernelGGL(k_msm_digit_sums<T>, dim3(dp.nd0 + dp.nd1, nwin), dim3(64 * LP), 0, s, w.buckets.as<uint8_t>(), (const uint32_t*)w.offsets.as<uint32_t>(), dp,
+        hipLaunchKernelGGL(k_msm_digit_sums<T>, dim3((dp.nd0 + dp.nd1 + DS_PER_WG - 1) / DS_PER_WG, nwin), dim3(64 * LP), 0, s, w.buckets.as<uint8_t>(), (const uint32_t*)w.offsets.as<uint32_t>(), dp,
                            w.red.as<uint8_t>());
         hipLaunchKernelGGL(k_msm_digit_weight<T>, dim3(2, nwin), dim3(256 * LP), 0, s, w.red.as<uint8_t>(), dp, w.wsum.as<uint8_t>());
         hipLaunchKernelGGL(k_msm_final<T>, dim3(1), dim3(64), 0, s, w.wsum.as<uint8_t>(), nwin, b.c, dp.lb, (uint8_t*)d_out);
