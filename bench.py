@@ -139,7 +139,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    depth = max(1, min(args.inflight, 14))      # the chip runs 16 hardware queues side by side; keep two spare
+    depth = max(1, min(args.inflight, 15))      # the chip runs 16 hardware queues side by side: 15 slots + the context stream
     if world > 1:
         depth = min(depth, 8)      # sharded proofs: the host also runs an all-gather + combine per proof
 
