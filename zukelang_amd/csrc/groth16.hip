@@ -229,17 +229,28 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
     HIPCHK(hipEventRecord(sl.fork, sl.s0));
     HIPCHK(hipStreamWaitEvent(sl.s1, sl.fork, 0));
     HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
-    // B (G2, the longest chain) first
-    ZKCHK(msm_run(k.g2, sl.wsB, dB, res + 2 * g1b, sl.s1));
-    if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, res + 2 * g1b, 1, out + 96, sl.s1));
-    HIPCHK(hipEventRecord(sl.join1, sl.s1));
-    ZKCHK(msm_run(k.g1, sl.wsC, dC, res + g1b, sl.s0));
-    if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + g1b, 1, out + 288, sl.s0));
-    ZKCHK(msm_run(k.g1, sl.wsA, dA, res, sl.s2));
-    if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res, 1, out, sl.s2));
-    HIPCHK(hipEventRecord(sl.join2, sl.s2));
-    HIPCHK(hipStreamWaitEvent(sl.s0, sl.join1, 0));
-    HIPCHK(hipStreamWaitEvent(sl.s0, sl.join2, 0));
+    if (sl.serial) {
+        // one stream: sort + accumulate per MSM, then the reductions of A and C (same bases) as ONE chain of launches
+        ZKCHK(msm_run(k.g2, sl.wsB, dB, res + 2 * g1b, sl.s0));
+        ZKCHK(msm_sort_accumulate(k.g1, sl.wsC, dC, sl.s0));
+        ZKCHK(msm_sort_accumulate(k.g1, sl.wsA, dA, sl.s0));
+        MsmWorkspace* ws[2] = {&sl.wsA, &sl.wsC};
+        void* outs[2] = {res, res + g1b};
+        ZKCHK(msm_reduce(k.g1, ws, outs, 2, sl.s0));
+        if (!raw) ZKCHK(proof_points_to_bytes_dev(res, out, res + g1b, out + 288, res + 2 * g1b, out + 96, sl.s0));
+    } else {
+        // B (G2, the longest chain) first
+        ZKCHK(msm_run(k.g2, sl.wsB, dB, res + 2 * g1b, sl.s1));
+        if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, res + 2 * g1b, 1, out + 96, sl.s1));
+        HIPCHK(hipEventRecord(sl.join1, sl.s1));
+        ZKCHK(msm_run(k.g1, sl.wsC, dC, res + g1b, sl.s0));
+        if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + g1b, 1, out + 288, sl.s0));
+        ZKCHK(msm_run(k.g1, sl.wsA, dA, res, sl.s2));
+        if (!raw) ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res, 1, out, sl.s2));
+        HIPCHK(hipEventRecord(sl.join2, sl.s2));
+        HIPCHK(hipStreamWaitEvent(sl.s0, sl.join1, 0));
+        HIPCHK(hipStreamWaitEvent(sl.s0, sl.join2, 0));
+    }
     if (!raw) HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 384, hipMemcpyDeviceToHost, sl.s0));
     return ZK_OK;
 }

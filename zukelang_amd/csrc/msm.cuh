@@ -42,6 +42,10 @@ int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine,
 int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b);
 // d_scalars: n canonical (non-Montgomery) Fr, 32 B each, on device.  d_result: one XYZZ point.
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_result_xyzz, hipStream_t s);
+// the same in two halves: sort + bucket accumulation per MSM, then ONE chain of reduction launches for up to 8 MSMs
+// over the same bases (their workspaces share bucket count and chunk length); outs[i]: one dense XYZZ point each
+int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, hipStream_t s);
+int msm_reduce(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s);
 // step 4 of msm_run (msm_acc_g1.hip / msm_acc_g2.hip)
 int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, const uint32_t* offsets, const uint32_t* sorted, uint32_t nb,
                           uint32_t chunk, void* buckets, void* head, void* tail, hipStream_t s);
@@ -49,6 +53,8 @@ int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, con
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s);
 // same, asynchronous: device XYZZ -> device bytes (no allocation, no synchronization)
 int points_xyzz_to_bytes_dev(Curve curve, const void* d_xyzz, uint64_t count, void* d_bytes, hipStream_t s);
+// the A, C (G1) and B (G2) points of a Groth16 proof, XYZZ -> uncompressed bytes, in one launch
+int proof_points_to_bytes_dev(const void* d_g1a, void* out_a, const void* d_g1c, void* out_c, const void* d_g2b, void* out_b, hipStream_t s);
 // bytes (device copy of host encoding) -> affine Montgomery; *d_flag |= 1 not on curve, |= 2 bad encoding
 int points_bytes_to_affine(Curve curve, void* d_affine, const void* d_bytes, uint64_t n, int* d_flag, hipStream_t s);
 int points_affine_to_bytes(Curve curve, void* d_bytes, const void* d_affine, uint64_t n, hipStream_t s);

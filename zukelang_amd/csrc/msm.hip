@@ -108,6 +108,14 @@ template <class F> __global__ void k_xyzz_to_bytes(uint8_t* dst, const uint8_t* 
     aff_encode(dst + B * i, xyzz_to_aff(xyzz_load<F>(src + 2 * B * i)));
 }
 
+// The three points of a Groth16 proof in ONE launch (three single-lane conversions, each with its own inversion,
+// side by side instead of one after the other): block 0, 1: G1 points, block 2: the G2 point.
+__global__ __launch_bounds__(64) void k_proof_to_bytes(const uint8_t* g1a, uint8_t* out_a, const uint8_t* g1c, uint8_t* out_c, const uint8_t* g2b, uint8_t* out_b) {
+    if (threadIdx.x != 0) return;
+    if (blockIdx.x == 2) aff_encode(out_b, xyzz_to_aff(xyzz_load<Fp2>(g2b)));
+    else aff_encode(blockIdx.x ? out_c : out_a, xyzz_to_aff(xyzz_load<Fp>(blockIdx.x ? g1c : g1a)));
+}
+
 // ------------------------------------------------------------------ precomputation: table[j*n + i] = 2^(c*j) * P_i
 template <class F> __global__ void k_precompute(uint8_t* table, uint64_t n, uint32_t c, uint32_t nw) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,12 +303,33 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
 // point: half the registers and two instead of three dependent base-field products per Fp2 product --
 // these kernels are chains of dependent additions run by a few waves, so latency is what they cost).
 template <class T> struct Lanes { static constexpr uint32_t N = RawLayout<T>::LANES; };
+// The reduction kernels serve several MSMs of one proof in ONE launch (blockIdx.z = job): the MSMs share the base
+// set (hence bucket count, chunk length, window plan) and differ in the scalars, so their reductions are the same
+// launch geometry on different buffers -- one latency-bound chain per proof and curve instead of one per MSM.
+static constexpr uint32_t MAX_TAIL_JOBS = 8;
+struct TailJob {
+    const uint32_t* offsets;
+    uint8_t* buckets;
+    const uint8_t* head;
+    const uint8_t* tail;
+    uint32_t* worklist;
+    uint8_t* red;
+    uint8_t* wsum;
+    uint8_t* out;
+};
+struct TailJobs {
+    TailJob j[MAX_TAIL_JOBS];
+};
 static constexpr uint32_t FIXUP_SERIAL_MAX = 16;
 template <class T>
-__global__ __launch_bounds__(128) void k_msm_fixup(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t chunk,
-                                                   uint8_t* __restrict__ buckets, const uint8_t* __restrict__ head,
-                                                   const uint8_t* __restrict__ tail, uint32_t* __restrict__ worklist) {
+__global__ __launch_bounds__(128) void k_msm_fixup(TailJobs jobs, uint32_t nb, uint32_t chunk) {
     constexpr int XB = RawLayout<T>::XYZZ;
+    const TailJob& job = jobs.j[blockIdx.z];
+    const uint32_t* __restrict__ offsets = job.offsets;
+    uint8_t* __restrict__ buckets = job.buckets;
+    const uint8_t* __restrict__ head = job.head;
+    const uint8_t* __restrict__ tail = job.tail;
+    uint32_t* __restrict__ worklist = job.worklist;
     const uint32_t kb = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<T>::N;
     if (kb >= nb) return;
     const uint32_t s = offsets[kb], e = offsets[kb + 1];
@@ -343,10 +372,14 @@ template <class T, int NT, int GROUP = 0> FF_INLINE void block_tree_sum(Xyzz<T>&
     }
 }
 template <class T>
-__global__ __launch_bounds__(256) void k_msm_fixup_big(const uint32_t* __restrict__ offsets, uint32_t chunk,
-                                                       uint8_t* __restrict__ buckets, const uint8_t* __restrict__ head,
-                                                       const uint8_t* __restrict__ tail, const uint32_t* __restrict__ worklist) {
+__global__ __launch_bounds__(256) void k_msm_fixup_big(TailJobs jobs, uint32_t chunk) {
     constexpr int XB = RawLayout<T>::XYZZ;
+    const TailJob& job = jobs.j[blockIdx.z];
+    const uint32_t* __restrict__ offsets = job.offsets;
+    uint8_t* __restrict__ buckets = job.buckets;
+    const uint8_t* __restrict__ head = job.head;
+    const uint8_t* __restrict__ tail = job.tail;
+    const uint32_t* __restrict__ worklist = job.worklist;
     constexpr uint32_t LP = Lanes<T>::N, NP = 256 / LP;
     __shared__ uint32_t lds[LANE_POINT_WORDS][256];
     const uint32_t count = worklist[0];
@@ -384,9 +417,12 @@ struct DigitPlan {
 // as many waves busy for two thirds of that time; with a dozen proofs in flight SIMD time is what counts.)
 static constexpr uint32_t DS_GROUP = 16, DS_PER_WG = 64 / DS_GROUP;
 template <class T>
-__global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(const uint8_t* __restrict__ buckets, const uint32_t* __restrict__ offsets,
-                                                                       DigitPlan p, uint8_t* __restrict__ S) {
+__global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(TailJobs jobs, DigitPlan p) {
     constexpr int XB = RawLayout<T>::XYZZ;
+    const TailJob& job = jobs.j[blockIdx.z];
+    const uint8_t* __restrict__ buckets = job.buckets;
+    const uint32_t* __restrict__ offsets = job.offsets;
+    uint8_t* __restrict__ S = job.red;
     constexpr uint32_t LP = Lanes<T>::N;
     __shared__ uint32_t lds[LANE_POINT_WORDS][64 * LP];
     const uint32_t win = blockIdx.y, pt = threadIdx.x / LP, sub = pt / DS_GROUP, lane = pt % DS_GROUP;
@@ -411,8 +447,10 @@ __global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(const uint8
 }
 // V[win][k] = sum_d d * S[win][k][d]
 template <class T>
-__global__ __launch_bounds__(256 * Lanes<T>::N) void k_msm_digit_weight(const uint8_t* __restrict__ S, DigitPlan p, uint8_t* __restrict__ V) {
+__global__ __launch_bounds__(256 * Lanes<T>::N) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
     constexpr int XB = RawLayout<T>::XYZZ;
+    const uint8_t* __restrict__ S = jobs.j[blockIdx.z].red;
+    uint8_t* __restrict__ V = jobs.j[blockIdx.z].wsum;
     constexpr uint32_t LP = Lanes<T>::N;
     __shared__ uint32_t lds[LANE_POINT_WORDS][256 * LP];
     const uint32_t k = blockIdx.x, win = blockIdx.y, pt = threadIdx.x / LP;
@@ -430,9 +468,11 @@ __global__ __launch_bounds__(256 * Lanes<T>::N) void k_msm_digit_weight(const ui
 }
 // W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one point).
 // The result leaves in the DENSE, fully reduced layout (it is an output of the library).
-template <class T> __global__ __launch_bounds__(64) void k_msm_final(const uint8_t* __restrict__ V, uint32_t nw, uint32_t c, uint32_t lb, uint8_t* __restrict__ out) {
+template <class T> __global__ __launch_bounds__(64) void k_msm_final(TailJobs jobs, uint32_t nw, uint32_t c, uint32_t lb) {
     constexpr int XB = RawLayout<T>::XYZZ;
-    if (blockIdx.x != 0 || threadIdx.x >= Lanes<T>::N) return;
+    if (threadIdx.x >= Lanes<T>::N) return;
+    const uint8_t* __restrict__ V = jobs.j[blockIdx.z].wsum;
+    uint8_t* __restrict__ out = jobs.j[blockIdx.z].out;
     Xyzz<T> acc = xyzz_inf<T>();
     for (uint32_t j = nw; j-- > 0;) {
         if (j != nw - 1)
@@ -573,6 +613,12 @@ int points_xyzz_to_bytes_dev(Curve curve, const void* d_xyzz, uint64_t count, vo
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
+int proof_points_to_bytes_dev(const void* d_g1a, void* out_a, const void* d_g1c, void* out_c, const void* d_g2b, void* out_b, hipStream_t s) {
+    hipLaunchKernelGGL(k_proof_to_bytes, dim3(3), dim3(64), 0, s, (const uint8_t*)d_g1a, (uint8_t*)out_a, (const uint8_t*)d_g1c, (uint8_t*)out_c,
+                       (const uint8_t*)d_g2b, (uint8_t*)out_b);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s) {
     DevBuf tmp;
     ZKCHK(tmp.alloc(aff_bytes(curve) * count));
@@ -639,10 +685,10 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     return ZK_OK;
 }
 
-// F: the curve's coordinate field; T: how the reduction kernels hold a point (Fp, or Fp2H lane pairs for G2)
-template <class F, class T> static int msm_run_t(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
+// Steps 1-4 of one MSM: digits, counting sort, bucket accumulation (leaves raw bucket sums and chunk partials in w).
+int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, hipStream_t s) {
+    if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.cap_points < b.n) ZK_FAIL(ZK_ERR_ARG, "msm: workspace does not match bases");
     const uint32_t nbw = 1u << (b.c - 1);
-    const uint32_t nwin = b.precomp ? 1 : b.nw;
     DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
@@ -678,26 +724,45 @@ template <class F, class T> static int msm_run_t(const MsmBases& b, MsmWorkspace
         ZKCHK(msm_accumulate_launch(b.curve, w.nthreads, b.table.p, w.offsets.as<uint32_t>(), w.sorted.as<uint32_t>(), w.nbuckets, w.chunk,
                                     w.buckets.p, w.head.p, w.tail.p, s));
     }
-    {
-        ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
-        constexpr uint32_t LP = Lanes<T>::N;
-        HIPCHK(hipMemsetAsync(w.worklist.p, 0, 4, s));
-        hipLaunchKernelGGL(k_msm_fixup<T>, grid_for((uint64_t)w.nbuckets * LP, 128), dim3(128), 0, s, w.offsets.as<uint32_t>(), w.nbuckets, w.chunk,
-                           w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), w.worklist.as<uint32_t>());
-        hipLaunchKernelGGL(k_msm_fixup_big<T>, dim3(w.nbuckets < 256 ? w.nbuckets : 256), dim3(256), 0, s, w.offsets.as<uint32_t>(), w.chunk,
-                           w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), (const uint32_t*)w.worklist.as<uint32_t>());
-        const DigitPlan dp = digit_plan(b.c);
-        hipLaunchKernelGGL(k_msm_digit_sums<T>, dim3((dp.nd0 + dp.nd1 + DS_PER_WG - 1) / DS_PER_WG, nwin), dim3(64 * LP), 0, s, w.buckets.as<uint8_t>(), (const uint32_t*)w.offsets.as<uint32_t>(), dp,
-                           w.red.as<uint8_t>());
-        hipLaunchKernelGGL(k_msm_digit_weight<T>, dim3(2, nwin), dim3(256 * LP), 0, s, w.red.as<uint8_t>(), dp, w.wsum.as<uint8_t>());
-        hipLaunchKernelGGL(k_msm_final<T>, dim3(1), dim3(64), 0, s, w.wsum.as<uint8_t>(), nwin, b.c, dp.lb, (uint8_t*)d_out);
-    }
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
+// Steps 5-7 for `count` MSMs over the SAME bases in one chain of launches (T: how the kernels hold a point: Fp, or
+// Fp2H lane pairs for G2).  outs[i]: one dense XYZZ point each.
+template <class T> static int msm_reduce_t(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s) {
+    constexpr uint32_t LP = Lanes<T>::N;
+    const uint32_t nwin = b.precomp ? 1 : b.nw;
+    TailJobs jobs{};
+    for (uint32_t i = 0; i < count; i++) {
+        MsmWorkspace& w = *ws[i];
+        if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.nbuckets != ws[0]->nbuckets || w.chunk != ws[0]->chunk)
+            ZK_FAIL(ZK_ERR_ARG, "msm_reduce: workspaces of one batch must share the bases");
+        jobs.j[i] = TailJob{w.offsets.as<uint32_t>(), w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), w.worklist.as<uint32_t>(),
+                            w.red.as<uint8_t>(), w.wsum.as<uint8_t>(), (uint8_t*)outs[i]};
+        HIPCHK(hipMemsetAsync(w.worklist.p, 0, 4, s));
+    }
+    const uint32_t nb = ws[0]->nbuckets, chunk = ws[0]->chunk;
+    ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
+    dim3 gf = grid_for((uint64_t)nb * LP, 128);
+    gf.z = count;
+    hipLaunchKernelGGL(k_msm_fixup<T>, gf, dim3(128), 0, s, jobs, nb, chunk);
+    hipLaunchKernelGGL(k_msm_fixup_big<T>, dim3(nb < 256 ? nb : 256, 1, count), dim3(256), 0, s, jobs, chunk);
+    const DigitPlan dp = digit_plan(b.c);
+    hipLaunchKernelGGL(k_msm_digit_sums<T>, dim3((dp.nd0 + dp.nd1 + DS_PER_WG - 1) / DS_PER_WG, nwin, count), dim3(64 * LP), 0, s, jobs, dp);
+    hipLaunchKernelGGL(k_msm_digit_weight<T>, dim3(2, nwin, count), dim3(256 * LP), 0, s, jobs, dp);
+    hipLaunchKernelGGL(k_msm_final<T>, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int msm_reduce(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s) {
+    if (count == 0 || count > MAX_TAIL_JOBS) ZK_FAIL(ZK_ERR_ARG, "msm_reduce: 1..8 MSMs per batch");
+    return b.curve == CURVE_G1 ? msm_reduce_t<Fp>(b, ws, outs, count, s) : msm_reduce_t<Fp2H>(b, ws, outs, count, s);
+}
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
-    if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.cap_points < b.n) ZK_FAIL(ZK_ERR_ARG, "msm: workspace does not match bases");
-    return b.curve == CURVE_G1 ? msm_run_t<Fp, Fp>(b, w, d_scalars, d_out, s) : msm_run_t<Fp2, Fp2H>(b, w, d_scalars, d_out, s);
+    ZKCHK(msm_sort_accumulate(b, w, d_scalars, s));
+    MsmWorkspace* ws[1] = {&w};
+    void* outs[1] = {d_out};
+    return msm_reduce(b, ws, outs, 1, s);
 }
 int xyzz_sum_columns(Curve curve, void* d_out, const void* d_parts, uint32_t count, uint32_t npoints, hipStream_t s) {
     if (curve == CURVE_G1) hipLaunchKernelGGL(k_xyzz_sum_columns<Fp>, grid_for(npoints, 64), dim3(64), 0, s, (uint8_t*)d_out, (const uint8_t*)d_parts, count, npoints);
