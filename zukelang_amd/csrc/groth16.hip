@@ -237,7 +237,10 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
         MsmWorkspace* ws[2] = {&sl.wsA, &sl.wsC};
         void* outs[2] = {res, res + g1b};
         ZKCHK(msm_reduce(k.g1, ws, outs, 2, sl.s0));
-        if (!raw) ZKCHK(proof_points_to_bytes_dev(res, out, res + g1b, out + 288, res + 2 * g1b, out + 96, sl.s0));
+        if (!raw) {
+            const uint32_t o1[2] = {0, 288}, o2[1] = {96};          // results: A | C | B;  proof: a | b | c
+            ZKCHK(proof_points_to_bytes_dev(res, 2, o1, res + 2 * g1b, 1, o2, out, sl.s0));
+        }
     } else {
         // B (G2, the longest chain) first
         ZKCHK(msm_run(k.g2, sl.wsB, dB, res + 2 * g1b, sl.s1));

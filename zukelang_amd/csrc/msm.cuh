@@ -53,8 +53,8 @@ int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, con
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s);
 // same, asynchronous: device XYZZ -> device bytes (no allocation, no synchronization)
 int points_xyzz_to_bytes_dev(Curve curve, const void* d_xyzz, uint64_t count, void* d_bytes, hipStream_t s);
-// the A, C (G1) and B (G2) points of a Groth16 proof, XYZZ -> uncompressed bytes, in one launch
-int proof_points_to_bytes_dev(const void* d_g1a, void* out_a, const void* d_g1c, void* out_c, const void* d_g2b, void* out_b, hipStream_t s);
+// the points of a proof (n1 <= 8 dense XYZZ in G1, n2 <= 4 in G2) -> uncompressed bytes at d_out + off[i], in one launch
+int proof_points_to_bytes_dev(const void* d_g1, uint32_t n1, const uint32_t* off1, const void* d_g2, uint32_t n2, const uint32_t* off2, void* d_out, hipStream_t s);
 // bytes (device copy of host encoding) -> affine Montgomery; *d_flag |= 1 not on curve, |= 2 bad encoding
 int points_bytes_to_affine(Curve curve, void* d_affine, const void* d_bytes, uint64_t n, int* d_flag, hipStream_t s);
 int points_affine_to_bytes(Curve curve, void* d_bytes, const void* d_affine, uint64_t n, hipStream_t s);

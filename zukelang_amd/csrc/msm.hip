@@ -108,12 +108,16 @@ template <class F> __global__ void k_xyzz_to_bytes(uint8_t* dst, const uint8_t* 
     aff_encode(dst + B * i, xyzz_to_aff(xyzz_load<F>(src + 2 * B * i)));
 }
 
-// The three points of a Groth16 proof in ONE launch (three single-lane conversions, each with its own inversion,
-// side by side instead of one after the other): block 0, 1: G1 points, block 2: the G2 point.
-__global__ __launch_bounds__(64) void k_proof_to_bytes(const uint8_t* g1a, uint8_t* out_a, const uint8_t* g1c, uint8_t* out_c, const uint8_t* g2b, uint8_t* out_b) {
+// All points of a proof in ONE launch (single-lane conversions, each with its own inversion, side by side instead of
+// one after the other): blocks [0, n1) take the G1 points g1[i] -> out + off.g1[i], blocks [n1, n1 + n2) the G2 points.
+struct ProofOffsets {
+    uint32_t g1[8], g2[4];
+};
+__global__ __launch_bounds__(64) void k_proof_to_bytes(const uint8_t* g1, uint32_t n1, const uint8_t* g2, ProofOffsets off, uint8_t* out) {
     if (threadIdx.x != 0) return;
-    if (blockIdx.x == 2) aff_encode(out_b, xyzz_to_aff(xyzz_load<Fp2>(g2b)));
-    else aff_encode(blockIdx.x ? out_c : out_a, xyzz_to_aff(xyzz_load<Fp>(blockIdx.x ? g1c : g1a)));
+    const uint32_t b = blockIdx.x;
+    if (b < n1) aff_encode(out + off.g1[b], xyzz_to_aff(xyzz_load<Fp>(g1 + 192 * (size_t)b)));
+    else aff_encode(out + off.g2[b - n1], xyzz_to_aff(xyzz_load<Fp2>(g2 + 384 * (size_t)(b - n1))));
 }
 
 // ------------------------------------------------------------------ precomputation: table[j*n + i] = 2^(c*j) * P_i
@@ -613,9 +617,12 @@ int points_xyzz_to_bytes_dev(Curve curve, const void* d_xyzz, uint64_t count, vo
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
-int proof_points_to_bytes_dev(const void* d_g1a, void* out_a, const void* d_g1c, void* out_c, const void* d_g2b, void* out_b, hipStream_t s) {
-    hipLaunchKernelGGL(k_proof_to_bytes, dim3(3), dim3(64), 0, s, (const uint8_t*)d_g1a, (uint8_t*)out_a, (const uint8_t*)d_g1c, (uint8_t*)out_c,
-                       (const uint8_t*)d_g2b, (uint8_t*)out_b);
+int proof_points_to_bytes_dev(const void* d_g1, uint32_t n1, const uint32_t* off1, const void* d_g2, uint32_t n2, const uint32_t* off2, void* d_out, hipStream_t s) {
+    if (n1 > 8 || n2 > 4) ZK_FAIL(ZK_ERR_ARG, "proof_points_to_bytes_dev: at most 8 G1 and 4 G2 points");
+    ProofOffsets off{};
+    for (uint32_t i = 0; i < n1; i++) off.g1[i] = off1[i];
+    for (uint32_t i = 0; i < n2; i++) off.g2[i] = off2[i];
+    hipLaunchKernelGGL(k_proof_to_bytes, dim3(n1 + n2), dim3(64), 0, s, (const uint8_t*)d_g1, n1, (const uint8_t*)d_g2, off, (uint8_t*)d_out);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }

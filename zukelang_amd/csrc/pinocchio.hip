@@ -241,13 +241,32 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     // proof byte offsets: vv 0 | ww 96 | yy 288 | h 384 | vavv 480 | waww 576 | yayy 768 | bvwy 864
     const size_t off1[PIN_G1] = {0, 288, 480, 768, 864, 384};
     const size_t off2[PIN_G2] = {96, 576};
-    for (int i = 0; i < PIN_G2; i++) {
-        ZKCHK(msm_run(k.g2[i], sl.ws2[i], sl.scal2[i].p, res + PIN_G1 * x1 + i * x2, s0));
-        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, res + PIN_G1 * x1 + i * x2, 1, out + off2[i], s0));
-    }
-    for (int i = 0; i < PIN_G1; i++) {
-        ZKCHK(msm_run(k.g1[i], sl.ws1[i], sl.scal1[i].p, res + i * x1, s0));
-        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res + i * x1, 1, out + off1[i], s0));
+    // sort + bucket accumulation per MSM; the reductions of MSMs whose workspaces have the same geometry (equal pool
+    // sizes: the five pools over I_mid, the two G2 pools) go out as ONE chain of launches each
+    for (int i = 0; i < PIN_G2; i++) ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], sl.scal2[i].p, s0));
+    for (int i = 0; i < PIN_G1; i++) ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], sl.scal1[i].p, s0));
+    auto reduce_groups = [&](MsmBases* bases, MsmWorkspace* wss, int n, char* res_base, size_t stride) -> int {
+        bool done[8] = {false, false, false, false, false, false, false, false};
+        for (int i = 0; i < n; i++) {
+            if (done[i]) continue;
+            MsmWorkspace* ws[8];
+            void* outs[8];
+            uint32_t cnt = 0;
+            for (int j = i; j < n; j++)
+                if (!done[j] && wss[j].c == wss[i].c && wss[j].nw == wss[i].nw && wss[j].nbuckets == wss[i].nbuckets && wss[j].chunk == wss[i].chunk) {
+                    ws[cnt] = &wss[j]; outs[cnt] = res_base + stride * j; cnt++; done[j] = true;
+                }
+            ZKCHK(msm_reduce(bases[i], ws, outs, cnt, s0));
+        }
+        return ZK_OK;
+    };
+    ZKCHK(reduce_groups(k.g2, sl.ws2, PIN_G2, res + PIN_G1 * x1, x2));
+    ZKCHK(reduce_groups(k.g1, sl.ws1, PIN_G1, res, x1));
+    {
+        uint32_t o1[PIN_G1], o2[PIN_G2];
+        for (int i = 0; i < PIN_G1; i++) o1[i] = (uint32_t)off1[i];
+        for (int i = 0; i < PIN_G2; i++) o2[i] = (uint32_t)off2[i];
+        ZKCHK(proof_points_to_bytes_dev(res, PIN_G1, o1, res + PIN_G1 * x1, PIN_G2, o2, out, s0));      // eight conversions, one launch
     }
     HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 960, hipMemcpyDeviceToHost, s0));
     HIPCHK(hipMemcpyAsync(sl.host + 960, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, s0));
