@@ -232,10 +232,10 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
     if (sl.serial) {
         // one stream: sort + accumulate per MSM, then the reductions of A and C (same bases) as ONE chain of launches
         ZKCHK(msm_run(k.g2, sl.wsB, dB, res + 2 * g1b, sl.s0));
-        ZKCHK(msm_sort_accumulate(k.g1, sl.wsC, dC, sl.s0));
-        ZKCHK(msm_sort_accumulate(k.g1, sl.wsA, dA, sl.s0));
         MsmWorkspace* ws[2] = {&sl.wsA, &sl.wsC};
+        const void* scal[2] = {dA, dC};
         void* outs[2] = {res, res + g1b};
+        ZKCHK(msm_sort_accumulate_many(k.g1, ws, scal, 2, sl.s0));
         ZKCHK(msm_reduce(k.g1, ws, outs, 2, sl.s0));
         if (!raw) {
             const uint32_t o1[2] = {0, 288}, o2[1] = {96};          // results: A | C | B;  proof: a | b | c

@@ -45,10 +45,19 @@ int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_r
 // the same in two halves: sort + bucket accumulation per MSM, then ONE chain of reduction launches for up to 8 MSMs
 // over the same bases (their workspaces share bucket count and chunk length); outs[i]: one dense XYZZ point each
 int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, hipStream_t s);
+// ... and for up to 4 MSMs over the same bases (different scalar vectors) as one chain of launches
+int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const void* const* d_scalars, uint32_t count, hipStream_t s);
 int msm_reduce(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s);
-// step 4 of msm_run (msm_acc_g1.hip / msm_acc_g2.hip)
-int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, const uint32_t* offsets, const uint32_t* sorted, uint32_t nb,
-                          uint32_t chunk, void* buckets, void* head, void* tail, hipStream_t s);
+// step 4 of msm_run (msm_acc_g1.hip / msm_acc_g2.hip) for up to 4 MSMs over the same table in one launch (blockIdx.y = job)
+static constexpr uint32_t MAX_ACC_JOBS = 4;
+struct AccJobs {
+    const uint32_t* offsets[MAX_ACC_JOBS];
+    const uint32_t* sorted[MAX_ACC_JOBS];
+    uint8_t* buckets[MAX_ACC_JOBS];
+    uint8_t* head[MAX_ACC_JOBS];
+    uint8_t* tail[MAX_ACC_JOBS];
+};
+int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s);
 // XYZZ (device) -> uncompressed bytes (host); count points
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s);
 // same, asynchronous: device XYZZ -> device bytes (no allocation, no synchronization)

@@ -201,14 +201,29 @@ template <class Counter> FF_INLINE uint32_t wave_aggregated_add(Counter* __restr
     if (ok) pos = atomicAdd(&ctr[key], 1u);
     return pos;
 }
-__global__ void k_msm_count(const uint32_t* __restrict__ scalars, DigitArgs a, uint32_t* __restrict__ counts) {
+// The sort kernels serve up to 4 MSMs over the same bases in one launch (blockIdx.y = job): same digit geometry,
+// different scalar vectors and buffers.
+static constexpr uint32_t MAX_SORT_JOBS = 4;
+struct SortJobs {
+    const uint32_t* scalars[MAX_SORT_JOBS];
+    uint32_t* counts[MAX_SORT_JOBS];
+    uint32_t* offsets[MAX_SORT_JOBS];
+    uint32_t* cursor[MAX_SORT_JOBS];
+    uint32_t* sorted[MAX_SORT_JOBS];
+    uint32_t* wgcount[MAX_SORT_JOBS];
+};
+__global__ void k_msm_count(SortJobs jobs, DigitArgs a) {
+    const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
+    uint32_t* __restrict__ counts = jobs.counts[blockIdx.y];
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // no early return: the ballots need whole waves
     uint32_t key = 0, val = 0;
     const bool ok = g < a.n * a.nw && digit_of(scalars, g % a.n, (uint32_t)(g / a.n), a, key, val);
     (void)wave_aggregated_add(counts, ok, key);
 }
-__global__ void k_msm_scatter(const uint32_t* __restrict__ scalars, DigitArgs a, uint32_t* __restrict__ cursor,
-                              uint32_t* __restrict__ sorted) {
+__global__ void k_msm_scatter(SortJobs jobs, DigitArgs a) {
+    const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
+    uint32_t* __restrict__ cursor = jobs.cursor[blockIdx.y];
+    uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t key = 0, val = 0;
     const bool ok = g < a.n * a.nw && digit_of(scalars, g % a.n, (uint32_t)(g / a.n), a, key, val);
@@ -224,8 +239,9 @@ __global__ void k_msm_scatter(const uint32_t* __restrict__ scalars, DigitArgs a,
 // fall out of the same scan.
 static constexpr uint32_t SORT_THREADS = 1024;
 static constexpr uint32_t SORT_MAX_BUCKETS = 32768;
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(const uint32_t* __restrict__ scalars, DigitArgs a, uint64_t per_wg,
-                                                                uint32_t nb, uint32_t* __restrict__ wgcount) {
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(SortJobs jobs, DigitArgs a, uint64_t per_wg, uint32_t nb) {
+    const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
+    uint32_t* __restrict__ wgcount = jobs.wgcount[blockIdx.y];
     __shared__ uint32_t hist[SORT_MAX_BUCKETS];
     const uint32_t wg = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) hist[b] = 0;
@@ -239,9 +255,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(const uint32_t*
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) wgcount[(uint64_t)wg * nb + b] = hist[b];   // [workgroup][bucket]: coalesced
 }
-__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(const uint32_t* __restrict__ scalars, DigitArgs a, uint64_t per_wg,
-                                                                  uint32_t nb, const uint32_t* __restrict__ base,
-                                                                  const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(SortJobs jobs, DigitArgs a, uint64_t per_wg, uint32_t nb) {
+    const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
+    const uint32_t* __restrict__ base = jobs.wgcount[blockIdx.y];
+    const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
+    uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
     __shared__ uint32_t cur[SORT_MAX_BUCKETS];
     const uint32_t wg = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cur[b] = offsets[b] + base[(uint64_t)wg * nb + b];
@@ -257,7 +275,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(const uint32_
 // Column scan of the [workgroup][bucket] count matrix: one lane per bucket walks down the workgroups
 // (row-coalesced), turning counts into each workgroup's exclusive rank inside the bucket and leaving
 // the bucket totals, which the single-workgroup k_scan below turns into bucket offsets.
-__global__ void k_sort_colscan(uint32_t* __restrict__ cnt, uint32_t nb, uint32_t nwg, uint32_t* __restrict__ totals) {
+__global__ void k_sort_colscan(SortJobs jobs, uint32_t nb, uint32_t nwg) {
+    uint32_t* __restrict__ cnt = jobs.wgcount[blockIdx.y];
+    uint32_t* __restrict__ totals = jobs.counts[blockIdx.y];
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t run = 0;
@@ -270,8 +290,10 @@ __global__ void k_sort_colscan(uint32_t* __restrict__ cnt, uint32_t nb, uint32_t
 }
 
 // single workgroup: offsets[k] = sum_{q<k} counts[q], offsets[nb] = total; cursor = offsets
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                               uint32_t* __restrict__ cursor, uint32_t nb) {
+__global__ __launch_bounds__(1024) void k_scan(SortJobs jobs, uint32_t nb) {
+    const uint32_t* __restrict__ counts = jobs.counts[blockIdx.x];
+    uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.x];
+    uint32_t* __restrict__ cursor = jobs.cursor[blockIdx.x];
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
     const uint32_t per = (nb + 1023) / 1024;
@@ -692,17 +714,32 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
     return ZK_OK;
 }
 
-// Steps 1-4 of one MSM: digits, counting sort, bucket accumulation (leaves raw bucket sums and chunk partials in w).
-int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, hipStream_t s) {
-    if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.cap_points < b.n) ZK_FAIL(ZK_ERR_ARG, "msm: workspace does not match bases");
+// Steps 1-4 for `count` MSMs over the same bases: digits, counting sort, bucket accumulation (leaves raw bucket sums and
+// chunk partials in the workspaces).  One chain of launches for all of them.
+int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const void* const* d_scalars, uint32_t count, hipStream_t s) {
+    if (count == 0 || count > MAX_SORT_JOBS) ZK_FAIL(ZK_ERR_ARG, "msm_sort_accumulate_many: 1..4 MSMs per batch");
+    SortJobs sj{};
+    AccJobs aj{};
+    for (uint32_t i = 0; i < count; i++) {
+        MsmWorkspace& w = *ws[i];
+        if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.cap_points < b.n || w.nbuckets != ws[0]->nbuckets || w.chunk != ws[0]->chunk ||
+            w.sort_wgs != ws[0]->sort_wgs)
+            ZK_FAIL(ZK_ERR_ARG, "msm: workspace does not match bases");
+        sj.scalars[i] = (const uint32_t*)d_scalars[i];
+        sj.counts[i] = w.counts.as<uint32_t>(); sj.offsets[i] = w.offsets.as<uint32_t>(); sj.cursor[i] = w.cursor.as<uint32_t>();
+        sj.sorted[i] = w.sorted.as<uint32_t>(); sj.wgcount[i] = w.wgcount.as<uint32_t>();
+        aj.offsets[i] = w.offsets.as<uint32_t>(); aj.sorted[i] = w.sorted.as<uint32_t>();
+        aj.buckets[i] = w.buckets.as<uint8_t>(); aj.head[i] = w.head.as<uint8_t>(); aj.tail[i] = w.tail.as<uint8_t>();
+    }
+    MsmWorkspace& w = *ws[0];
     const uint32_t nbw = 1u << (b.c - 1);
     DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
-        uint32_t off = j * b.c, w = off >> 5, sh = off & 31;
+        uint32_t off = j * b.c, wd = off >> 5, sh = off & 31;
         unsigned __int128 add = (unsigned __int128)v << sh;
         uint64_t cy = 0;
-        for (uint32_t k = w; k < 9; k++) {
+        for (uint32_t k = wd; k < 9; k++) {
             cy += (uint64_t)da.K[k] + (uint32_t)(add & 0xffffffffu);
             da.K[k] = (uint32_t)cy;
             cy >>= 32;
@@ -714,25 +751,32 @@ int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalar
         ScopedTimer t("msm_sort", s);
         if (w.sort_wgs) {
             const uint64_t total = b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
-            hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs), dim3(SORT_THREADS), 0, s, (const uint32_t*)d_scalars, da, per_wg, w.nbuckets, w.wgcount.as<uint32_t>());
-            hipLaunchKernelGGL(k_sort_colscan, grid_for(w.nbuckets, 256), dim3(256), 0, s, w.wgcount.as<uint32_t>(), w.nbuckets, w.sort_wgs, w.counts.as<uint32_t>());
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, (const uint32_t*)w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
-            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs), dim3(SORT_THREADS), 0, s, (const uint32_t*)d_scalars, da, per_wg, w.nbuckets, (const uint32_t*)w.wgcount.as<uint32_t>(),
-                               (const uint32_t*)w.offsets.as<uint32_t>(), w.sorted.as<uint32_t>());
+            hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
+            dim3 gc = grid_for(w.nbuckets, 256);
+            gc.y = count;
+            hipLaunchKernelGGL(k_sort_colscan, gc, dim3(256), 0, s, sj, w.nbuckets, w.sort_wgs);
+            hipLaunchKernelGGL(k_scan, dim3(count), dim3(1024), 0, s, sj, w.nbuckets);
+            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
         } else {
-            HIPCHK(hipMemsetAsync(w.counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
-            hipLaunchKernelGGL(k_msm_count, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.counts.as<uint32_t>());
-            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, w.counts.as<uint32_t>(), w.offsets.as<uint32_t>(), w.cursor.as<uint32_t>(), w.nbuckets);
-            hipLaunchKernelGGL(k_msm_scatter, grid_for(b.n * b.nw, 256), dim3(256), 0, s, (const uint32_t*)d_scalars, da, w.cursor.as<uint32_t>(), w.sorted.as<uint32_t>());
+            for (uint32_t i = 0; i < count; i++) HIPCHK(hipMemsetAsync(ws[i]->counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
+            dim3 g = grid_for(b.n * b.nw, 256);
+            g.y = count;
+            hipLaunchKernelGGL(k_msm_count, g, dim3(256), 0, s, sj, da);
+            hipLaunchKernelGGL(k_scan, dim3(count), dim3(1024), 0, s, sj, w.nbuckets);
+            hipLaunchKernelGGL(k_msm_scatter, g, dim3(256), 0, s, sj, da);
         }
     }
     {
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2", s, 1);
-        ZKCHK(msm_accumulate_launch(b.curve, w.nthreads, b.table.p, w.offsets.as<uint32_t>(), w.sorted.as<uint32_t>(), w.nbuckets, w.chunk,
-                                    w.buckets.p, w.head.p, w.tail.p, s));
+        ZKCHK(msm_accumulate_launch(b.curve, w.nthreads, b.table.p, aj, count, w.nbuckets, w.chunk, s));
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
+}
+int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, hipStream_t s) {
+    MsmWorkspace* ws[1] = {&w};
+    const void* sc[1] = {d_scalars};
+    return msm_sort_accumulate_many(b, ws, sc, 1, s);
 }
 // Steps 5-7 for `count` MSMs over the SAME bases in one chain of launches (T: how the kernels hold a point: Fp, or
 // Fp2H lane pairs for G2).  outs[i]: one dense XYZZ point each.

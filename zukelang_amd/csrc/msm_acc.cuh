@@ -35,10 +35,12 @@ template <class F> FF_INLINE Aff<F> packed_aff_unpack(const PackedAff<F>& a, boo
 }
 
 template <class F>
-__global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __restrict__ table, const uint32_t* __restrict__ offsets,
-                                                           const uint32_t* __restrict__ sorted, uint32_t nb, uint32_t chunk,
-                                                           uint8_t* __restrict__ buckets, uint8_t* __restrict__ head,
-                                                           uint8_t* __restrict__ tail) {
+__global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __restrict__ table, AccJobs jobs, uint32_t nb, uint32_t chunk) {
+    const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
+    const uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
+    uint8_t* __restrict__ buckets = jobs.buckets[blockIdx.y];
+    uint8_t* __restrict__ head = jobs.head[blockIdx.y];
+    uint8_t* __restrict__ tail = jobs.tail[blockIdx.y];
     constexpr int AB = FieldOps<F>::WORDS * 8, XB = RawLayout<F>::XYZZ;       // table: dense; sums: raw layout
     constexpr bool PAIR = std::is_same<F, Fp2H>::value;      // G2: two lanes per chunk, one Fp2 component each
     const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);

@@ -6,10 +6,8 @@
 #include "msm_acc.cuh"
 
 namespace zk {
-int msm_accumulate_launch_g1(uint64_t nthreads, const void* table, const uint32_t* offsets, const uint32_t* sorted, uint32_t nb, uint32_t chunk,
-                             void* buckets, void* head, void* tail, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_accumulate<Fp>, dim3((unsigned)((nthreads + 127) / 128)), dim3(128), 0, s, (const uint8_t*)table, offsets, sorted, nb, chunk,
-                       (uint8_t*)buckets, (uint8_t*)head, (uint8_t*)tail);
+int msm_accumulate_launch_g1(uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s) {
+    hipLaunchKernelGGL(k_msm_accumulate<Fp>, dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
