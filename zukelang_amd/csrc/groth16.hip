@@ -230,13 +230,20 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
     HIPCHK(hipStreamWaitEvent(sl.s1, sl.fork, 0));
     HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
     if (sl.serial) {
-        // one stream: sort + accumulate per MSM, then the reductions of A and C (same bases) as ONE chain of launches
-        ZKCHK(msm_run(k.g2, sl.wsB, dB, res + 2 * g1b, sl.s0));
+        // one stream: sort + accumulate (A and C together: same bases), then ALL reductions as one chain of launches
+        ZKCHK(msm_sort_accumulate(k.g2, sl.wsB, dB, sl.s0));
         MsmWorkspace* ws[2] = {&sl.wsA, &sl.wsC};
         const void* scal[2] = {dA, dC};
         void* outs[2] = {res, res + g1b};
         ZKCHK(msm_sort_accumulate_many(k.g1, ws, scal, 2, sl.s0));
-        ZKCHK(msm_reduce(k.g1, ws, outs, 2, sl.s0));
+        MsmWorkspace* ws2[1] = {&sl.wsB};
+        void* outs2[1] = {res + 2 * g1b};
+        if (k.g1.c == k.g2.c && k.g1.nw == k.g2.nw) {
+            ZKCHK(msm_reduce_mixed(&k.g1, ws, outs, 2, &k.g2, ws2, outs2, 1, sl.s0));      // all three reductions: one chain of launches
+        } else {                                                                            // tiny keys: the pools got different windows
+            ZKCHK(msm_reduce(k.g2, ws2, outs2, 1, sl.s0));
+            ZKCHK(msm_reduce(k.g1, ws, outs, 2, sl.s0));
+        }
         if (!raw) {
             const uint32_t o1[2] = {0, 288}, o2[1] = {96};          // results: A | C | B;  proof: a | b | c
             ZKCHK(proof_points_to_bytes_dev(res, 2, o1, res + 2 * g1b, 1, o2, out, sl.s0));

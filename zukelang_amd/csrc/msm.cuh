@@ -48,6 +48,9 @@ int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalar
 // ... and for up to 4 MSMs over the same bases (different scalar vectors) as one chain of launches
 int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const void* const* d_scalars, uint32_t count, hipStream_t s);
 int msm_reduce(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s);
+// the same for n1 products in G1 and n2 in G2 together (one window plan): one chain of launches for both curves
+int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* outs1, uint32_t n1,
+                     const MsmBases* b2, MsmWorkspace* const* ws2, void* const* outs2, uint32_t n2, hipStream_t s);
 // step 4 of msm_run (msm_acc_g1.hip / msm_acc_g2.hip) for up to 4 MSMs over the same table in one launch (blockIdx.y = job)
 static constexpr uint32_t MAX_ACC_JOBS = 4;
 struct AccJobs {

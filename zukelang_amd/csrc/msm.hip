@@ -342,22 +342,25 @@ struct TailJob {
     uint8_t* red;
     uint8_t* wsum;
     uint8_t* out;
+    uint32_t nb, chunk;          // buckets of this MSM, sorted entries per accumulate chunk
 };
+// Jobs [0, n1) are G1 products (T = Fp), jobs [n1, n1 + n2) G2 products (T = Fp2H): ONE launch per step serves both
+// curves, with the launch geometry of the larger one (blocks and lanes a job has no use for leave at once).
 struct TailJobs {
     TailJob j[MAX_TAIL_JOBS];
+    uint32_t n1;
 };
 static constexpr uint32_t FIXUP_SERIAL_MAX = 16;
-template <class T>
-__global__ __launch_bounds__(128) void k_msm_fixup(TailJobs jobs, uint32_t nb, uint32_t chunk) {
+template <class T> FF_INLINE void fixup_body(const TailJob& job) {
     constexpr int XB = RawLayout<T>::XYZZ;
-    const TailJob& job = jobs.j[blockIdx.z];
     const uint32_t* __restrict__ offsets = job.offsets;
     uint8_t* __restrict__ buckets = job.buckets;
     const uint8_t* __restrict__ head = job.head;
     const uint8_t* __restrict__ tail = job.tail;
     uint32_t* __restrict__ worklist = job.worklist;
+    const uint32_t chunk = job.chunk;
     const uint32_t kb = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<T>::N;
-    if (kb >= nb) return;
+    if (kb >= job.nb) return;
     const uint32_t s = offsets[kb], e = offsets[kb + 1];
     if (e == s) return;                                 // empty bucket: nobody reads its slot
     const uint32_t t0 = s / chunk, t1 = (e - 1) / chunk;
@@ -372,6 +375,10 @@ __global__ __launch_bounds__(128) void k_msm_fixup(TailJobs jobs, uint32_t nb, u
         xyzz_add_impl(acc, q);
     }
     xyzz_store_raw<T>(buckets + (uint64_t)XB * kb, acc);
+}
+__global__ __launch_bounds__(128) void k_msm_fixup(TailJobs jobs) {
+    if (blockIdx.z < jobs.n1) fixup_body<Fp>(jobs.j[blockIdx.z]);
+    else fixup_body<Fp2H>(jobs.j[blockIdx.z]);
 }
 // sum of the accumulators of the NT / lanes points of a workgroup, result in point 0
 // (GROUP = points per independent sum, a power of two; 0 = the whole workgroup: result in point 0 of every group)
@@ -397,17 +404,15 @@ template <class T, int NT, int GROUP = 0> FF_INLINE void block_tree_sum(Xyzz<T>&
         }
     }
 }
-template <class T>
-__global__ __launch_bounds__(256) void k_msm_fixup_big(TailJobs jobs, uint32_t chunk) {
+template <class T> FF_INLINE void fixup_big_body(const TailJob& job, uint32_t (*lds)[256]) {
     constexpr int XB = RawLayout<T>::XYZZ;
-    const TailJob& job = jobs.j[blockIdx.z];
     const uint32_t* __restrict__ offsets = job.offsets;
     uint8_t* __restrict__ buckets = job.buckets;
     const uint8_t* __restrict__ head = job.head;
     const uint8_t* __restrict__ tail = job.tail;
     const uint32_t* __restrict__ worklist = job.worklist;
+    const uint32_t chunk = job.chunk;
     constexpr uint32_t LP = Lanes<T>::N, NP = 256 / LP;
-    __shared__ uint32_t lds[LANE_POINT_WORDS][256];
     const uint32_t count = worklist[0];
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {        // block-uniform loop
         const uint32_t kb = worklist[1 + i];
@@ -424,35 +429,39 @@ __global__ __launch_bounds__(256) void k_msm_fixup_big(TailJobs jobs, uint32_t c
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void k_msm_fixup_big(TailJobs jobs) {
+    __shared__ uint32_t lds[LANE_POINT_WORDS][256];
+    if (blockIdx.z < jobs.n1) fixup_big_body<Fp>(jobs.j[blockIdx.z], lds);
+    else fixup_big_body<Fp2H>(jobs.j[blockIdx.z], lds);
+}
 
 // ------------------------------------------------------------------ bucket reduction: R = sum_w w * B_w, w = b + 1
 // A lone wave issues one instruction every ~4 cycles, so a chain of dependent EC additions costs
 // ~15 us per link whatever the chip is doing: the reduction must be SHALLOW, not merely parallel.
 // Write w = hi * 2^lb + lo.  Then R = sum_lo lo * S0[lo] + 2^lb * sum_hi hi * S1[hi] with the digit
 // sums S0[d] = sum of buckets whose low digit is d, S1[d] = those whose high digit is d:
-//   digit_sums    64 points per (digit, value): strided loads + LDS tree         depth ~ 2 + 6
+//   digit_sums    16 points per (digit, value): strided loads + LDS tree         depth ~ 8-16 + 4
 //   digit_weight  d * S[d] by double-and-add (d < 2^lb), LDS tree over d         depth ~ 2 lb + 8
 //   final         2^lb * V1 + V0 (and Horner over windows in classic mode)        depth ~ lb + 1
-// ~40 links instead of the ~100+ of per-lane running sums, and 2x the bucket reads (cheap).
+// ~45 links instead of the ~100+ of per-lane running sums, and 2x the bucket reads (cheap).
 // Empty buckets are recognised from the sort's offsets, so the bucket array is never cleared.
 struct DigitPlan {
     uint32_t nbw, lb, nd0, nd1;
 };
-// 16 points per digit value, four values per 64-point workgroup: every lane sums cnt/16 buckets serially, then a
-// 4-level tree.  (One value per workgroup -- 2-4 buckets per lane, 6 levels -- finishes sooner but keeps four times
-// as many waves busy for two thirds of that time; with a dozen proofs in flight SIMD time is what counts.)
-static constexpr uint32_t DS_GROUP = 16, DS_PER_WG = 64 / DS_GROUP;
-template <class T>
-__global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(TailJobs jobs, DigitPlan p) {
+// 16 points per digit value: every lane sums cnt/16 buckets serially, then a 4-level tree.  (One value per 64-point
+// workgroup -- 2-4 buckets per lane, 6 levels -- finishes sooner but keeps four times as many waves busy for two thirds
+// of that time; with a dozen proofs in flight SIMD time is what counts.)  NT threads hold NT / lanes points.
+static constexpr uint32_t DS_GROUP = 16;
+static constexpr int DS_THREADS = 128, DW_THREADS = 512;
+template <class T, int NT> FF_INLINE void digit_sums_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
     constexpr int XB = RawLayout<T>::XYZZ;
-    const TailJob& job = jobs.j[blockIdx.z];
     const uint8_t* __restrict__ buckets = job.buckets;
     const uint32_t* __restrict__ offsets = job.offsets;
     uint8_t* __restrict__ S = job.red;
-    constexpr uint32_t LP = Lanes<T>::N;
-    __shared__ uint32_t lds[LANE_POINT_WORDS][64 * LP];
+    constexpr uint32_t LP = Lanes<T>::N, PER_WG = NT / LP / DS_GROUP;
     const uint32_t win = blockIdx.y, pt = threadIdx.x / LP, sub = pt / DS_GROUP, lane = pt % DS_GROUP;
-    const uint32_t b = blockIdx.x * DS_PER_WG + sub;
+    if (blockIdx.x * PER_WG >= p.nd0 + p.nd1) return;             // whole workgroup (the launch is sized for the smaller PER_WG)
+    const uint32_t b = blockIdx.x * PER_WG + sub;
     const bool valid = b < p.nd0 + p.nd1;
     const uint64_t base = (uint64_t)win * p.nbw;
     const bool low = b < p.nd0;
@@ -468,37 +477,45 @@ __global__ __launch_bounds__(64 * Lanes<T>::N) void k_msm_digit_sums(TailJobs jo
             }
         }
     }
-    block_tree_sum<T, 64 * LP, DS_GROUP>(acc, lds);
+    block_tree_sum<T, NT, DS_GROUP>(acc, lds);
     if (valid && lane == 0) xyzz_store_raw<T>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
 }
+__global__ __launch_bounds__(DS_THREADS) void k_msm_digit_sums(TailJobs jobs, DigitPlan p) {
+    __shared__ uint32_t lds[LANE_POINT_WORDS][DS_THREADS];
+    if (blockIdx.z < jobs.n1) digit_sums_body<Fp, DS_THREADS>(jobs.j[blockIdx.z], p, lds);
+    else digit_sums_body<Fp2H, DS_THREADS>(jobs.j[blockIdx.z], p, lds);
+}
 // V[win][k] = sum_d d * S[win][k][d]
-template <class T>
-__global__ __launch_bounds__(256 * Lanes<T>::N) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
+template <class T, int NT> FF_INLINE void digit_weight_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
     constexpr int XB = RawLayout<T>::XYZZ;
-    const uint8_t* __restrict__ S = jobs.j[blockIdx.z].red;
-    uint8_t* __restrict__ V = jobs.j[blockIdx.z].wsum;
-    constexpr uint32_t LP = Lanes<T>::N;
-    __shared__ uint32_t lds[LANE_POINT_WORDS][256 * LP];
+    const uint8_t* __restrict__ S = job.red;
+    uint8_t* __restrict__ V = job.wsum;
+    constexpr uint32_t LP = Lanes<T>::N, NP = NT / LP;
     const uint32_t k = blockIdx.x, win = blockIdx.y, pt = threadIdx.x / LP;
     const uint32_t cnt = k == 0 ? p.nd0 : p.nd1;
     const uint8_t* base = S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + (k == 0 ? 0 : p.nd0));
     Xyzz<T> acc = xyzz_inf<T>();
-    for (uint32_t d = pt; d < cnt; d += 256) {
+    for (uint32_t d = pt; d < cnt; d += NP) {
         if (!d) continue;
         const Xyzz<T> q = xyzz_load_raw<T>(base + (uint64_t)XB * d);
         const Xyzz<T> m = xyzz_mul_u32_inl(q, d);
         xyzz_add_impl(acc, m);
     }
-    block_tree_sum<T, 256 * LP>(acc, lds);
+    block_tree_sum<T, NT>(acc, lds);
     if (threadIdx.x < LP) xyzz_store_raw<T>(V + (uint64_t)XB * (2 * win + k), acc);
+}
+__global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
+    __shared__ uint32_t lds[LANE_POINT_WORDS][DW_THREADS];
+    if (blockIdx.z < jobs.n1) digit_weight_body<Fp, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
+    else digit_weight_body<Fp2H, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
 }
 // W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one point).
 // The result leaves in the DENSE, fully reduced layout (it is an output of the library).
-template <class T> __global__ __launch_bounds__(64) void k_msm_final(TailJobs jobs, uint32_t nw, uint32_t c, uint32_t lb) {
+template <class T> FF_INLINE void final_body(const TailJob& job, uint32_t nw, uint32_t c, uint32_t lb) {
     constexpr int XB = RawLayout<T>::XYZZ;
     if (threadIdx.x >= Lanes<T>::N) return;
-    const uint8_t* __restrict__ V = jobs.j[blockIdx.z].wsum;
-    uint8_t* __restrict__ out = jobs.j[blockIdx.z].out;
+    const uint8_t* __restrict__ V = job.wsum;
+    uint8_t* __restrict__ out = job.out;
     Xyzz<T> acc = xyzz_inf<T>();
     for (uint32_t j = nw; j-- > 0;) {
         if (j != nw - 1)
@@ -510,6 +527,10 @@ template <class T> __global__ __launch_bounds__(64) void k_msm_final(TailJobs jo
         xyzz_add_impl(acc, lo);
     }
     xyzz_store<T>(out, acc);
+}
+__global__ __launch_bounds__(64) void k_msm_final(TailJobs jobs, uint32_t nw, uint32_t c, uint32_t lb) {
+    if (blockIdx.z < jobs.n1) final_body<Fp>(jobs.j[blockIdx.z], nw, c, lb);
+    else final_body<Fp2H>(jobs.j[blockIdx.z], nw, c, lb);
 }
 template <class F> __global__ void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
     constexpr int XB = FieldOps<F>::WORDS * 16;
@@ -778,36 +799,49 @@ int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalar
     const void* sc[1] = {d_scalars};
     return msm_sort_accumulate_many(b, ws, sc, 1, s);
 }
-// Steps 5-7 for `count` MSMs over the SAME bases in one chain of launches (T: how the kernels hold a point: Fp, or
-// Fp2H lane pairs for G2).  outs[i]: one dense XYZZ point each.
-template <class T> static int msm_reduce_t(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s) {
-    constexpr uint32_t LP = Lanes<T>::N;
+// Steps 5-7 for a batch of MSMs in one chain of launches: n1 products in G1 (bases b1) and n2 in G2 (bases b2), all with
+// the same window plan.  outs[i]: one dense XYZZ point each.
+int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* outs1, uint32_t n1,
+                     const MsmBases* b2, MsmWorkspace* const* ws2, void* const* outs2, uint32_t n2, hipStream_t s) {
+    if (n1 + n2 == 0 || n1 + n2 > MAX_TAIL_JOBS) ZK_FAIL(ZK_ERR_ARG, "msm_reduce: 1..8 MSMs per batch");
+    const MsmBases& b = n1 ? *b1 : *b2;
+    if (n1 && n2 && (b1->c != b2->c || b1->nw != b2->nw || b1->precomp != b2->precomp)) ZK_FAIL(ZK_ERR_ARG, "msm_reduce: one window plan per batch");
     const uint32_t nwin = b.precomp ? 1 : b.nw;
     TailJobs jobs{};
-    for (uint32_t i = 0; i < count; i++) {
-        MsmWorkspace& w = *ws[i];
-        if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.nbuckets != ws[0]->nbuckets || w.chunk != ws[0]->chunk)
-            ZK_FAIL(ZK_ERR_ARG, "msm_reduce: workspaces of one batch must share the bases");
+    jobs.n1 = n1;
+    uint64_t max_lanes = 0;
+    uint32_t max_nb = 0;
+    for (uint32_t i = 0; i < n1 + n2; i++) {
+        MsmWorkspace& w = i < n1 ? *ws1[i] : *ws2[i - n1];
+        const MsmBases& bi = i < n1 ? *b1 : *b2;
+        if (w.c != bi.c || w.precomp != bi.precomp || w.curve != bi.curve || bi.curve != (i < n1 ? CURVE_G1 : CURVE_G2))
+            ZK_FAIL(ZK_ERR_ARG, "msm_reduce: workspace does not match its bases");
         jobs.j[i] = TailJob{w.offsets.as<uint32_t>(), w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), w.worklist.as<uint32_t>(),
-                            w.red.as<uint8_t>(), w.wsum.as<uint8_t>(), (uint8_t*)outs[i]};
+                            w.red.as<uint8_t>(), w.wsum.as<uint8_t>(), (uint8_t*)(i < n1 ? outs1[i] : outs2[i - n1]), w.nbuckets, w.chunk};
         HIPCHK(hipMemsetAsync(w.worklist.p, 0, 4, s));
+        const uint64_t lanes = (uint64_t)w.nbuckets * (i < n1 ? 1 : 2);
+        if (lanes > max_lanes) max_lanes = lanes;
+        if (w.nbuckets > max_nb) max_nb = w.nbuckets;
     }
-    const uint32_t nb = ws[0]->nbuckets, chunk = ws[0]->chunk;
-    ScopedTimer t(b.curve == CURVE_G1 ? "msm_reduce_g1" : "msm_reduce_g2", s);
-    dim3 gf = grid_for((uint64_t)nb * LP, 128);
+    const uint32_t count = n1 + n2;
+    const char* fam = n2 == 0 ? "msm_reduce_g1" : (n1 == 0 ? "msm_reduce_g2" : "msm_reduce");
+    ScopedTimer t(fam, s);
+    dim3 gf = grid_for(max_lanes, 128);
     gf.z = count;
-    hipLaunchKernelGGL(k_msm_fixup<T>, gf, dim3(128), 0, s, jobs, nb, chunk);
-    hipLaunchKernelGGL(k_msm_fixup_big<T>, dim3(nb < 256 ? nb : 256, 1, count), dim3(256), 0, s, jobs, chunk);
+    hipLaunchKernelGGL(k_msm_fixup, gf, dim3(128), 0, s, jobs);
+    hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
     const DigitPlan dp = digit_plan(b.c);
-    hipLaunchKernelGGL(k_msm_digit_sums<T>, dim3((dp.nd0 + dp.nd1 + DS_PER_WG - 1) / DS_PER_WG, nwin, count), dim3(64 * LP), 0, s, jobs, dp);
-    hipLaunchKernelGGL(k_msm_digit_weight<T>, dim3(2, nwin, count), dim3(256 * LP), 0, s, jobs, dp);
-    hipLaunchKernelGGL(k_msm_final<T>, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb);
+    // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 4 values; G1: 8)
+    const uint32_t per_wg = (n2 ? DS_THREADS / 2 : DS_THREADS) / DS_GROUP;
+    hipLaunchKernelGGL(k_msm_digit_sums, dim3((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count), dim3(DS_THREADS), 0, s, jobs, dp);
+    hipLaunchKernelGGL(k_msm_digit_weight, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
+    hipLaunchKernelGGL(k_msm_final, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
 int msm_reduce(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s) {
-    if (count == 0 || count > MAX_TAIL_JOBS) ZK_FAIL(ZK_ERR_ARG, "msm_reduce: 1..8 MSMs per batch");
-    return b.curve == CURVE_G1 ? msm_reduce_t<Fp>(b, ws, outs, count, s) : msm_reduce_t<Fp2H>(b, ws, outs, count, s);
+    return b.curve == CURVE_G1 ? msm_reduce_mixed(&b, ws, outs, count, nullptr, nullptr, nullptr, 0, s)
+                               : msm_reduce_mixed(nullptr, nullptr, nullptr, 0, &b, ws, outs, count, s);
 }
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_out, hipStream_t s) {
     ZKCHK(msm_sort_accumulate(b, w, d_scalars, s));

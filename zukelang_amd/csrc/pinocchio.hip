@@ -245,23 +245,26 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     // sizes: the five pools over I_mid, the two G2 pools) go out as ONE chain of launches each
     for (int i = 0; i < PIN_G2; i++) ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], sl.scal2[i].p, s0));
     for (int i = 0; i < PIN_G1; i++) ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], sl.scal1[i].p, s0));
-    auto reduce_groups = [&](MsmBases* bases, MsmWorkspace* wss, int n, char* res_base, size_t stride) -> int {
-        bool done[8] = {false, false, false, false, false, false, false, false};
-        for (int i = 0; i < n; i++) {
-            if (done[i]) continue;
-            MsmWorkspace* ws[8];
-            void* outs[8];
-            uint32_t cnt = 0;
-            for (int j = i; j < n; j++)
-                if (!done[j] && wss[j].c == wss[i].c && wss[j].nw == wss[i].nw && wss[j].nbuckets == wss[i].nbuckets && wss[j].chunk == wss[i].chunk) {
-                    ws[cnt] = &wss[j]; outs[cnt] = res_base + stride * j; cnt++; done[j] = true;
-                }
-            ZKCHK(msm_reduce(bases[i], ws, outs, cnt, s0));
+    // reductions: every product whose pool got the same window plan goes into one mixed G1 / G2 chain of launches
+    // (from 2^16 constraints up that is all eight of them)
+    {
+        bool done1[PIN_G1] = {}, done2[PIN_G2] = {};
+        for (;;) {
+            int lead_c = -1, lead_nw = -1;
+            for (int i = 0; i < PIN_G1 && lead_c < 0; i++) if (!done1[i]) { lead_c = (int)k.g1[i].c; lead_nw = (int)k.g1[i].nw; }
+            for (int i = 0; i < PIN_G2 && lead_c < 0; i++) if (!done2[i]) { lead_c = (int)k.g2[i].c; lead_nw = (int)k.g2[i].nw; }
+            if (lead_c < 0) break;
+            MsmWorkspace *w1[PIN_G1], *w2[PIN_G2];
+            void *o1[PIN_G1], *o2[PIN_G2];
+            const MsmBases *b1 = nullptr, *b2 = nullptr;
+            uint32_t n1 = 0, n2 = 0;
+            for (int i = 0; i < PIN_G1; i++)
+                if (!done1[i] && (int)k.g1[i].c == lead_c && (int)k.g1[i].nw == lead_nw) { w1[n1] = &sl.ws1[i]; o1[n1] = res + i * x1; n1++; done1[i] = true; b1 = &k.g1[i]; }
+            for (int i = 0; i < PIN_G2; i++)
+                if (!done2[i] && (int)k.g2[i].c == lead_c && (int)k.g2[i].nw == lead_nw) { w2[n2] = &sl.ws2[i]; o2[n2] = res + PIN_G1 * x1 + i * x2; n2++; done2[i] = true; b2 = &k.g2[i]; }
+            ZKCHK(msm_reduce_mixed(b1, w1, o1, n1, b2, w2, o2, n2, s0));
         }
-        return ZK_OK;
-    };
-    ZKCHK(reduce_groups(k.g2, sl.ws2, PIN_G2, res + PIN_G1 * x1, x2));
-    ZKCHK(reduce_groups(k.g1, sl.ws1, PIN_G1, res, x1));
+    }
     {
         uint32_t o1[PIN_G1], o2[PIN_G2];
         for (int i = 0; i < PIN_G1; i++) o1[i] = (uint32_t)off1[i];
