@@ -12,12 +12,13 @@ from oracle import pyref as P
 from zukelang_amd import r1cs as RC
 from zukelang_amd.curve import G1, G2
 from zukelang_amd.groth16 import Groth16
+from zukelang_amd import pinocchio as PIN
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 frb = P.fr_to_bytes
 t_end = time.time() + budget
-n_msm = n_g16 = 0
+n_msm = n_g16 = n_pin = 0
 while time.time() < t_end:
     # ---- MSM with duplicates, negations, identity, tiny / huge / zero scalars
     G, naive, gen, mul = rnd.choice([(G1, O.g1_msm_naive, O.g1_generator, O.g1_mul), (G2, O.g2_msm_naive, O.g2_generator, O.g2_mul)])
@@ -53,6 +54,22 @@ while time.time() < t_end:
         assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch", n, lag)
         pr.close()
     n_g16 += 1
+    # ---- every fourth round: Pinocchio ZK prove at a random size against the trapdoor evaluation, then the product's verifier
+    if n_g16 % 4 == 0:
+        n = 2 * rnd.randrange(1, 400)
+        cs, w = RC.iterated_cubic(n, rnd.randrange(1, P.R))
+        tox = [rnd.randrange(1, P.R) for _ in range(11)]
+        it = iter(tox)
+        pk, vk = PIN.ZK.keygen(lambda: next(it), cs)
+        prover = PIN.ZK(cs, pk)
+        proof = prover.prove(lambda: next(it), w)
+        csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+        exp = O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, b"".join(frb(x) for x in w), b"".join(frb(x) for x in tox[:8]), *(frb(x) for x in tox[8:]))
+        assert proof.to_bytes() == exp, ("Pinocchio mismatch", n)
+        if n <= 40:
+            assert PIN.ZK.verify([w[k] for k in range(cs.m) if not cs.mid[k]], vk, proof)
+        prover.close()
+        n_pin += 1
     if (n_msm % 10) == 0:
-        print("soak: %d MSM cases, %d Groth16 cases ok" % (n_msm, n_g16), flush=True)
-print("SOAK-OK msm=%d groth16=%d" % (n_msm, n_g16))
+        print("soak: %d MSM cases, %d Groth16 cases, %d Pinocchio cases ok" % (n_msm, n_g16, n_pin), flush=True)
+print("SOAK-OK msm=%d groth16=%d pinocchio=%d" % (n_msm, n_g16, n_pin))
