@@ -15,8 +15,9 @@ n = (1 << logn) * W
 cs, w = RC.iterated_cubic(n, next(RC.fr_stream(1)))
 st = RC.fr_stream(2); rng = lambda: next(st)
 pk, _ = Groth16.keygen(rng, cs)
-G = max(1, 12 // (W + 1))          # groups per round, as GroupProver
-B = G * W
+B = 12                              # proofs per round, as GroupProver: batch + ceil(batch / W) <= 14 slots
+while B + (B + W - 1) // W > 14: B -= 1
+G = (B + W - 1) // W                # Fr stages rank 0 runs per round at most
 pr = Groth16(cs, pk, 0, W); pr.set_witness(w); pr.reserve_slots(B + G)
 v = [C.c_uint64() for _ in range(6)]
 _lib.check(L.zk_groth16_pool_layout(pr.handle, *[C.byref(x) for x in v]))
@@ -28,22 +29,28 @@ l1, l2 = 32 * (hi1 - lo1), 32 * (hi2 - lo2)
 recv = [[dmalloc(W * l1), dmalloc(W * l1), dmalloc(W * l2)] for _ in range(G)]
 part = np.zeros(768, dtype=np.uint8)
 fr_pending = False
+count = 0
+def owned(base):
+    """how many proofs of a round starting at job index `base` belong to rank 0"""
+    return len([t for t in range(B) if (base + t) % W == 0])
 def launch_fr():
-    global fr_pending
+    global fr_pending, n_launched
     rb, sb = fr_bytes([rng()]), fr_bytes([rng()])
-    for k in range(G):
+    n_launched = owned(count)
+    for k in range(n_launched):
         _lib.check(L.zk_groth16_scalars_async(pr.handle, None, _p(rb), _p(sb), C.c_uint32(B + k), C.c_void_p(full[k][0]), C.c_void_p(full[k][1]), C.c_void_p(full[k][2])))
     fr_pending = True
 def group(distributed):
     """One round as GroupProver.prove_many runs it: the NEXT round's Fr stages are enqueued before this round's MSMs are waited for."""
-    global fr_pending
+    global fr_pending, count
     rb, sb = fr_bytes([rng()]), fr_bytes([rng()])
     if distributed:
         if not fr_pending:
             launch_fr()
-        for k in range(G):
+        for k in range(n_launched):
             _lib.check(L.zk_groth16_scalars_wait(pr.handle, C.c_uint32(B + k)))
         fr_pending = False
+        count += B
         for k in range(G):
             for j in range(W):      # stand-in for the all-to-all: W slices land in recv
                 _lib.check(L.zk_device_memcpy(C.c_void_p(recv[k][0] + j * l1), C.c_void_p(full[k][0] + 32 * lo1), C.c_size_t(l1)))
@@ -66,7 +73,7 @@ for mode in (True, False):
     t0 = time.perf_counter(); REPS = 5
     for _ in range(REPS): group(mode)
     if fr_pending:
-        for k in range(G):
+        for k in range(n_launched):
             _lib.check(L.zk_groth16_scalars_wait(pr.handle, C.c_uint32(B + k)))
         fr_pending = False
     _lib.check(L.zk_sync())

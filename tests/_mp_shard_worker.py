@@ -108,16 +108,19 @@ def main():
         # distributed Fr stage: proofs in groups of `world`, rank j runs the Fr stage of the j-th proof only
         from zukelang_amd.groth16 import GroupProver
         rs = [(r, s)] + [(next(st), next(st)) for _ in range(2 * world)]          # 2 full groups + 1 proof
-        gp = GroupProver(prover, groups=2 if world == 2 else 1)      # rounds of 4 (two groups) resp. 3 proofs: the last round is partial
+        gp = GroupProver(prover, batch=3 if world == 2 else 4)      # rounds that are NOT a multiple of the world size: ownership rotates
         got = gp.prove_many(rs)
         assert len(got) == len(rs)
         assert (got[0].a, got[0].b, got[0].c) == expect, "rank %d: group proof 0 differs" % rank
         for (rr, ss), pr in zip(rs[1:], got[1:]):
             e2 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
             assert (pr.a, pr.b, pr.c) == e2, "rank %d: a group proof differs" % rank
-        own = gp.prove_many(rs[:world], combine_all=False)
-        assert [i for i, x in enumerate(own) if x is not None] == [rank]
-        assert (own[rank].a, own[rank].b, own[rank].c) == tuple(getattr(got[rank], f) for f in "abc")
+        start = gp.count                                              # proof i of the job belongs to rank (start + i) % world
+        own = gp.prove_many(rs[:world + 1], combine_all=False)
+        mine = [i for i in range(world + 1) if (start + i) % world == rank]
+        assert [i for i, x in enumerate(own) if x is not None] == mine
+        for i in mine:
+            assert (own[i].a, own[i].b, own[i].c) == tuple(getattr(got[i], f) for f in "abc")
         prover.close()
     dist.barrier()
     if rank == 0:

@@ -357,28 +357,35 @@ class Groth16:
 
 
 class GroupProver:
-    """N > 1 with a DISTRIBUTED Fr stage.  Proofs are handled in rounds of G groups of `world` proofs: rank j
-    runs QAP.eval (QAP.ml:120-135) and builds the three scalar vectors only for the proofs it owns (the j-th
-    of every group); one all-to-all per vector and group hands rank g its slice [lo_g, hi_g) of every proof's
-    scalars; every rank then runs the point-sharded MSMs (groth16.ml:116-161) of all G * world proofs of the
-    round over its slice (that many proofs in flight, one slot each), the 768-byte partial sums of the round
-    travel in one all-gather, and zk_groth16_combine finishes each proof.  Per proof and rank that is 1/world
-    of an Fr stage plus one sharded MSM triple -- with the replicated Fr stage of prove_async / prove_wait on
-    a sharded key it is a whole Fr stage.  The next round's Fr stages are enqueued before this round's MSMs
-    are waited for."""
+    """N > 1 with a DISTRIBUTED Fr stage.  Proofs are handled in rounds of `batch`; proof number i of the job belongs
+    to rank i % world, which alone runs QAP.eval (QAP.ml:120-135) for it and builds its three scalar vectors; one
+    all-to-all per vector hands rank g its slice [lo_g, hi_g) of the scalars of the k-th proof of every owner
+    (k = 0, 1, ...: ceil(batch / world) exchanges per round); every rank then runs the point-sharded MSMs
+    (groth16.ml:116-161) of all proofs of the round over its slice (that many proofs in flight, one slot each), the
+    768-byte partial sums of the round travel in one all-gather, and zk_groth16_combine finishes each proof.
+    Per proof and rank that is 1/world of an Fr stage plus one sharded MSM triple -- with the replicated Fr stage of
+    prove_async / prove_wait on a sharded key it is a whole Fr stage.  The next round's Fr stages are enqueued before
+    this round's MSMs are waited for; ownership rotates with the running proof count, so the ranks stay balanced when
+    `batch` is not a multiple of `world`."""
 
     MAX_SLOTS = 15
 
-    def __init__(self, prover, groups=None):
+    def __init__(self, prover, batch=None):
         import torch
         self.torch = torch
         self.p = prover
         self.world, self.rank = prover.world, prover.rank
         W = self.world
-        # slots = G * (W + 1) streams; the chip runs 16 hardware queues side by side and RCCL / the framework need a few
-        self.G = groups if groups else max(1, 12 // (W + 1))
-        if self.G * (W + 1) > self.MAX_SLOTS:
-            raise ValueError("GroupProver: groups * (world + 1) must not exceed %d slots" % self.MAX_SLOTS)
+        if batch is None:
+            # MSM slots + Fr slots = batch + ceil(batch / W) streams <= 14: the chip runs 16 hardware queues side by side and
+            # RCCL / the framework need some
+            batch = 12
+            while batch + (batch + W - 1) // W > 14:
+                batch -= 1
+        self.batch = batch                          # proofs per round; MSM slots 0..batch-1
+        self.K = (batch + W - 1) // W               # Fr stages a rank runs per round at most; Fr slots batch..batch+K-1
+        if self.batch < 1 or self.batch + self.K > self.MAX_SLOTS:
+            raise ValueError("GroupProver: batch + ceil(batch / world) must not exceed %d slots" % self.MAX_SLOTS)
         L = _lib.lib()
         v = [C.c_uint64() for _ in range(6)]
         _lib.check(L.zk_groth16_pool_layout(prover.handle, *[C.byref(x) for x in v]))
@@ -389,25 +396,27 @@ class GroupProver:
         dev = torch.device("cuda", torch.cuda.current_device())
         u8 = dict(dtype=torch.uint8, device=dev)
         self.len1, self.len2 = 32 * (self.hi1 - self.lo1), 32 * (self.hi2 - self.lo2)
-        # per group of the round: the owner's full vectors A, C, B and the received slices [world][slice]
-        self.full = [[torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p2, **u8)] for _ in range(self.G)]
-        self.recv = [[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.G)]
-        self.batch = self.G * W                   # proofs per round; MSM slots 0..batch-1, Fr slots batch..batch+G-1
-        prover.reserve_slots(self.batch + self.G)
+        # per owned proof of the round: the owner's full vectors A, C, B and the received slices [world][slice]
+        self.full = [[torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p2, **u8)] for _ in range(self.K)]
+        self.recv = [[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.K)]
+        self.count = 0                              # proofs handled so far: proof i of the job belongs to rank i % world
+        prover.reserve_slots(self.batch + self.K)
         torch.cuda.current_stream().synchronize()
 
-    def _launch_fr(self, rnd):
-        """rnd: list of (r, s), at most `batch`; this rank owns rnd[k * world + rank].  Returns the groups launched."""
+    def _launch_fr(self, rnd, base):
+        """rnd: list of (r, s), at most `batch`; proof t of the round belongs to rank (base + t) % world.
+        Returns the indices k of the Fr slots launched."""
         launched = []
-        for k in range(self.G):
-            t = k * self.world + self.rank
-            if t >= len(rnd):
-                break
+        t = (self.rank - base) % self.world
+        k = 0
+        while t < len(rnd):
             rb, sb = fr_bytes([rnd[t][0]]), fr_bytes([rnd[t][1]])
             f = self.full[k]
             _lib.check(_lib.lib().zk_groth16_scalars_async(self.p.handle, None, _p(rb), _p(sb), C.c_uint32(self.batch + k),
                                                            C.c_void_p(f[0].data_ptr()), C.c_void_p(f[1].data_ptr()), C.c_void_p(f[2].data_ptr())))
             launched.append(k)
+            k += 1
+            t += self.world
         return launched
 
     def _finish_fr_and_exchange(self, launched, count):
@@ -416,7 +425,7 @@ class GroupProver:
             if rc == ZK_ERR_REMAINDER:
                 raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
             _lib.check(rc)
-        for k in range((count + self.world - 1) // self.world):       # every rank takes part in every group's exchange
+        for k in range((count + self.world - 1) // self.world):       # every rank takes part in every exchange of the round
             for i, bounds in ((0, self.bounds1), (1, self.bounds1), (2, self.bounds2)):
                 exchange_slices(self.full[k][i], bounds, self.rank, self.world, out=self.recv[k][i])
         self.torch.cuda.current_stream().synchronize()        # the slices have landed before the library's streams read them
@@ -424,29 +433,32 @@ class GroupProver:
     def prove_many(self, rs_list, combine_all=True):
         """All ranks call this with the same list of (r, s); the witness is the resident one (set_witness).
         Returns the proofs in order -- all of them on every rank, or with combine_all=False only the ones
-        this rank owns (index % world == rank; None elsewhere): each proof then costs ONE combine in the job
-        instead of one per rank."""
+        this rank owns (None elsewhere): each proof then costs ONE combine in the job instead of one per rank."""
         L = _lib.lib()
         W = self.world
         rounds = [rs_list[i:i + self.batch] for i in range(0, len(rs_list), self.batch)]
+        bases, c = [], self.count
+        for rnd in rounds:
+            bases.append(c % W)
+            c += len(rnd)
         proofs = []
-        launched = self._launch_fr(rounds[0]) if rounds else []
+        launched = self._launch_fr(rounds[0], bases[0]) if rounds else []
         for ri, rnd in enumerate(rounds):
-            cnt = len(rnd)
+            cnt, base = len(rnd), bases[ri]
             self._finish_fr_and_exchange(launched, cnt)
             if ri + 1 < len(rounds):
-                launched = self._launch_fr(rounds[ri + 1])      # overlaps with this round's MSMs
+                launched = self._launch_fr(rounds[ri + 1], bases[ri + 1])      # overlaps with this round's MSMs
             for t in range(cnt):
-                k, j = divmod(t, W)
+                k, owner = t // W, (base + t) % W
                 rv = self.recv[k]
-                _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(t), C.c_void_p(rv[0].data_ptr() + j * self.len1),
-                                                          C.c_void_p(rv[1].data_ptr() + j * self.len1), C.c_void_p(rv[2].data_ptr() + j * self.len2)))
+                _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(t), C.c_void_p(rv[0].data_ptr() + owner * self.len1),
+                                                          C.c_void_p(rv[1].data_ptr() + owner * self.len1), C.c_void_p(rv[2].data_ptr() + owner * self.len2)))
             parts = np.zeros((self.batch, 768), dtype=np.uint8)
             for t in range(cnt):
                 _lib.check(L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(t), _p(parts[t])))
             gathered = all_gather_bytes(parts.reshape(-1), W).reshape(W, self.batch, 768)        # [rank][proof]
             for t in range(cnt):
-                if not combine_all and t % W != self.rank:
+                if not combine_all and (base + t) % W != self.rank:
                     proofs.append(None)
                     continue
                 out = np.zeros(384, dtype=np.uint8)
@@ -454,4 +466,5 @@ class GroupProver:
                 _lib.check(L.zk_groth16_combine(_p(blk), C.c_uint32(W), _p(out)))
                 b = bytes(out)
                 proofs.append(Proof(b[:96], b[96:288], b[288:]))
+        self.count = c
         return proofs
