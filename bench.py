@@ -285,7 +285,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_all.items())},
-            "proof_compressed_hex": proof.to_compressed().hex(),
+            "proof_compressed_hex": proof.to_compressed().hex() if proof is not None else None,     # N > 1: rank 0 prints a proof it combined itself
         }
         print(json.dumps(out))
     prover.close()
