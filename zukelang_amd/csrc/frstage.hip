@@ -77,15 +77,11 @@ __global__ void k_scale_pad2(uint32_t* out, const uint32_t* in, const uint32_t* 
 __global__ __launch_bounds__(NTT_THREADS) void k_tree_levels_fused(uint32_t* __restrict__ d, const uint32_t* __restrict__ pntt,
                                                                   const uint32_t* __restrict__ tw_fwd, const uint32_t* __restrict__ tw_inv,
                                                                   uint32_t levels, uint32_t log_T, uint64_t n2) {
-    __shared__ uint32_t lds[8][NTT_T];       // transform workspace
-    __shared__ uint32_t cur[8][NTT_T];       // the tile's coefficients between levels
+    __shared__ NttTile lds;       // transform workspace
+    __shared__ NttTile cur;       // the tile's coefficients between levels, each < 2r
     const uint32_t T = 1u << log_T;
     const uint64_t base = (uint64_t)blockIdx.x << log_T;
-    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x = fe_load<FrParams>(d + 8 * (base + e));
-#pragma unroll
-        for (int l = 0; l < 8; l++) cur[l][e] = x.v[l];
-    }
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) fr9_lds_put(cur, e, fr9_load(d + 8 * (base + e)));
     __syncthreads();
     for (uint32_t lv = 1; lv <= levels; lv++) {
         const uint32_t half = 1u << (lv - 1), lm = (half << 1) - 1;
@@ -93,41 +89,22 @@ __global__ __launch_bounds__(NTT_THREADS) void k_tree_levels_fused(uint32_t* __r
         for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
             const bool low = (e & lm) < half;
 #pragma unroll
-            for (int l = 0; l < 8; l++) lds[l][e] = low ? cur[l][e + half] : 0u;
+            for (int l = 0; l < FR29_L; l++) lds[l][e] = low ? cur[l][e + half] : 0u;
         }
         __syncthreads();
         lds_ntt_stages<false>(lds, tw_fwd, T, lv, 0, 0, 0, false);
-        for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-            Fr x;
-#pragma unroll
-            for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
-            x = fe_mul(x, fe_load<FrParams>(tab + 8 * ((base + e) & (n2 - 1))));
-#pragma unroll
-            for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
-        }
+        for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS)
+            fr9_lds_put(lds, e, fr9_mul(fr9_lds_get(lds, e), fr9_load(tab + 8 * ((base + e) & (n2 - 1)))));
         __syncthreads();
         lds_ntt_stages<true>(lds, tw_inv, T, lv, 0, 0, 0, false);
         for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-            Fr x;
-#pragma unroll
-            for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
-            if ((e & lm) < half) {
-                Fr lo;
-#pragma unroll
-                for (int l = 0; l < 8; l++) lo.v[l] = cur[l][e];
-                x = fe_add(x, lo);
-            }
-#pragma unroll
-            for (int l = 0; l < 8; l++) cur[l][e] = x.v[l];
+            Fr9 x = fr9_lds_get(lds, e);                                  // < 42 r
+            if ((e & lm) < half) x = fr9_add(x, fr9_lds_get(cur, e));
+            fr9_lds_put(cur, e, fr9_reduce_weak(x));
         }
         __syncthreads();
     }
-    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x;
-#pragma unroll
-        for (int l = 0; l < 8; l++) x.v[l] = cur[l][e];
-        fe_store<FrParams>(d + 8 * (base + e), x);
-    }
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) fr9_store(d + 8 * (base + e), fr9_lds_get(cur, e));
 }
 // out[k] = k < cnt ? in[top - k] : 0    (reversal of a coefficient window, zero padded)
 __global__ void k_reverse_pad(uint32_t* out, const uint32_t* in, uint64_t top, uint64_t cnt, uint64_t total) {
@@ -298,7 +275,7 @@ int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, voi
     if (lg == 0) ZKCHK(fr_pointwise_mul(A.p, A.p, B.p, S, s));
     else {
         ZKCHK(ntt_forward(B.p, S, lg, s));
-        ZKCHK(ntt_mul_table(A.p, S, lg, B.p, S - 1, true, nullptr, nullptr, s));
+        ZKCHK(ntt_mul_table(A.p, S, lg, B.p, S - 1, true, nullptr, nullptr, s, true));
     }
     HIPCHK(hipMemcpyAsync(d_out, A.p, 32 * nout, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // A, B are freed on return
@@ -384,6 +361,7 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
         hipLaunchKernelGGL(k_invfact, g1d(nch, 64), dim3(64), 0, s, FRP(f.invfact), FRP(alt), (const uint32_t*)FRP(prod), n2);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.e_ntt), (const uint32_t*)FRP(alt), (const uint32_t*)nullptr, (uint64_t)n2, (uint64_t)S);
         ZKCHK(ntt_forward(f.e_ntt.p, S, f.log_S, s));
+        ZKCHK(fr_to_factor(f.e_ntt.p, S, s));
         HIPCHK(hipStreamSynchronize(s));
     }
     // ---- subproduct tree, bottom-up.  q holds Q_{l,node} (low 2^l coefficients, monic), n2 entries per level.
@@ -405,6 +383,7 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
             hipLaunchKernelGGL(k_tree_unwrap, g1d(n2 >> (l + 1)), dim3(256), 0, s, FRP(prod), l + 1, (uint64_t)(n2 >> (l + 1)));
             HIPCHK(hipMemcpyAsync(q.p, prod.p, 32 * (size_t)n2, hipMemcpyDeviceToDevice, s));
         }
+        ZKCHK(fr_to_factor(f.pntt.p, (uint64_t)n2 * f.log_n2, s));
         // ---- Z = prod_{i<n} (X - i)
         if (n == n2) {
             HIPCHK(hipMemcpyAsync(f.z.p, q.p, 32 * (size_t)n, hipMemcpyDeviceToDevice, s));   // root product, monic
@@ -442,6 +421,7 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
         }
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.iz_ntt), (const uint32_t*)FRP(g), (const uint32_t*)nullptr, need, (uint64_t)S);
         ZKCHK(ntt_forward(f.iz_ntt.p, S, f.log_S, s));
+        ZKCHK(fr_to_factor(f.iz_ntt.p, S, s));
         HIPCHK(hipStreamSynchronize(s));
     }
     HIPCHK(hipGetLastError());
@@ -495,7 +475,7 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), (const uint32_t*)FRP(sc.d), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, (FRP(sc.bufA) + 8 * (uint64_t)S), (const uint32_t*)(FRP(sc.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
         ZKCHK(ntt_forward((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, s));
-        ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), (uint64_t)S - 1, true, nullptr, nullptr, s));   // v*w, coefficients 0..2n-2
+        ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), (uint64_t)S - 1, true, nullptr, nullptr, s, true));   // v*w, coefficients 0..2n-2
         // t[k] = (v w)[2n-2-k], k < n-1
         hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, (FRP(sc.bufA) + 8 * (uint64_t)S), (const uint32_t*)FRP(sc.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
         ZKCHK(ntt_mul_table((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, f.iz_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
@@ -512,6 +492,7 @@ int frstage_init_lagrange(FrStage& f, hipStream_t s) {
     ZKCHK(f.zt.alloc(32 * (size_t)(n > 1 ? n - 1 : 1)));
     hipLaunchKernelGGL(k_inv_range, g1d((S + FCH - 1) / FCH, 64), dim3(64), 0, s, FRP(f.g_ntt), S);
     ZKCHK(ntt_forward(f.g_ntt.p, S, f.log_S, s));
+    ZKCHK(fr_to_factor(f.g_ntt.p, S, s));
     const uint32_t nch = (S + FCH - 1) / FCH;              // factorials up to 2 n <= S
     DevBuf prod;
     ZKCHK(prod.alloc(32 * (size_t)nch));

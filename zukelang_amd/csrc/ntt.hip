@@ -23,6 +23,12 @@ __device__ static const uint32_t OMEGA_MONT[8] = {0x0c17f47cu, 0x9cab6d5cu, 0xfd
 __device__ static const uint32_t OMEGA_INV_MONT[8] = {0xb3082d19u, 0x55a9e082u, 0xc7dc4a13u, 0x082f90b2u,
                                                       0xc76b052cu, 0x76ce3accu, 0x6e54185du, 0x15c39d95u};
 
+FF_INLINE Fr fr_c32() {                            // 32 in Montgomery form: x_R * 32 = x * 2^261
+    Fr c;
+#pragma unroll
+    for (int l = 0; l < 8; l++) c.v[l] = FR29_C32[l];
+    return c;
+}
 // tw[2^(k-1) + j] = w_{2^k}^(+-j), j < 2^(k-1), k = 1..K.  Entry 0 unused.
 __global__ void k_gen_twiddles(uint32_t* tw, uint32_t log_k, int inverse) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,7 +45,7 @@ __global__ void k_gen_twiddles(uint32_t* tw, uint32_t log_k, int inverse) {
         if ((e >> b) & 1) acc = fe_mul(acc, base);
         base = fe_sqr(base);
     }
-    fe_store<FrParams>(tw + 8 * i, acc);
+    fe_store<FrParams>(tw + 8 * i, fe_mul(acc, fr_c32()));                // w * 2^261: the factor form of fr29.cuh
 }
 
 struct PassArgs {
@@ -64,7 +70,7 @@ struct PassIO {
 template <bool INVERSE>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw,
                                                          PassArgs a, const uint32_t* __restrict__ scale, PassIO io) {
-    __shared__ uint32_t lds[8][NTT_T];
+    __shared__ NttTile lds;
     const uint32_t T = 1u << a.log_T;
     const uint32_t log_L = a.log_hi - a.s;
     const uint32_t RSm = (1u << a.log_RS) - 1;
@@ -87,24 +93,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__
     uint32_t* dst = io.dst ? io.dst : data;
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
         const uint64_t g = gidx(e);
-        Fr x;
-        if (io.pad_half) x = (g & lenm) < half ? fe_load<FrParams>(src + 8 * (g + half)) : fe_zero<FrParams>();
-        else x = fe_load<FrParams>(src + 8 * g);
-#pragma unroll
-        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
+        Fr9 x;
+        if (io.pad_half) x = (g & lenm) < half ? fr9_load(src + 8 * (g + half)) : fr9_zero();
+        else x = fr9_load(src + 8 * g);
+        fr9_lds_put(lds, e, x);
     }
     __syncthreads();
     lds_ntt_stages<INVERSE>(lds, tw, T, a.s, a.log_RS, log_L, c0, a.strided != 0);
-    Fr sc;
-    if (scale) sc = fe_load<FrParams>(scale);
+    Fr9 sc;
+    if (scale) sc = fr9_load(scale);
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x;
-#pragma unroll
-        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
-        if (scale) x = fe_mul(x, sc);
+        Fr9 x = fr9_lds_get(lds, e);                     // < 48 r
+        if (scale) x = fr9_mul(x, sc);
         const uint64_t g = gidx(e);
-        if (io.add_low && (g & lenm) < half) x = fe_add(x, fe_load<FrParams>(io.lo + 8 * g));
-        fe_store<FrParams>(dst + 8 * g, x);
+        if (io.add_low && (g & lenm) < half) x = fr9_add(x, fr9_load(io.lo + 8 * g));
+        fr9_store(dst + 8 * g, x);
     }
 }
 // The middle of a convolution in ONE kernel: the last (contiguous) forward pass, the pointwise product
@@ -114,34 +117,22 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_mid(uint32_t* __restrict__ 
                                                         const uint32_t* __restrict__ tw_inv, uint32_t log_T, uint32_t s,
                                                         const uint32_t* __restrict__ tab, uint64_t tab_mask,
                                                         const uint32_t* __restrict__ scale) {
-    __shared__ uint32_t lds[8][NTT_T];
+    __shared__ NttTile lds;
     const uint32_t T = 1u << log_T;
     const uint64_t base = (uint64_t)blockIdx.x << log_T;
-    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x = fe_load<FrParams>(data + 8 * (base + e));
-#pragma unroll
-        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
-    }
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) fr9_lds_put(lds, e, fr9_load(data + 8 * (base + e)));
     __syncthreads();
     lds_ntt_stages<false>(lds, tw_fwd, T, s, 0, 0, 0, false);
-    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x;
-#pragma unroll
-        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
-        x = fe_mul(x, fe_load<FrParams>(tab + 8 * ((base + e) & tab_mask)));
-#pragma unroll
-        for (int l = 0; l < 8; l++) lds[l][e] = x.v[l];
-    }
+    for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS)      // own elements only: no barrier needed before
+        fr9_lds_put(lds, e, fr9_mul(fr9_lds_get(lds, e), fr9_load(tab + 8 * ((base + e) & tab_mask))));
     __syncthreads();
     lds_ntt_stages<true>(lds, tw_inv, T, s, 0, 0, 0, false);
-    Fr sc;
-    if (scale) sc = fe_load<FrParams>(scale);
+    Fr9 sc;
+    if (scale) sc = fr9_load(scale);
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr x;
-#pragma unroll
-        for (int l = 0; l < 8; l++) x.v[l] = lds[l][e];
-        if (scale) x = fe_mul(x, sc);
-        fe_store<FrParams>(data + 8 * (base + e), x);
+        Fr9 x = fr9_lds_get(lds, e);
+        if (scale) x = fr9_mul(x, sc);
+        fr9_store(data + 8 * (base + e), x);
     }
 }
 
@@ -175,15 +166,26 @@ __global__ void k_fr_pointwise_mul(uint32_t* out, const uint32_t* a, const uint3
     if (i >= n) return;
     fe_store<FrParams>(out + 8 * i, fe_mul(fe_load<FrParams>(a + 8 * i), fe_load<FrParams>(b + 8 * i)));
 }
-// 2^-k in Montgomery form for k = 0..32, filled once
+// Scale factors of the inverse transforms, filled once, in the factor form of fr29.cuh (f * 2^261):
+// out[k] = 2^-k for k = 0..32, and out[33 + k] = 32 * 2^-k -- the scale to use when the pointwise table of a
+// convolution was in the DATA form (a transform output, x * 2^256): the product then lacks a factor 32.
 __global__ void k_gen_inv_pow2(uint32_t* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Fr half = fe_inv(fe_from_u32<FrParams>(2));
     Fr acc = fe_one<FrParams>();
+    const Fr c32 = fr_c32();
     for (int k = 0; k <= 32; k++) {
-        fe_store<FrParams>(out + 8 * k, acc);
+        const Fr f = fe_mul(acc, c32);
+        fe_store<FrParams>(out + 8 * k, f);
+        fe_store<FrParams>(out + 8 * (33 + k), fe_mul(f, c32));
         acc = fe_mul(acc, half);
     }
+}
+// buf <- 32 * buf: a transform output (data form) becomes a pointwise table (factor form)
+__global__ void k_fr_to_factor(uint32_t* buf, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store<FrParams>(buf + 8 * i, fe_mul(fe_load<FrParams>(buf + 8 * i), fr_c32()));
 }
 
 // heap-allocated and never destroyed: static destructors must not call into a HIP runtime that is already gone
@@ -193,7 +195,7 @@ int ntt_ensure_twiddles(uint32_t log_n) {
     Ctx& c = ctx();
     if (log_n > 30) ZK_FAIL(ZK_ERR_ARG, "NTT size above 2^30 is not supported");
     if (!g_inv_pow2.p) {
-        ZKCHK(g_inv_pow2.alloc(33 * 32));
+        ZKCHK(g_inv_pow2.alloc(66 * 32));
         hipLaunchKernelGGL(k_gen_inv_pow2, dim3(1), dim3(64), 0, c.stream, g_inv_pow2.as<uint32_t>());
         HIPCHK(hipGetLastError());
     }
@@ -264,8 +266,11 @@ static int run_ntt(void* d, uint64_t total, uint32_t log_len, bool inverse, bool
 //   pad_src != nullptr : x = upper half of every node of pad_src, zero padded (tree level); else x = work
 //   add_dst != nullptr : the result plus the node's lower half goes to add_dst (tree level); else to work
 // scale: multiply by 2^-log_len (when the table does not already carry it).
+// The table is in the factor form (fr_to_factor of a transform output, scaled or not); a table that is a plain
+// transform output is announced with tab_is_data and needs scale = true.
 int ntt_mul_table(void* work, uint64_t total, uint32_t log_len, const void* tab, uint64_t tab_mask, bool scale,
-                  const void* pad_src, void* add_dst, hipStream_t s) {
+                  const void* pad_src, void* add_dst, hipStream_t s, bool tab_is_data) {
+    if (tab_is_data && !scale) ZK_FAIL(ZK_ERR_ARG, "ntt_mul_table: a data-form table needs the scaled form");
     if (total == 0 || (total & (total - 1)) || ((uint64_t)1 << log_len) > total || log_len == 0) ZK_FAIL(ZK_ERR_ARG, "ntt_mul_table: bad sizes");
     ZKCHK(ntt_ensure_twiddles(log_len));
     Ctx& c = ctx();
@@ -276,7 +281,7 @@ int ntt_mul_table(void* work, uint64_t total, uint32_t log_len, const void* tab,
     plan(log_len, log_T, st, last);
     if (st.empty() && (pad_src || add_dst)) ZK_FAIL(ZK_ERR_ARG, "ntt_mul_table: fused edges need a node larger than one tile");
     dim3 grid((unsigned)(total >> log_T));
-    const uint32_t* sc = scale ? g_inv_pow2.as<uint32_t>() + 8 * log_len : nullptr;
+    const uint32_t* sc = scale ? g_inv_pow2.as<uint32_t>() + 8 * (log_len + (tab_is_data ? 33 : 0)) : nullptr;
     ScopedTimer t("ntt_mul_table", s);
     for (size_t i = 0; i < st.size(); i++) {
         PassIO io{};
@@ -311,6 +316,12 @@ int fr_to_mont(void* dst, const void* src, uint64_t n, int* flag, hipStream_t s)
 int fr_from_mont(void* dst, const void* src, uint64_t n, hipStream_t s) {
     if (!n) return ZK_OK;
     hipLaunchKernelGGL(k_fr_from_mont, grid1d(n), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int fr_to_factor(void* buf, uint64_t n, hipStream_t s) {
+    if (!n) return ZK_OK;
+    hipLaunchKernelGGL(k_fr_to_factor, grid1d(n), dim3(256), 0, s, (uint32_t*)buf, n);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }

@@ -97,7 +97,8 @@ int ntt_ensure_twiddles(uint32_t log_n);
 int ntt_forward(void* d_data, uint64_t total, uint32_t log_len, hipStream_t s);
 int ntt_inverse(void* d_data, uint64_t total, uint32_t log_len, bool scale, hipStream_t s);
 int ntt_mul_table(void* work, uint64_t total, uint32_t log_len, const void* tab, uint64_t tab_mask, bool scale,
-                  const void* pad_src, void* add_dst, hipStream_t s);
+                  const void* pad_src, void* add_dst, hipStream_t s, bool tab_is_data = false);
+int fr_to_factor(void* d_buf, uint64_t n, hipStream_t s);   // transform output -> pointwise-table form (x 32, see fr29.cuh)
 int fr_bitrev_permute(void* d_data, uint64_t total, uint32_t log_len, hipStream_t s);
 int fr_to_mont(void* d_dst, const void* d_src, uint64_t n, int* d_flag_noncanonical, hipStream_t s);
 int fr_from_mont(void* d_dst, const void* d_src, uint64_t n, hipStream_t s);
