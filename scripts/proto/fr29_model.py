@@ -61,8 +61,7 @@ def reduce_weak(a):
 def canon(a):
     t = reduce_weak(a)
     assert val(t) < 2 * R, val(t) / R
-    for _ in range(2):
-        if val(t) >= R: t = unpack(val(t) - R)
+    if val(t) >= R: t = unpack(val(t) - R)
     return val(t)
 rnd = random.Random(1)
 def lazy(bound):   # a lazily reduced representative below bound * r

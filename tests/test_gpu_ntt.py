@@ -22,6 +22,19 @@ def test_fft_matches_oracle(log_n):
     assert bytes(FFT_Fr.ifft(data)) == O.fr_ntt(data, log_n, True)
 
 
+@pytest.mark.parametrize("log_n", [4, 10, 12, 14])
+def test_fft_extreme_values(log_n):
+    """Largest residues everywhere (and sparse mixes of 0, 1, r - 1): the lazily reduced 29-bit-limb butterflies
+    (csrc/fr29.cuh) run at the top of their value bounds."""
+    n = 1 << log_n
+    top = (RC.FR_MODULUS - 1).to_bytes(32, "little")
+    rnd = random.Random(7 + log_n)
+    pool = [top, bytes(32), (1).to_bytes(32, "little"), (RC.FR_MODULUS - 2).to_bytes(32, "little"), ((1 << 254) + 5).to_bytes(32, "little")]
+    for data in (top * n, b"".join(rnd.choice(pool) for _ in range(n)), b"".join(top if i & 1 else bytes(32) for i in range(n))):
+        assert bytes(FFT_Fr.fft(data, log_n)) == O.fr_ntt(data, log_n, False)
+        assert bytes(FFT_Fr.ifft(data)) == O.fr_ntt(data, log_n, True)
+
+
 @pytest.mark.parametrize("log_n", [18, 20, 22])
 def test_fft_roundtrip_and_linearity_large(log_n):
     """Full benchmark sizes: fft o ifft = id (FFT.ml:88-96) and linearity -- size-independent."""

@@ -94,8 +94,8 @@ FF_INLINE Fr9 fr9_mul(const Fr9& a, const Fr9& b) {
     r.v[FR29_L - 1] = (uint32_t)acc;
     return r;
 }
-// value < 64 r -> the same value mod r, < 2r + (a little), exact limbs.  q = floor(top / ((r >> 232) + 1)) never
-// exceeds the true quotient and falls short of it by at most one.
+// value < 64 r -> the same value mod r, below 2r, exact limbs.  q = floor(top / ((r >> 232) + 1)) never exceeds
+// the true quotient and falls short of it by at most one (scripts/proto/fr29_model.py checks the extremes).
 FF_INLINE Fr9 fr9_reduce_weak(const Fr9& a) {
     uint32_t t[FR29_L];
 #pragma unroll
@@ -118,9 +118,8 @@ FF_INLINE Fr9 fr9_reduce_weak(const Fr9& a) {
 }
 // full reduction to [0, r) and the 8-word memory format
 FF_INLINE Fr fr9_canon_pack(const Fr9& a) {
-    Fr9 t = fr9_reduce_weak(a);                        // < 2r and a bit: two conditional subtractions
-#pragma unroll
-    for (int rep = 0; rep < 2; rep++) {
+    Fr9 t = fr9_reduce_weak(a);                        // < 2r: one conditional subtraction
+    {
         uint32_t u[FR29_L];
         int32_t bw = 0;
 #pragma unroll
