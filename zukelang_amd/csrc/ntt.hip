@@ -4,7 +4,7 @@
 // zeta_N = w^(2^32/N), w = 5^((r-1)/2^32) (FFT.ml:208-232): out[k] = sum_j a_j zeta_N^(jk).
 //
 // MI355X design: the log N butterfly stages are grouped into passes; each pass pulls tiles of
-// 1024 elements (32 KiB) into LDS in limb-major (SoA) layout -- lanes walk consecutive dwords, so
+// 1024 elements into LDS as 9 x 29-bit limbs (fr29.cuh; 36 KiB) in limb-major (SoA) layout -- lanes walk consecutive dwords, so
 // ds_read_b32 / ds_write_b32 are conflict-free for every butterfly distance >= 32 and 2-way at
 // worst below -- runs up to 10 stages there, and writes back, so HBM sees ceil(log N / 8..10)
 // round trips instead of log N.  Strided passes fetch rows of C >= 4 consecutive elements
