@@ -44,6 +44,22 @@ def test_constants_and_generators():
     assert pow(P.OMEGA, 1 << 32, P.R) == 1 and pow(P.OMEGA, 1 << 31, P.R) != 1
 
 
+def test_public_known_answers():
+    """Encodings of 2 G1, 3 G1 and 2 G2 in the zcash / IETF compressed format, as they circulate in public BLS12-381
+    test suites (e.g. the BLS public keys of the secret keys 2 and 3).  There is no network here, so they were written
+    down from memory and not fetched: 48- and 96-byte strings from outside this repository that the C oracle and the
+    big-int restatement both reproduce."""
+    kat1 = {2: "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e",
+            3: "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224"}
+    for k, hx in kat1.items():
+        assert P.g1_compress(P.pt_mul(P.G1, k)).hex() == hx
+        assert O.g1_compress(O.g1_mul(O.g1_generator(), frb(k))).hex() == hx
+    kat2 = ("aa4edef9c1ed7f729f520e47730a124fd70662a904ba1074728114d1031e1572c6c886f6b57ec72a6178288c47c33577"
+            "1638533957d540a9d2370f17cc7ed5863bc0b995b8825e0ee1ea1e1e4d00dbae81f14b0bf3611b78c952aacab827a053")
+    assert P.g2_compress(P.pt_mul(P.G2, 2)).hex() == kat2
+    assert O.g2_compress(O.g2_mul(O.g2_generator(), frb(2))).hex() == kat2
+
+
 def test_field_vs_bigint():
     for _ in range(50):
         a, b = rnd.randrange(P.R), rnd.randrange(P.R)
