@@ -65,14 +65,19 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
     uint32_t seg_start = pos;
     bool first = true;
     Xyzz<F> acc = xyzz_inf<F>();
+    // (G2: the products are calls, which drain outstanding loads anyway -- only the reference is fetched ahead there,
+    // the 24 look-ahead registers would be spilled)
     uint32_t v_next = sorted[pos];
-    PackedAff<F> p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+    PackedAff<F> p_next;
+    if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
     for (; pos < end; pos++) {
         const uint32_t v = v_next;
-        const PackedAff<F> pk = p_next;
+        PackedAff<F> pk;
+        if constexpr (PAIR) pk = packed_aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
+        else pk = p_next;
         if (pos + 1 < end) {
             v_next = sorted[pos + 1];
-            p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+            if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
         }
         if (pos == bend) {                              // run finished inside the chunk
             const bool complete = seg_start == bstart;
