@@ -29,6 +29,21 @@ FF_INLINE void lds_ntt_stages(NttTile& lds, const uint32_t* __restrict__ tw, uin
         const uint32_t hlm = (1u << log_hl) - 1;
         const uint64_t h = (uint64_t)1 << (log_hl + log_L);              // global half-distance
         const bool shrink = !INVERSE && (st & 3) == 3;
+        if (log_hl + log_L == 0) {
+            // span 2: the twiddle is w_2^0 = 1 and the product is skipped (a fifth of the stages of the fused tree levels).
+            // DIT: first stage, inputs < 2r, outputs < 6r like with the product.  DIF: last stage, y = u - v + 32 r stays
+            // below 56 r, which the pointwise product or the store that follows accepts.
+            for (uint32_t b = threadIdx.x; b < T / 2; b += NTT_THREADS) {
+                const uint32_t e = ((b >> log_hs) << (log_hs + 1)) | (b & (hs - 1));
+                const Fr9 u = fr9_lds_get(lds, e), v = fr9_lds_get(lds, e + hs);
+                Fr9 x = fr9_add(u, v);
+                if (shrink) x = fr9_reduce_weak(x);
+                fr9_lds_put(lds, e, x);
+                fr9_lds_put(lds, e + hs, INVERSE ? fr9_sub<2>(u, v) : fr9_sub<5>(u, v));
+            }
+            __syncthreads();
+            continue;
+        }
         for (uint32_t b = threadIdx.x; b < T / 2; b += NTT_THREADS) {
             uint32_t e = ((b >> log_hs) << (log_hs + 1)) | (b & (hs - 1));
             uint32_t rho = (e >> log_RS) & hlm;
