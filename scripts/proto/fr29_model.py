@@ -26,6 +26,10 @@ def add(a, b): return carry([x + y for x, y in zip(a, b)])
 def sub(a, b, ki):
     assert all(k >= y for k, y in zip(KR[ki], b)), "limb borrow"
     return carry([x + (k - y) for x, y, k in zip(a, b, KR[ki])])
+def sub_raw(a, b, ki):
+    r = [x + (k - y) for x, y, k in zip(a, b, KR[ki])]
+    assert all(0 <= x <= U32 for x in r)
+    return r
 def mul(a, b):
     acc, m, r = 0, [], [0] * L
     for k in range(L):
@@ -84,6 +88,7 @@ for it in range(20000):
 for it in range(3000):
     u, v, w = lazy(24), lazy(24), lazy(1)
     x = add(u, v); y = mul(sub(u, v, 5), w)
+    assert mul(sub_raw(u, v, 5), w) == y          # no carry pass before a product by a factor with exact limbs
     assert val(x) < 48 * R and val(reduce_weak(x)) < 2 * R and val(y) < 2 * R
     assert (val(y) * Rp - (val(u) - val(v)) * val(w)) % R == 0
     # DIT: u below 38 r, v below 42 r

@@ -67,6 +67,15 @@ template <int KI> FF_INLINE Fr9 fr9_sub(const Fr9& a, const Fr9& b) {
     fr9_carry(r.v);
     return r;
 }
+// The same without the carry pass: limbs up to 2^31, only good as the FIRST operand of a product whose second operand
+// has exact 29-bit limbs (a factor read from memory): 9 * 2^31 * 2^29 + 9 * 2^58 < 2^64.
+template <int KI> FF_INLINE Fr9 fr9_sub_raw(const Fr9& a, const Fr9& b) {
+    static_assert(KI >= 0 && KI < FR29_NK, "no such multiple of r");
+    Fr9 r;
+#pragma unroll
+    for (int i = 0; i < FR29_L; i++) r.v[i] = a.v[i] + (FR29_KR[KI][i] - b.v[i]);
+    return r;
+}
 // (a b + m r) / 2^261 < 2r for bounds A * B <= 64.  r = 1 mod 2^29: m_k = -acc mod 2^29 and m_k * r_0 = m_k.
 FF_INLINE Fr9 fr9_mul(const Fr9& a, const Fr9& b) {
     uint64_t acc = 0;

@@ -1,6 +1,7 @@
 // Radix-2 butterfly stages over one LDS-resident tile (shared by the NTT passes and the fused
 // basis-conversion levels of the Fr stage).  Layout: limb-major lds[9][NTT_T] of lazily reduced
-// 29-bit-limb integers (fr29.cuh); twiddles are read from memory in the 8-word format, as w * 2^261.
+// 29-bit-limb integers (fr29.cuh); twiddles are read from memory in the 8-word format, as w * 2^261 (a heap of
+// unpacked 36-byte entries measured 1-3 % slower: three loads per twiddle instead of two aligned ones).
 //
 // Bound discipline (value < B r, see fr29.cuh):
 //   DIT (inverse): inputs < 2r; x = u + v w < (B + 2) r, y = u - v w + 4r < (B + 4) r: after s <= 10 stages B <= 42.
@@ -59,7 +60,7 @@ FF_INLINE void lds_ntt_stages(NttTile& lds, const uint32_t* __restrict__ tw, uin
             } else {
                 x = fr9_add(u, v);
                 if (shrink) x = fr9_reduce_weak(x);
-                y = fr9_mul(fr9_sub<5>(u, v), w);
+                y = fr9_mul(fr9_sub_raw<5>(u, v), w);
             }
             fr9_lds_put(lds, e, x);
             fr9_lds_put(lds, e + hs, y);
