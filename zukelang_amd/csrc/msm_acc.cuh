@@ -48,6 +48,7 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
     uint64_t start64 = t * chunk;
     if (start64 >= N) return;
     uint32_t pos = (uint32_t)start64;
+    const uint32_t pos0 = pos;
     const uint32_t end = min(pos + chunk, N);
     // largest kb with offsets[kb] <= pos (then offsets[kb+1] > pos, so the bucket is non-empty)
     uint32_t lo = 0, hi = nb;
@@ -91,7 +92,10 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
         const Aff<F> p = packed_aff_unpack<F>(pk, (v >> 31) != 0);
         // The mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk.  G2 runs
         // as F = Fp2H, one Fp2 component per lane of a pair, which gives it the register footprint of G1.
-        xyzz_madd_impl(acc, p);
+        // Second step of the chunk (a wave-uniform test): every lane holds the identity (run border just crossed) or
+        // the single affine point of step one, so the 6-product addition of two affine points does.
+        if (pos == pos0 + 1) xyzz_mmadd_impl(acc, p);
+        else xyzz_madd_impl(acc, p);
     }
     {
         const bool complete = (seg_start == bstart) && (end == bend);
