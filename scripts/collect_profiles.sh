@@ -2,7 +2,7 @@
 # Collects the round's committed evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC traffic,
 # Pinocchio, window sweep.  Everything lands under gpurun_out/r01c/; copy what is judged into profiles/.
 set -o pipefail
-O=gpurun_out/r01e; mkdir -p $O
+O=gpurun_out/r01f; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 echo "== default bench"; timeout -k 10 400 python bench.py > $O/bench_2^16.json 2> $O/bench_2^16.err || exit 1
 for n in 18 20; do echo "== 2^$n"; timeout -k 10 400 python bench.py --log-n $n --no-cpu-baseline > $O/bench_2^$n.json 2> $O/bench_2^$n.err || exit 1; done
