@@ -9,7 +9,7 @@
 //
 // Bounds (value < B r, limbs 0..7 <= 2^29 + 7): the product needs A * B <= 64 (2^261 / r = 70) and returns < 2r;
 // a - b adds K r with K >= B_b + 1 a power of two (spread form: no limb borrows, the value stays >= r so the top limb
-// is exact after the carry pass).  The NTT stages keep B <= 48 by construction (ntt_lds.cuh).
+// is exact after the carry pass).  The NTT stages keep B <= 56 by construction (ntt_lds.cuh).
 #pragma once
 #include "ff.cuh"
 #include "fr29_consts.cuh"

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(uint32_t* __restrict__
     Fr9 sc;
     if (scale) sc = fr9_load(scale);
     for (uint32_t e = threadIdx.x; e < T; e += NTT_THREADS) {
-        Fr9 x = fr9_lds_get(lds, e);                     // < 48 r
+        Fr9 x = fr9_lds_get(lds, e);                     // < 56 r
         if (scale) x = fr9_mul(x, sc);
         const uint64_t g = gidx(e);
         if (io.add_low && (g & lenm) < half) x = fr9_add(x, fr9_load(io.lo + 8 * g));

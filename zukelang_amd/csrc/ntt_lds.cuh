@@ -6,7 +6,8 @@
 // Bound discipline (value < B r, see fr29.cuh):
 //   DIT (inverse): inputs < 2r; x = u + v w < (B + 2) r, y = u - v w + 4r < (B + 4) r: after s <= 10 stages B <= 42.
 //   DIF (forward): inputs < 3r; x = u + v doubles B, y = (u - v + 32 r) w < 2r; x is brought back below 2r after
-//                  every fourth stage (B = 3, 6, 12, 24 -> 48 -> 2), so u - v + 32 r < 56 r and the outputs are < 48 r.
+//                  every fourth stage (B = 3, 6, 12, 24 -> 48 -> 2), so u - v + 32 r < 56 r and the outputs are < 48 r
+//                  (< 56 r after the product-free last stage of a contiguous pass).
 #pragma once
 #include "fr29.cuh"
 
