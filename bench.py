@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """Groth16 constraints/sec on BLS12-381 (BASELINE.json metric) on N MI355X.
 
-A step = one Groth16 prove of the synthetic iterated-cubic R1CS with the
-proving key, the circuit and the witness already resident in HBM.  N = 1: n = 2^16 constraints
-(BASELINE.json configs[1]).  N > 1: proofs of n = 2^16 * N constraints whose three
-multi-scalar products are sharded by base points over the ranks (one process per GPU).  Proofs go in
-groups of N: rank j runs the Fr stage of the j-th proof of a group, one all-to-all per scalar vector over
-RCCL hands every rank its slice of every proof's scalars, the 768-byte partial sums of the group travel in
-one all-gather (EC addition is not an RCCL reduction operator) and are added on the GPU; per-GPU work per
-proof is fixed => "weak" scaling.
+Workload = Groth16 prove of the synthetic iterated-cubic R1CS with the proving key, the circuit and
+the witness already resident in HBM.  A STEP = `--proofs-per-step` (16) consecutive proofs of the pipelined prover
+(`--inflight` proofs in flight, one HIP stream each; the pipeline is NOT drained between steps), so that the default
+20 steps are >= 0.5 s of timed GPU work.  N = 1: n = 2^16 constraints (BASELINE.json configs[1]) is the headline
+`value`; the same run then times the other single-GPU configurations (2^18, 2^20 = config 3's size, optionally 2^22 =
+config 4's size on one GPU, and Pinocchio 2^18 = config 5) and reports them under `other_workloads`, each with its own
+parity check.  N > 1: proofs of n = 2^16 * N constraints (BASELINE config 4 = --log-n 19 at N = 8) whose three
+multi-scalar products are sharded by base points over the ranks (one process per GPU).  Proofs go in rounds: rank j runs
+the Fr stage of the proofs it owns, one all-to-all per scalar vector over RCCL hands every rank its slice of every
+proof's scalars, the 768-byte partial sums of a round travel in one all-gather (EC addition is not an RCCL reduction
+operator) and are added on the GPU; per-GPU work per proof is fixed => "weak" scaling.
+
+PARITY GATE: after every timed region the proof of the LAST timed (r, s) is compared with the oracle's trapdoor
+evaluation (exact at any n; CPU, outside the timed region).  A mismatch aborts the run: no throughput is printed for
+wrong proofs.
 
 Prints ONE JSON line on rank 0 (contract: see the round brief).
 """
@@ -26,6 +33,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before torch / HIP initiali
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUND = "r02"
 
 
 def seeded(seed):
@@ -34,15 +42,19 @@ def seeded(seed):
     return lambda: next(st)
 
 
-def pmc_traffic(kernel, n, world):
-    """HBM bytes per launch of `kernel` from the committed PMC collection (profiles/r01_pmc_traffic.json:
+def oracle():
+    """The CPU checker (oracle/): imported only by the parity gate and the cpu_baseline leg, never inside a timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    return O
+
+
+def pmc_traffic():
+    """HBM bytes per launch per kernel family from the committed PMC collection (profiles/r02_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md says).
-    Counters cannot be read from inside this process; the figure applies to the default workload only."""
-    if n != 1 << 16 or world != 1:
-        return None
+    Counters cannot be read from inside this process; the figures apply to the named workload only."""
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        return doc["kernels"][kernel]["hbm_bytes_per_launch"]
+        return json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_traffic.json")))
     except Exception:
         return None
 
@@ -52,8 +64,7 @@ def cpu_baseline():
     apply_powers, schoolbook mul / div_rem) on ONE host core, on a bounded sample: n = 128 (~15 s: the
     literal algorithm is O(m n) scalar multiplications, 4x the work of n = 64).
     Also used as a checker: the GPU proof of the same sample must be byte-identical."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
+    O = oracle()
     from zukelang_amd import r1cs as RC
     from zukelang_amd.groth16 import Groth16, PKey
     n = 128
@@ -78,13 +89,277 @@ def cpu_baseline():
                       "iterated-cubic R1CS at n=128, m=130; %.2f s; GPU proof of the sample byte-identical" % dt}
 
 
+def collect_families(L, _lib, nproofs):
+    out = {}
+    buf = C.create_string_buffer(8192)
+    _lib.check(L.zk_profile_names(buf, 8192))
+    for name in buf.value.decode().split(","):
+        if not name:
+            continue
+        ms, cnt = C.c_double(), C.c_uint64()
+        _lib.check(L.zk_profile_get(name.encode(), C.byref(ms), C.byref(cnt)))
+        out[name] = {"ms_total": ms.value, "launches": cnt.value, "ms_per_proof": ms.value / nproofs}
+    return out
+
+
+# ALGORITHMIC bytes per (scalar, point) pair of a multi-scalar product: 32 B scalar + the affine point.
+PAIR_BYTES = {"g1": 128.0, "g2": 224.0}
+# Field products per group addition in the accumulate kernels: the multiplier-bound model.
+MADD_PRODUCTS = {"g1": 9.04, "g2": 28.0}
+
+
+def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windows, peak_products, traffic, workload_key):
+    """One roofline object per MSM bucket-accumulation family (`msm_accumulate_g1` covers the two G1 products A and C of
+    a proof in ONE launch, `msm_accumulate_g2` the G2 product B).  achieved = algorithmic bytes per launch / average launch
+    duration, both in the timed region (launches stretched by the other proofs in flight) and with one proof in flight."""
+    objs = {}
+    for key, fam in (("g1", "msm_accumulate_g1"), ("g2", "msm_accumulate_g2")):
+        alg_per_proof = PAIR_BYTES[key] * pairs[key] / world
+        o = {"bound": "hbm", "kernel": fam, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_proof": alg_per_proof}
+        for tag, fams, nproofs in (("timed_region", fam_timed, n_timed), ("one_proof_in_flight", fam_alone, n_alone)):
+            members = [k for k in fams if k == fam or k.startswith(fam + ":")]          # sub-steps of a family are "family:step"
+            if not members or not fams[fam if fam in fams else members[0]]["launches"]:
+                continue
+            ms_per_proof = sum(fams[k]["ms_total"] for k in members) / nproofs
+            launches_per_proof = max(fams[k]["launches"] for k in members) / nproofs
+            avg_ms = ms_per_proof / launches_per_proof
+            bytes_per_launch = alg_per_proof / launches_per_proof
+            ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            madds = alg_per_proof / PAIR_BYTES[key] * windows            # one group addition per (point, window) digit
+            mul_equiv = madds * MADD_PRODUCTS[key] / (ms_per_proof * 1e-3) / 1e9
+            o[tag] = {"avg_launch_ms": avg_ms, "launches_per_proof": launches_per_proof, "algorithmic_bytes_per_launch": bytes_per_launch,
+                      "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                      "alu": {"unit": "G Fp products/s (XYZZ mixed-addition equivalents)", "achieved": mul_equiv, "peak_measured": peak_products,
+                              "frac": mul_equiv / peak_products if peak_products else None}}
+        t = None
+        if traffic and workload_key in traffic.get("workloads", {}):
+            t = traffic["workloads"][workload_key].get(fam, {}).get("hbm_bytes_per_launch")
+        o["traffic"] = t
+        if "timed_region" in o:
+            o["achieved"], o["frac"] = o["timed_region"]["achieved"], o["timed_region"]["frac"]
+        elif "one_proof_in_flight" in o:
+            o["achieved"], o["frac"] = o["one_proof_in_flight"]["achieved"], o["one_proof_in_flight"]["frac"]
+        objs[key] = o
+    return objs
+
+
+def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, world, dist, lagrange=False, replicated_fr=False, events=True):
+    """Times `steps` steps of `--proofs-per-step` proofs at n = 2^log_n * world; returns the result dict (rank 0 checks parity)."""
+    from zukelang_amd import r1cs as RC
+    from zukelang_amd.groth16 import Groth16
+    t_setup = time.perf_counter()
+    n = (1 << log_n) * world
+    cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
+    rng = seeded(0x5EED0002)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, _vk = Groth16.keygen(lambda: next(it), cs, lagrange=lagrange)
+    prover = Groth16(cs, pk, rank, world, lagrange=lagrange)
+    prover.set_witness(w)
+    pps = args.proofs_per_step
+    nproofs = steps * pps
+    nwarm = warmup * pps
+    rs = [(rng(), rng()) for _ in range(min(nproofs + nwarm, 64) + 8)]       # recycled: the parity gate checks the last one used
+
+    def sync():
+        _lib.check(L.zk_sync())
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    depth = max(1, min(inflight, 15))      # the chip runs 16 hardware queues side by side: 15 slots + the context stream
+    if world > 1:
+        depth = min(depth, 8)      # sharded proofs: the host also runs an all-gather + combine per proof
+    prover.reserve_slots(depth if world == 1 or replicated_fr else 1)          # setup, not warm-up: slots are otherwise created at first use
+    group = None
+    if world > 1 and not replicated_fr:
+        from zukelang_amd.groth16 import GroupProver
+        group = GroupProver(prover)
+    setup_s = time.perf_counter() - t_setup
+
+    def run(first, count):
+        """count proofs; proof i uses rs[(first + i) % len(rs)].  One GPU: `depth` of them in flight, proof i on slot i % depth.
+        N > 1: rounds of `group.batch` (distributed Fr stage), each rank finishing the proofs it owns.
+        Returns (last proof this rank holds, index into rs of that proof)."""
+        if group is not None:
+            got = group.prove_many([rs[(first + i) % len(rs)] for i in range(count)], combine_all=False)
+            mine = [(g, (first + i) % len(rs)) for i, g in enumerate(got) if g is not None]
+            return mine[-1] if mine else (None, None)
+        last = None
+        for i in range(count):
+            if depth == 1:
+                last = prover.prove_rs(None, *rs[(first + i) % len(rs)])
+                continue
+            if i >= depth:
+                last = prover.prove_wait(i % depth)
+            prover.prove_async(None, *rs[(first + i) % len(rs)], i % depth)
+        if depth > 1:
+            for i in range(max(0, count - depth), count):
+                last = prover.prove_wait(i % depth)
+        return last, (first + count - 1) % len(rs)
+
+    run(0, max(nwarm, 1))
+    sync()
+    # A box that has been idle starts in a low-power state and needs seconds of load before its clocks
+    # settle (first bench of a fresh box: 8.4 ms/proof against 2.6 ms once warm).  Untimed: keep proving
+    # until three consecutive batches are within 5 % of the best one, at most --settle seconds.
+    t_settle = time.perf_counter()
+    best, stable, batches = None, 0, 0
+    while settle > 0 and (batches < 6 if dist is not None else (time.perf_counter() - t_settle < settle and stable < 3)):
+        batches += 1          # N > 1: a fixed count, every rank must run the same number of (collective) proofs
+        t0 = time.perf_counter()
+        run(0, depth)
+        sync()
+        bt = time.perf_counter() - t0
+        stable = stable + 1 if best is not None and bt <= 1.05 * best else 0
+        best = bt if best is None else min(best, bt)
+    # the MSM accumulate kernels are bracketed by HIP events on their own streams DURING the timed region
+    # (level 1: two recycled event records per launch; nothing synchronises)
+    _lib.check(L.zk_profile_reset())
+    _lib.check(L.zk_profile_enable(1 if events else 0))
+    t0 = time.perf_counter()
+    proof, proof_idx = run(nwarm, nproofs)
+    sync()
+    dt = time.perf_counter() - t0
+    _lib.check(L.zk_profile_enable(0))
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fam_timed = collect_families(L, _lib, nproofs)           # accumulate kernels inside the timed region (empty with --no-live-events)
+
+    # ---- single-proof latency and every kernel family un-overlapped: one proof at a time, untimed w.r.t. `value`
+    n_alone = 4 if log_n <= 20 else 2
+    lat = None
+    fam_alone = {}
+    if world == 1:
+        _lib.check(L.zk_profile_reset())
+        prover.prove_rs(None, *rs[0])
+        t1 = time.perf_counter()
+        for i in range(n_alone):
+            prover.prove_rs(None, *rs[1 + i])
+        lat = (time.perf_counter() - t1) / n_alone
+        _lib.check(L.zk_profile_enable(2))
+        for i in range(n_alone):
+            prover.prove_rs(None, *rs[1 + i])
+        fam_alone = collect_families(L, _lib, n_alone)
+        _lib.check(L.zk_profile_enable(0))
+        _lib.check(L.zk_profile_reset())
+
+    # ---- PARITY GATE (CPU oracle, outside every timed region): the last timed proof this rank holds
+    parity = None
+    if proof is not None and not args.no_parity_gate:
+        O = oracle()
+        frs = lambda xs: bytes(RC.fr_bytes(xs))
+        csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+        r_, s_ = rs[proof_idx]
+        t2 = time.perf_counter()
+        exp = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), frs([r_]), frs([s_]))
+        if (proof.a, proof.b, proof.c) != exp:
+            raise SystemExit("PARITY FAILURE: the last timed proof at n = 2^%d x %d differs from the oracle's trapdoor evaluation -- no throughput reported" % (log_n, world))
+        parity = {"checked": "last timed proof == oracle groth16_prove_trapdoor (exact at any n), bytes of a | b | c", "oracle_s": round(time.perf_counter() - t2, 2)}
+
+    p1 = 3 + (n + 2) + (n - 1) + cs.n_mid
+    p2 = 2 + (n + 2)
+    pairs = {"g1": (n + 2) + p1, "g2": p2}          # scalar-point pairs actually multiplied per proof: A (n+2) + C (the whole pool) | B
+    res = {"log_n": log_n, "constraints": n, "variables": cs.m, "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3,
+           "ms_per_step": dt / steps * 1e3, "timed_s": dt, "timed_proofs": nproofs, "proofs_in_flight": group.batch if group is not None else depth,
+           "single_proof_latency_ms": None if lat is None else lat * 1e3, "single_proof_value": None if lat is None else n / lat,
+           "setup_s": round(setup_s, 1), "parity": parity, "pairs": pairs, "p1": p1, "p2": p2,
+           "fam_timed": fam_timed, "fam_alone": fam_alone, "n_alone": n_alone, "nproofs": nproofs,
+           "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_alone.items())},
+           "proof_compressed_hex": proof.to_compressed().hex() if proof is not None else None,
+           "group_batch": group.batch if group is not None else None}
+    if group is not None:
+        # exchange volume per proof and rank (device to device over xGMI): three scalar vectors, 32 B per element
+        res["exchange"] = {"all_to_all_bytes_per_proof_sent_by_owner": 32 * (2 * p1 + p2), "all_gather_bytes_per_proof_per_rank": 768,
+                           "slice_points_g1": [hi - lo for lo, hi in group.bounds1],
+                           "slice_points_g2": [hi - lo for lo, hi in group.bounds2]}
+    prover.close()
+    del prover
+    return res
+
+
+def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
+    """BASELINE config 5: Pinocchio Protocol-2 ZK prove (pinocchio.ml:427-514), witness resident, proofs pipelined over slots."""
+    from zukelang_amd import r1cs as RC, pinocchio as PIN
+    n = 1 << log_n
+    cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
+    st = RC.fr_stream(0x5EED0003)
+    tox = [next(st) for _ in range(8)]
+    it = iter(tox)
+    pk, _vk = PIN.ZK.keygen(lambda: next(it), cs)
+    prover = PIN.ZK(cs, pk)
+    prover.set_witness(RC.fr_bytes(w))
+    depth = inflight
+    prover.reserve_slots(depth)
+    ds = [[next(st) for _ in range(3)] for _ in range(16)]
+
+    def run(count):
+        last = None
+        for i in range(count):
+            if i >= depth:
+                last = prover.prove_wait(i % depth)
+            prover.prove_async(*ds[i % len(ds)], i % depth)
+        for i in range(max(0, count - depth), count):
+            last = prover.prove_wait(i % depth)
+        return last, (count - 1) % len(ds)
+    run(2 * depth)
+    _lib.check(L.zk_sync())
+    t0 = time.perf_counter()
+    proof, idx = run(nproofs)
+    _lib.check(L.zk_sync())
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(2):
+        prover.prove_with(w, *ds[i])
+    lat = (time.perf_counter() - t1) / 2
+    parity = None
+    if not args.no_parity_gate:
+        O = oracle()
+        frs = lambda xs: bytes(RC.fr_bytes(xs))
+        csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+        exp = O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(tox), *(frs([x]) for x in ds[idx]))
+        if proof.to_bytes() != exp:
+            raise SystemExit("PARITY FAILURE: the last timed Pinocchio proof differs from the oracle's trapdoor evaluation")
+        parity = {"checked": "last timed proof == oracle pinocchio_prove_trapdoor, 960 bytes"}
+    prover.close()
+    m_mid = cs.n_mid
+    alg = 5 * 128 * m_mid + 2 * 128 * cs.m + 2 * 128 * n + 2 * 224 * m_mid + 192 * n       # SURVEY.md 8d: 1792 n B at m_mid = m = n
+    return {"workload": "pinocchio_zk_prove (BASELINE config 5), iterated-cubic R1CS, key+circuit+witness resident in HBM", "log_n": log_n, "constraints": n,
+            "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3, "timed_s": dt, "timed_proofs": nproofs,
+            "proofs_in_flight": depth, "single_proof_latency_ms": lat * 1e3, "single_proof_note": "one at a time, witness handed over as a host buffer",
+            "prove_algorithmic_bytes_per_constraint": alg / n, "prove_hbm_frac": alg / (dt / nproofs) / 1e9 / HBM_PEAK_GBS, "parity": parity}
+
+
+def summarize(res, world, peak_products, traffic, lagrange):
+    """Public form of one Groth16 workload result: throughput, latency, both accumulate rooflines, whole-prove HBM fraction."""
+    windows = 255 // int(os.environ.get("ZK_MSM_WINDOW", "16")) + 1        # resident keys: c = 16 from 2^16 points up
+    key = "groth16_2^%d" % res["log_n"] + ("_lagrange" if lagrange else "")
+    roofs = roofline_objects(res["fam_timed"], res["nproofs"], res["fam_alone"], res["n_alone"], res["pairs"], world, windows, peak_products, traffic, key)
+    out = {k: res[k] for k in ("log_n", "constraints", "variables", "value", "unit", "ms_per_proof", "timed_s", "timed_proofs", "proofs_in_flight",
+                               "single_proof_latency_ms", "single_proof_value", "setup_s", "parity", "kernel_ms_per_proof")}
+    out["prove_algorithmic_bytes_per_constraint"] = 928
+    out["prove_hbm_frac"] = 928.0 * res["constraints"] / (res["ms_per_proof"] * 1e-3) / 1e9 / HBM_PEAK_GBS / world
+    out["roofline_g1"], out["roofline_g2"] = roofs.get("g1"), roofs.get("g2")
+    return out, roofs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed proofs; the timed region includes filling and draining the pipeline of proofs in flight (about one proof latency, 5 ms at 2^16: -5 %% at 20 steps, -1 %% at 100)")
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = --proofs-per-step consecutive proofs of the pipelined prover")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps")
+    ap.add_argument("--proofs-per-step", type=int, default=16)
+    ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU of the headline workload")
+    ap.add_argument("--sizes", default="18,20", help="one GPU: further log2 sizes timed in the same run and reported under other_workloads ('' = none; add 22 for config 4's size: ~2 min of host-side key generation)")
+    ap.add_argument("--no-pinocchio", action="store_true", help="skip the Pinocchio 2^18 workload (config 5) of the default run")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs): same as --sizes '' --no-pinocchio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the oracle comparison of the last timed proof (profiling runs only)")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
                     "not the reference's key format -- the default and the headline use the tau-power key)")
@@ -115,170 +390,65 @@ def main():
             local_rank = local_rank % max(ndev, 1)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
+    if args.lagrange_key and world > 1:
+        raise SystemExit("--lagrange-key is a single-GPU option")
 
-    from zukelang_amd import _lib, r1cs as RC
-    from zukelang_amd.groth16 import Groth16
+    from zukelang_amd import _lib
     L = _lib.lib()
     _lib.check(L.zk_init(local_rank))
 
-    n = (1 << args.log_n) * world
-    cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
-    rng = seeded(0x5EED0002)
-    if args.lagrange_key and world > 1:
-        raise SystemExit("--lagrange-key is a single-GPU option")
-    pk, _vk = Groth16.keygen(rng, cs, lagrange=args.lagrange_key)
-    prover = Groth16(cs, pk, rank, world, lagrange=args.lagrange_key)
-    prover.set_witness(w)
-    rs = [(rng(), rng()) for _ in range(args.steps + args.warmup + 8)]
+    head = bench_groth16(args, L, _lib, args.log_n, args.steps, args.warmup, args.inflight, args.settle, rank, world, dist,
+                         lagrange=args.lagrange_key, replicated_fr=args.replicated_fr, events=not args.no_live_events)
+    peak = C.c_double()
+    _lib.check(L.zk_bench_field_mul(1, 2000, C.byref(peak)))       # the library's dependent-chain product benchmark on this chip, in this process
+    traffic = pmc_traffic()
+    head_pub, roofs = summarize(head, world, peak.value, traffic, args.lagrange_key)
 
-    def sync():
-        _lib.check(L.zk_sync())
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    depth = max(1, min(args.inflight, 15))      # the chip runs 16 hardware queues side by side: 15 slots + the context stream
-    if world > 1:
-        depth = min(depth, 8)      # sharded proofs: the host also runs an all-gather + combine per proof
-
-    prover.reserve_slots(depth if world == 1 or args.replicated_fr else 1)          # setup, not warm-up: slots are otherwise created at first use
-
-    group = None
-    if world > 1 and not args.replicated_fr:
-        from zukelang_amd.groth16 import GroupProver
-        group = GroupProver(prover)
-
-    def run(first, count):
-        """count proofs.  One GPU: `depth` of them in flight, proof i on slot i % depth.  N > 1: groups of N
-        (distributed Fr stage), each rank finishing the proofs it owns."""
-        if group is not None:
-            got = group.prove_many([rs[(first + i) % len(rs)] for i in range(count)], combine_all=False)
-            mine = [g for g in got if g is not None]
-            return mine[-1] if mine else None
-        last = None
-        for i in range(count):
-            if depth == 1:
-                last = prover.prove_rs(None, *rs[first + i])
+    others = []
+    if world == 1 and rank == 0 and not args.headline_only:
+        for tok in [t for t in args.sizes.split(",") if t.strip()]:
+            ln = int(tok)
+            if ln == args.log_n:
                 continue
-            if i >= depth:
-                last = prover.prove_wait(i % depth)
-            prover.prove_async(None, *rs[first + i], i % depth)
-        if depth > 1:
-            for i in range(max(0, count - depth), count):
-                last = prover.prove_wait(i % depth)
-        return last
-
-    run(0, args.warmup)
-    sync()
-    # A box that has been idle starts in a low-power state and needs seconds of load before its clocks
-    # settle (first bench of a fresh box: 8.4 ms/proof against 2.6 ms once warm).  Untimed: keep proving
-    # until three consecutive batches are within 5 % of the best one, at most --settle seconds.
-    t_settle = time.perf_counter()
-    best, stable = None, 0
-    batches = 0
-    while args.settle > 0 and (batches < 6 if dist is not None else (time.perf_counter() - t_settle < args.settle and stable < 3)):
-        batches += 1          # N > 1: a fixed count, every rank must run the same number of (collective) proofs
-        t0 = time.perf_counter()
-        run(0, depth)
-        sync()
-        bt = time.perf_counter() - t0
-        stable = stable + 1 if best is not None and bt <= 1.05 * best else 0
-        best = bt if best is None else min(best, bt)
-    # the dominant kernels (MSM accumulate) are bracketed by HIP events on their own streams DURING the
-    # timed region (level 1: two recycled event records per launch; nothing synchronises)
-    _lib.check(L.zk_profile_reset())
-    _lib.check(L.zk_profile_enable(0 if args.no_live_events else 1))
-    t0 = time.perf_counter()
-    proof = run(args.warmup, args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    _lib.check(L.zk_profile_enable(0))
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    def collect(nproofs):
-        out = {}
-        buf = C.create_string_buffer(4096)
-        _lib.check(L.zk_profile_names(buf, 4096))
-        for name in buf.value.decode().split(","):
-            if not name:
-                continue
-            ms, cnt = C.c_double(), C.c_uint64()
-            _lib.check(L.zk_profile_get(name.encode(), C.byref(ms), C.byref(cnt)))
-            out[name] = {"ms_total": ms.value, "launches": cnt.value, "ms_per_proof": ms.value / nproofs}
-        return out
-
-    fam = collect(args.steps)           # accumulate kernels, measured inside the timed region (empty with --no-live-events)
-    # every family, in a separate un-timed pass (one proof at a time: un-overlapped between proofs)
-    _lib.check(L.zk_profile_reset())
-    _lib.check(L.zk_profile_enable(2))
-    for i in range(4):
-        prover.prove_rs(None, *rs[args.warmup + args.steps + i])
-    fam_all = collect(4)
-    _lib.check(L.zk_profile_enable(0))
-    _lib.check(L.zk_profile_reset())
-
-    # ---- roofline of the dominant kernel family (HBM bound: integer/byte work, no MFMA)
-    p1 = 3 + (n + 2) + (n - 1) + cs.n_mid
-    p2 = 2 + (n + 2)
-    # ALGORITHMIC bytes (SURVEY.md 8d): G1 MSM 128 B per (scalar, point) pair actually multiplied, G2 224 B.  Per proof the
-    # G1 accumulate kernel handles A (n+2 pairs) and C (the whole pool, p1 pairs) -- in ONE launch since both products share
-    # the base set -- and the G2 kernel B (p2 pairs).  Bytes per launch = bytes per proof * proofs / launches counted.
-    alg = {"msm_accumulate_g1": 128.0 * ((n + 2) + p1) / world, "msm_accumulate_g2": 224.0 * p2 / world}
-    roof = None
-    nproofs = args.steps
-    if not fam:
-        fam, nproofs = fam_all, 4
-    cands = [k for k in alg if k in fam]
-    if cands:
-        dom = max(cands, key=lambda k: fam[k]["ms_total"])
-        avg_ms = fam[dom]["ms_total"] / fam[dom]["launches"]
-        bytes_per_launch = alg[dom] * nproofs / fam[dom]["launches"]
-        ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        # the bound that actually binds: the integer multiplier.  One G1 mixed addition = 6 products + 2 squares +
-        # 1 fused double product = 3542 v_mad_u64_u32 = 9.04 full products (392 each); one G2 mixed addition on a
-        # lane pair = 2 x (8 fused double products + 2 products) = 28 full products.  Peak = the library's own
-        # dependent-chain benchmark of the product (zk_bench_field_mul) on this chip, in this process.
-        peak = C.c_double()
-        _lib.check(L.zk_bench_field_mul(1, 2000, C.byref(peak)))
-        windows = 255 // int(os.environ.get("ZK_MSM_WINDOW", "16")) + 1        # resident keys: c = 16 from 2^16 points up
-        madds = bytes_per_launch / (128.0 if dom.endswith("g1") else 224.0) * windows   # one mixed addition per (point, window) digit
-        per_madd = 9.04 if dom.endswith("g1") else 28.0
-        mul_equiv = madds * per_madd / (avg_ms * 1e-3) / 1e9
-        # the same kernel with ONE proof in flight (the un-timed pass above): launch durations not stretched by the other
-        # proofs' kernels sharing the SIMDs -- the figure that speaks about the kernel itself
-        alone = None
-        if dom in fam_all and fam_all[dom]["launches"]:
-            a_ms = fam_all[dom]["ms_total"] / fam_all[dom]["launches"]
-            a_bytes = alg[dom] * 4 / fam_all[dom]["launches"]
-            a_mul = a_bytes / (128.0 if dom.endswith("g1") else 224.0) * windows * per_madd / (a_ms * 1e-3) / 1e9
-            alone = {"avg_launch_ms": a_ms, "achieved_GBps": a_bytes / (a_ms * 1e-3) / 1e9, "alu_achieved": a_mul, "alu_frac": a_mul / peak.value}
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom, n, world), "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                "alu": {"unit": "G Fp products/s", "achieved": mul_equiv, "peak_measured": peak.value, "frac": mul_equiv / peak.value},
-                "one_proof_in_flight": alone,
-                "note": "algorithmic bytes = 128 B (G1) / 224 B (G2) per scalar-point pair; the kernel is bound by the integer multiplier, not by HBM "
-                        "(~9 Montgomery products of ~490 instructions per pair): see the `alu` object; traffic > algorithmic because the resident key "
-                        "stores one precomputed point per (point, window) (96 B gathered per pair) and partial sums are written in a 256 B raw layout, see DESIGN.md"}
+            per = {18: 80, 20: 24, 22: 8}.get(ln, max(8, int(0.6 / (2e-3 * (1 << max(0, ln - 16))))))       # proofs for >= 0.5 s at last round's rates
+            infl = args.inflight if ln <= 20 else 4
+            steps = max(1, (per + args.proofs_per_step - 1) // args.proofs_per_step)
+            r = bench_groth16(args, L, _lib, ln, steps, 1 if ln <= 18 else 0, infl, args.settle if ln <= 18 else min(args.settle, 2.0), 0, 1, None,
+                              lagrange=args.lagrange_key, events=not args.no_live_events)
+            pub, _ = summarize(r, 1, peak.value, traffic, args.lagrange_key)
+            pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
+            others.append(pub)
+        if not args.no_pinocchio:
+            others.append(bench_pinocchio(args, L, _lib, 18, 48, 8))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
     if rank == 0:
+        # the dominant kernel = the accumulate family with the larger UN-OVERLAPPED time per proof (one proof in flight); N > 1: the
+        # timed region's own events (no un-overlapped pass there)
+        def weight(k):
+            o = roofs[k]
+            t = o.get("one_proof_in_flight") or o.get("timed_region")
+            return t["avg_launch_ms"] * t["launches_per_proof"] if t else 0.0
+        cands = [k for k in roofs if roofs[k].get("one_proof_in_flight") or roofs[k].get("timed_region")]
+        roof = None
+        if cands:
+            dom = max(cands, key=weight)
+            roof = dict(roofs[dom])
+            roof["dominant_by"] = "un-overlapped time per proof (one proof in flight)" if roofs[dom].get("one_proof_in_flight") else "timed-region events"
+            roof["note"] = ("algorithmic bytes = 128 B (G1) / 224 B (G2) per scalar-point pair; achieved / frac are those of the TIMED REGION (launches stretched by the "
+                            "other proofs in flight), `one_proof_in_flight` the un-overlapped ones; the kernel is bound by the integer multiplier, not by HBM: see `alu`; "
+                            "traffic (PMC, profiles/%s_pmc_traffic.json) > algorithmic because the resident key stores one precomputed point per (point, window), see DESIGN.md" % PROFILE_ROUND)
         out = {
             "metric": "Groth16 constraints/sec on BLS12-381 at 1/2/4/8 MI355X; proof bit-exact",
-            "value": n * args.steps / dt,
+            "value": head["value"],
             "unit": "constraints/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -286,19 +456,28 @@ def main():
             "data": "synthetic",
             "config": {"workload": "groth16_prove, iterated-cubic R1CS (u -> u^3+u+3), BLS12-381, key+circuit+witness resident in HBM"
                                    + (", LAGRANGE-FORM KEY EXTENSION (not the reference key format)" if args.lagrange_key else ""),
-                       "constraints": n, "variables": cs.m, "proofs_in_flight": group.batch if group is not None else depth, "constraints_per_gpu": 1 << args.log_n,
-                       "sharding": ("MSM base points over ranks; Fr stage of proof j of each group of N on rank j + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
-                                    if group is not None else "MSM base points over ranks, Fr stage replicated; all-gather of 768 B partial sums + local EC reduce") if world > 1 else "single GPU",
+                       "step": "%d consecutive proofs of the pipelined prover (pipeline not drained between steps)" % args.proofs_per_step,
+                       "proofs_per_step": args.proofs_per_step, "timed_proofs": head["timed_proofs"], "timed_s": head["timed_s"],
+                       "constraints": head["constraints"], "variables": head["variables"], "proofs_in_flight": head["proofs_in_flight"], "constraints_per_gpu": 1 << args.log_n,
+                       "sharding": ("MSM base points over ranks; Fr stage of a proof on its owner rank + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
+                                    if head["group_batch"] is not None else "MSM base points over ranks, Fr stage replicated; all-gather of 768 B partial sums + local EC reduce") if world > 1 else "single GPU",
+                       "exchange": head.get("exchange"),
                        "rehearsal_ranks_share_gpus": rehearsal,
                        "prove_algorithmic_bytes_per_constraint": 928,
-                       "prove_hbm_frac": 928.0 * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS / world},
+                       "prove_hbm_frac": head_pub["prove_hbm_frac"]},
+            "ms_per_proof": head["ms_per_proof"],
+            "single_proof_latency_ms": head["single_proof_latency_ms"],
+            "single_proof_value": head["single_proof_value"],
+            "parity": head["parity"],
             "roofline": roof,
+            "roofline_g1": roofs.get("g1"),
+            "roofline_g2": roofs.get("g2"),
             "cpu_baseline": cpu,
-            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_all.items())},
-            "proof_compressed_hex": proof.to_compressed().hex() if proof is not None else None,     # N > 1: rank 0 prints a proof it combined itself
+            "kernel_ms_per_proof": head["kernel_ms_per_proof"],
+            "other_workloads": others,
+            "proof_compressed_hex": head["proof_compressed_hex"],     # N > 1: rank 0 prints a proof it combined itself
         }
         print(json.dumps(out))
-    prover.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -224,7 +224,8 @@ int zk_profile_enable(int level);   /* 0 off | 1 the MSM accumulate kernels only
 int zk_profile_reset(void);
 int zk_profile_get(const char* family, double* total_ms, uint64_t* launches);
 int zk_profile_names(char* buf, size_t buflen);   /* comma-separated family names */
-int zk_sync(void);                                 /* hipStreamSynchronize on the library's streams */
+int zk_sync(void);                                 /* waits for everything the library has enqueued on this device, the per-slot streams of
+                                                      proofs in flight included (hipDeviceSynchronize) */
 /* Throughput of the register-resident Montgomery multiplier (kind 0 = Fr, 1 = Fp): ALU ceiling.
  * kind | 4: one wave on the whole chip (dependent-chain latency). */
 int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s);

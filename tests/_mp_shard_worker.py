@@ -88,6 +88,11 @@ def main():
                 a = O.g1_add(a, part[:96]); c = O.g1_add(c, part[96:192]); b = O.g2_add(b, part[192:])
             ej = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rs[j][0]), P.fr_to_bytes(rs[j][1]))
             assert (a, b, c) == ej, "rank %d: distributed-Fr group proof %d differs" % (rank, j)
+        # collective error agreement: a failure only ONE rank sees reaches every rank before the next collective
+        from zukelang_amd.groth16 import agree_on_status
+        assert agree_on_status(0) == 0
+        assert agree_on_status(-4 if rank == world - 1 else 0) == -4
+        assert agree_on_status(-5 if rank == 0 else (-4 if rank == 1 else 0)) == -5
     else:
         from zukelang_amd import _lib
         from zukelang_amd.groth16 import Groth16
@@ -121,6 +126,21 @@ def main():
         assert [i for i, x in enumerate(own) if x is not None] == mine
         for i in mine:
             assert (own[i].a, own[i].b, own[i].c) == tuple(getattr(got[i], f) for f in "abc")
+        # an unsatisfied witness: only the OWNER of a proof sees ZK_ERR_REMAINDER (QAP.ml:134); every rank must raise
+        # before the round's all-to-all instead of hanging in it, and the prover must stay usable afterwards
+        w_bad = list(w)
+        w_bad[3] = (w_bad[3] + 1) % RC.FR_MODULUS
+        prover.set_witness(w_bad)
+        try:
+            gp.prove_many(rs[:1])            # ONE proof: a single rank owns it
+            raise SystemExit("rank %d: bad witness was not reported" % rank)
+        except AssertionError:
+            pass
+        prover.set_witness(w)
+        again = gp.prove_many(rs[:world])
+        for (rr, ss), pr in zip(rs[:world], again):
+            e2 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
+            assert (pr.a, pr.b, pr.c) == e2, "rank %d: proof after the failed round differs" % rank
         prover.close()
     dist.barrier()
     if rank == 0:

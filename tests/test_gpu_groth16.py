@@ -210,3 +210,53 @@ def test_lagrange_form_key_gives_the_same_proofs(maker):
     with pytest.raises(AssertionError):
         lag.prove_rs(w_bad, rng(), rng())
     std.close(); lag.close()
+
+
+def test_config3_window_sweep_is_parity_checked():
+    """BASELINE config 3 (window-size sweep at 2^20 constraints) under parity: the proof must be the
+    trapdoor oracle's bytes at every window width the sweep visits, not only at the default c = 16."""
+    n = 1 << 20
+    cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0001)))
+    rng = seeded_rng(0x5EED0002)
+    toxic = [rng() for _ in range(5)]
+    r, s = rng(), rng()
+    L, R_, Oo = csrs(cs)
+    e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
+    pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
+    expect = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    old = os.environ.get("ZK_MSM_WINDOW")
+    try:
+        for c in SWEEP_WINDOWS:
+            os.environ["ZK_MSM_WINDOW"] = str(c)          # read by the library when the key's base tables are built
+            prover = Groth16(cs, pk)
+            proof = prover.prove_rs(w, r, s)
+            prover.close()
+            assert (proof.a, proof.b, proof.c) == expect, "window %d" % c
+    finally:
+        if old is None:
+            os.environ.pop("ZK_MSM_WINDOW", None)
+        else:
+            os.environ["ZK_MSM_WINDOW"] = old
+
+
+SWEEP_WINDOWS = (12, 14, 15)
+
+
+def test_prove_from_the_interchange_files():
+    """Scope row f3: the README circuit and its solution read from the binary .r1cs / .wit fixtures
+    (zukelang_amd/r1cs_file.py; the CSR form of circuit.ml:73-75's gates) prove to the literal oracle's bytes."""
+    from zukelang_amd import r1cs_file as RF
+    gold = os.path.dirname(GOLDEN)
+    cs, names = RF.read_r1cs(bytes.fromhex(open(os.path.join(gold, "readme_circuit.r1cs.hex")).read().strip()))
+    sol = RF.read_witness(bytes.fromhex(open(os.path.join(gold, "readme_circuit_x3.wit.hex")).read().strip()))
+    assert names[0] == ("ONE", 1) and (cs.n, cs.m) == (3, 5)
+    rng = seeded_rng(0x5EED0002)
+    toxic = [rng() for _ in range(5)]
+    r, s = rng(), rng()
+    q = O.QAP(cs.n, cs.m, *csrs(cs))
+    opk1, opk2, _, _ = q.groth16_setup(frs(toxic), cs.mid)
+    prover = Groth16(cs, PKey(np.frombuffer(opk1, dtype=np.uint8), np.frombuffer(opk2, dtype=np.uint8)))
+    proof = prover.prove_rs(sol, r, s)
+    rc, a, b, c = q.groth16_prove(opk1, opk2, cs.mid, bytes(sol), P.fr_to_bytes(r), P.fr_to_bytes(s), 1)
+    assert rc == 0 and (proof.a, proof.b, proof.c) == (a, b, c)
+    prover.close()

@@ -74,3 +74,45 @@ def test_non_canonical_input_is_rejected():
     with pytest.raises(ZkError) as e:
         FFT_Fr.fft(bad, 1)
     assert e.value.code == -3
+
+
+@pytest.mark.parametrize("log_n", [18, 20])
+def test_fft_large_matches_oracle_on_a_strided_sample(log_n):
+    """beyond 2^16 the transform was property-tested only.  The oracle's O(n log n) restatement of
+    FFT.ml:29-67 handles 2^20 in seconds: compare 256 strided outputs (plus both ends) of fft and ifft bit for bit."""
+    n = 1 << log_n
+    data = _rand_fr(n, 900 + log_n)
+    for inverse, got in ((False, bytes(FFT_Fr.fft(data, log_n))), (True, bytes(FFT_Fr.ifft(data)))):
+        ref = O.fr_ntt(data, log_n, inverse)
+        idx = list(range(0, n, n // 256)) + [1, n - 1, n // 2 + 1]
+        for k in idx:
+            assert got[32 * k:32 * k + 32] == ref[32 * k:32 * k + 32], (log_n, inverse, k)
+        if log_n == 18:
+            assert got == ref
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (1, 7), (2, 2), (3, 5), (17, 1), (64, 64), (100, 29), (255, 257), (1000, 1), (1024, 1024), (4096, 3000), (4096, 4096)])
+def test_polynomial_mul_matches_oracle(na, nb):
+    """zk_fr_poly_mul == FFT.polynomial_mul (FFT.ml:98-105) == Polynomial.mul (polynomial.ml:124-131, the oracle's
+    schoolbook restatement): unequal lengths, sizes that are not powers of two, normalized output."""
+    a, b = _rand_fr(na, 5000 + na), _rand_fr(nb, 6000 + nb)
+    assert bytes(FFT_Fr.polynomial_mul(a, b)) == O.poly_mul(a, b)
+    assert bytes(FFT_Fr.polynomial_mul(b, a)) == O.poly_mul(a, b)
+
+
+def test_polynomial_mul_normalizes_like_the_reference():
+    """Polynomial.normalize (polynomial.ml:100-107): trailing zero coefficients are stripped, the zero polynomial is []."""
+    one = (1).to_bytes(32, "little")
+    zero = bytes(32)
+    top = (RC.FR_MODULUS - 1).to_bytes(32, "little")
+    a = _rand_fr(9, 1) + zero * 7                      # trailing zeros in an operand
+    b = _rand_fr(5, 2) + zero * 3
+    ref = O.poly_mul(a, b)
+    assert bytes(FFT_Fr.polynomial_mul(a, b)) == ref and len(ref) == 32 * (9 + 5 - 1)
+    assert bytes(FFT_Fr.polynomial_mul(zero * 4, a)) == b"" == O.poly_mul(zero * 4, a)      # 0 * f = []
+    assert bytes(FFT_Fr.polynomial_mul(b"", a)) == b""
+    assert bytes(FFT_Fr.polynomial_mul(one, a)) == O.poly_mul(one, a) == a[:32 * 9]
+    assert bytes(FFT_Fr.polynomial_mul(top * 33, top * 31)) == O.poly_mul(top * 33, top * 31)   # extreme values: (r-1)^2 sums
+    # polynomial.ml:135-139 KAT over Fr: (1 + x)(1 - x) = 1 - x^2
+    p1, p2 = one + one, one + top
+    assert bytes(FFT_Fr.polynomial_mul(p1, p2)) == one + zero + top

@@ -22,7 +22,7 @@ def _run(mode, world, n):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_mp_shard_worker.py"), mode, str(n)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "MP-OK %s %d %d" % (mode, world, n) in res.stdout
 
@@ -33,6 +33,6 @@ def test_point_sharded_sum_is_exact_gloo_cpu(world, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n", [(2, 256), (3, 1000)])
+@pytest.mark.parametrize("world,n", [(2, 256), (3, 1000), (2, 1 << 17)])      # the last: a realistic slice (2^16 per rank, LDS sort path, c = 16)
 def test_point_sharded_prove_gpu(world, n):
     _run("gpu", world, n)

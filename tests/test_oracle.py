@@ -60,6 +60,35 @@ def test_public_known_answers():
     assert O.g2_compress(O.g2_mul(O.g2_generator(), frb(2))).hex() == kat2
 
 
+def test_public_known_answers_eip2537():
+    """More pins from OUTSIDE this repository: the uncompressed coordinates that the published
+    EIP-2537 precompile vectors carry for -G1, 2 G1 (`bls_g1add_(g1+g1=2*g1)`), -G2 (the pairing vector
+    e(G1,G2) e(G1,-G2) = 1) and 2 G2 (`bls_g2add_(g2+g2=2*g2)`), written down from memory (no network) and reproduced
+    by both restatements -- a wrong recollection could not match by accident.  The reference still holds no vector of
+    its own: parity stays "unpinned" by /root/reference; these tie the oracle to the public BLS12-381 it claims to be."""
+    neg_g1_y = "114d1d6855d545a8aa7d76c8cf2e21f267816aef1db507c96655b9d5caac42364e6f38ba0ecb751bad54dcd6b939c2ca"
+    two_g1 = ("0572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e",
+              "166a9d8cabc673a322fda673779d8e3822ba3ecb8670e461f73bb9021d5fd76a4c56d9d4cd16bd1bba86881979749d28")
+    neg_g2_y = ("13fa4d4a0ad8b1ce186ed5061789213d993923066dddaf1040bc3ff59f825c78df74f2d75467e25e0f55f8a00fa030ed",     # y.c1
+                "0d1b3cc2c7027888be51d9ef691d77bcb679afda66c73f17f9ee3837a55024f78c71363275a75d75d86bab79f74782aa")     # y.c0
+    two_g2 = ("0a4edef9c1ed7f729f520e47730a124fd70662a904ba1074728114d1031e1572c6c886f6b57ec72a6178288c47c33577",       # x.c1
+              "1638533957d540a9d2370f17cc7ed5863bc0b995b8825e0ee1ea1e1e4d00dbae81f14b0bf3611b78c952aacab827a053",       # x.c0
+              "0f6d4552fa65dd2638b361543f887136a43253d9c66c411697003f7a13c308f5422e1aa0a59c8967acdefd8b6e36ccf3",       # y.c1
+              "0468fb440d82b0630aeb8dca2b5256789a66da69bf91009cbfe6bd221e47aa8ae88dece9764bf3bd999d95d71e4c9899")       # y.c0
+    g1, g2 = O.g1_generator(), O.g2_generator()
+    for pb, ob in ((P.g1_to_bytes(P.pt_neg(P.G1)), O.g1_mul(g1, frb(P.R - 1))),):
+        assert pb == ob and pb[:48] == g1[:48] and pb[48:].hex() == neg_g1_y
+    for pb, ob in ((P.g1_to_bytes(P.pt_mul(P.G1, 2)), O.g1_add(g1, g1)),):
+        assert pb == ob and (pb[:48].hex(), pb[48:].hex()) == two_g1
+    nb = P.g2_to_bytes(P.pt_neg(P.G2))
+    assert nb == O.g2_mul(g2, frb(P.R - 1)) and nb[:96] == g2[:96] and (nb[96:144].hex(), nb[144:].hex()) == neg_g2_y
+    db = P.g2_to_bytes(P.pt_mul(P.G2, 2))
+    assert db == O.g2_add(g2, g2) and tuple(db[48 * i:48 * i + 48].hex() for i in range(4)) == two_g2
+    # sign flag of the compressed form (curve.ml:199,208): -G carries 0x20, G does not
+    assert O.g1_compress(P.g1_to_bytes(P.pt_neg(P.G1)))[0] == 0xb7 and O.g1_compress(g1)[0] == 0x97
+    assert O.g2_compress(nb)[0] == 0xb3 and O.g2_compress(g2)[0] == 0x93
+
+
 def test_field_vs_bigint():
     for _ in range(50):
         a, b = rnd.randrange(P.R), rnd.randrange(P.R)

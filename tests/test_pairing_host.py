@@ -53,6 +53,18 @@ def test_bilinearity_and_products():
     assert check(lhs + [(P.pt_neg(P.pt_mul(P.G1, total)), P.G2)])
 
 
+def test_pairing_order_and_the_eip2537_identity():
+    """e(G1, G2) has order r (not 1), e(G1,G2) e(G1,-G2) = 1 (the EIP-2537 pairing vector), e(2 G1, 3 G2) = e(G1,G2)^6 --
+    on the product's host pairing and on the oracle's big-int pairing."""
+    e = P.pairing(P.G1, P.G2)
+    assert e != P.FP12_ONE
+    assert e.pow(P.R) == P.FP12_ONE
+    assert product([(P.G1, P.G2)]) == gt_bytes(e) and product([(P.G1, P.G2)]) != gt_bytes(P.FP12_ONE)
+    assert check([(P.G1, P.G2), (P.G1, P.pt_neg(P.G2))]) and check([(P.G1, P.G2), (P.pt_neg(P.G1), P.G2)])
+    assert product([(P.pt_mul(P.G1, 2), P.pt_mul(P.G2, 3))]) == gt_bytes(e.pow(6)) == product([(P.pt_mul(P.G1, 6), P.G2)])
+    assert product([(P.pt_mul(P.G1, P.R - 1), P.G2), (P.G1, P.G2)]) == gt_bytes(P.FP12_ONE)
+
+
 def test_rejects_points_off_the_curve_or_outside_the_subgroup():
     good2 = P.g2_to_bytes(P.G2)
     bad = bytearray(P.g1_to_bytes(P.G1))

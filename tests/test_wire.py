@@ -53,3 +53,33 @@ def test_groth16_records_round_trip():
     assert keys == ["a", "d1", "ti1", "ltd_mid", "tiztd", "b1", "b2", "d2", "ti2"]          # groth16.ml:24-34 declaration order
     pk2, mids2 = wire.groth16_pkey_of_json(js)
     assert mids2 == mids and bytes(pk2.g1) == g1 and bytes(pk2.g2) == g2
+
+
+def test_pinocchio_key_records_round_trip():
+    """pinocchio.ml:37-60 (pkey) and :62-75 (vkey): field order of the derivers, the I_mid / [m] / io maps as Var.Map
+    bindings, flat pools of include/zkmi355x.h on the other side."""
+    from zukelang_amd.pinocchio import PKey, VKey as PVKey
+    pt1 = lambda k: P.g1_to_bytes(P.pt_mul(P.G1, k))
+    pt2 = lambda k: P.g2_to_bytes(P.pt_mul(P.G2, k))
+    n = 3
+    all_vars = [("ONE", 1), ("c", 4), ("c", 5), ("input", 3), ("v", 6)]
+    mids, ios = all_vars[1:4], [all_vars[0], all_vars[4]]
+    k, m = len(mids), len(all_vars)
+    g1 = b"".join(pt1(100 + i) for i in range(5 * k + (n + 1) + 2 * m + 7))
+    g2 = b"".join(pt2(300 + i) for i in range(2 * k + (n + 1) + 2))
+    pk = PKey(np.frombuffer(g1, dtype=np.uint8), np.frombuffer(g2, dtype=np.uint8))
+    js = wire.pinocchio_pkey_to_json(pk, n, mids, all_vars)
+    assert list(wire.loads(js)) == ["vv", "ww", "yy", "vav", "waw", "yay", "si", "bvwy", "si2", "vt", "wt", "yt", "vavt", "wawt", "yayt",
+                                    "vbt", "wbt", "ybt", "v_all", "w_all"]
+    pk2, n2, mids2, all2 = wire.pinocchio_pkey_of_json(js)
+    assert (n2, mids2, all2) == (n, mids, all_vars) and bytes(pk2.g1) == g1 and bytes(pk2.g2) == g2
+    d = wire.loads(js)
+    assert d["yy"][1][0] == [b"c", 5] and wire.g1_of_json(d["yy"][1][1]) == g1[96 * (k + 1):96 * (k + 2)]      # yy is the 2nd G1 pool
+    assert wire.g2_of_json(d["wawt"]) == g2[-192:] and wire.g1_of_json(d["ybt"]) == g1[-96:]
+    v1 = b"".join(pt1(500 + i) for i in range(3 + 2 * len(ios)))
+    v2 = b"".join(pt2(600 + i) for i in range(6 + len(ios)))
+    vk = PVKey(np.frombuffer(v1, dtype=np.uint8), np.frombuffer(v2, dtype=np.uint8))
+    js = wire.pinocchio_vkey_to_json(vk, ios)
+    assert list(wire.loads(js)) == ["one", "one2", "av", "aw", "ay", "gm2", "bgm", "bgm2", "yt", "vv_io", "ww_io", "yy_io"]
+    vk2, ios2 = wire.pinocchio_vkey_of_json(js)
+    assert ios2 == ios and bytes(vk2.g1) == v1 and bytes(vk2.g2) == v2

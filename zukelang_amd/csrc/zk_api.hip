@@ -211,9 +211,9 @@ int zk_shutdown(void) {
 int zk_sync(void) {
     Ctx& c = ctx();
     if (!c.inited) return ZK_OK;
-    HIPCHK(hipStreamSynchronize(c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream2));
-    HIPCHK(hipStreamSynchronize(c.stream3));
+    // every stream of the process: the context streams AND the per-slot streams of every key (proofs in flight run on
+    // hipStreamNonBlocking slot streams; zk_profile_get reads events recorded there)
+    HIPCHK(hipDeviceSynchronize());
     return ZK_OK;
 }
 

@@ -140,6 +140,21 @@ def exchange_slices(full, bounds, rank, world, out=None):
     return out
 
 
+def agree_on_status(rc):
+    """Collective error agreement of the N > 1 paths.  A failure that only ONE rank can see (the owner of a proof finds
+    `p mod Z != 0`, QAP.ml:134, or a HIP error) must not let the other ranks walk into the next all-to-all / all-gather
+    alone: every rank contributes its local return code (0 or a negative ZK_ERR_*), all of them receive the most severe
+    one (the minimum) and raise the same exception -- or none does.  One 4-byte all-reduce; a no-op without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rc
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(rc)], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
 def msm_scalar_vectors(n, v, w, h, wit, mid, r, s):
     """Host mirror (Python ints) of the library's k_groth16_scalars: the three scalar vectors laid
     over the key pools g1 = a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid and g2 = b2 | d2 | ti2[n+2]:
@@ -279,9 +294,11 @@ class Groth16:
         if self.world == 1:
             rc = _lib.lib().zk_groth16_prove(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), _p(out))
         else:
-            part = self.prove_partial(w, rb, sb)
-            gathered = all_gather_bytes(part, self.world)
-            rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
+            part = np.zeros(768, dtype=np.uint8)
+            rc = _lib.lib().zk_groth16_prove_partial(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), _p(part))
+            if rc == 0:          # the Fr stage is replicated on this path: a bad witness fails on every rank at once
+                gathered = all_gather_bytes(part, self.world)
+                rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
         if rc == ZK_ERR_REMAINDER:
             raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
         _lib.check(rc)
@@ -293,21 +310,32 @@ class Groth16:
         _lib.check(_lib.lib().zk_groth16_reserve_slots(self.handle, C.c_uint32(count)))
 
     def prove_async(self, sol, r, s, slot):
-        """Enqueue one proof on `slot` (0..7) and return; `prove_wait(slot)` collects it.  Several
+        """Enqueue one proof on `slot` (0..14) and return; `prove_wait(slot)` collects it.  Several
         slots keep several proofs in flight on one key.  On a sharded key the slot produces this
-        rank's partial sums; prove_wait then runs the exchange (all-gather) and the combine."""
-        w = None if sol is None else self._sol_bytes(sol)
+        rank's partial sums; prove_wait then runs the exchange (all-gather) and the combine.
+        The witness buffer handed to the library stays referenced here until prove_wait(slot): the C side
+        copies it with hipMemcpyAsync and must not outlive a pageable host buffer."""
+        w = None
+        if sol is not None:
+            w = self._sol_bytes(sol)
+            if len(w) != 32 * self.circuit.m:
+                raise AssertionError("Variable not found")          # var.ml:75-77
         rb, sb = fr_bytes([r]), fr_bytes([s])
         fn = _lib.lib().zk_groth16_prove_async if self.world == 1 else _lib.lib().zk_groth16_prove_partial_async
         _lib.check(fn(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), C.c_uint32(slot)))
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[slot] = (w, rb, sb)
 
     def prove_wait(self, slot):
         out = np.zeros(384, dtype=np.uint8)
         if self.world == 1:
             rc = _lib.lib().zk_groth16_prove_wait(self.handle, C.c_uint32(slot), _p(out))
+            getattr(self, "_inflight", {}).pop(slot, None)
         else:
             part = np.zeros(768, dtype=np.uint8)
             rc = _lib.lib().zk_groth16_prove_partial_wait(self.handle, C.c_uint32(slot), _p(part))
+            getattr(self, "_inflight", {}).pop(slot, None)
             if rc == 0:
                 gathered = all_gather_bytes(part, self.world)
                 rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
@@ -420,11 +448,17 @@ class GroupProver:
         return launched
 
     def _finish_fr_and_exchange(self, launched, count):
-        for k in launched:
-            rc = _lib.lib().zk_groth16_scalars_wait(self.p.handle, C.c_uint32(self.batch + k))
-            if rc == ZK_ERR_REMAINDER:
-                raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
-            _lib.check(rc)
+        worst = 0
+        for k in launched:                       # wait for EVERY slot launched (none stays busy), keep the most severe code
+            worst = min(worst, _lib.lib().zk_groth16_scalars_wait(self.p.handle, C.c_uint32(self.batch + k)))
+        local = worst
+        worst = agree_on_status(worst)           # before the first collective of the round: all ranks raise, or none
+        if worst == ZK_ERR_REMAINDER:
+            raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134 (on every rank, whichever rank owned the proof)
+        if worst != 0:
+            if local == worst:
+                _lib.check(worst)
+            raise _lib.ZkError(worst, "a peer rank failed in the Fr stage of this round")
         for k in range((count + self.world - 1) // self.world):       # every rank takes part in every exchange of the round
             for i, bounds in ((0, self.bounds1), (1, self.bounds1), (2, self.bounds2)):
                 exchange_slices(self.full[k][i], bounds, self.rank, self.world, out=self.recv[k][i])

@@ -222,3 +222,75 @@ def fr_to_json(x):
 
 def fr_of_json(data):
     return int(loads(data).decode())
+
+
+# ---- Pinocchio keys (pinocchio.ml:37-60 pkey, :62-75 vkey), record fields in declaration order.
+# Flat pools of include/zkmi355x.h:  pk g1 = vv | yy | vav | yay | bvwy (n_mid each) | si (n+1) | v_all (m) | w_all (m) | vt | yt | vavt | yayt | vbt | wbt | ybt
+#                                    pk g2 = ww | waw (n_mid each) | si2 (n+1) | wt | wawt
+#                                    vk g1 = one | aw | bgm | vv_io | yy_io        vk g2 = one2 | av | ay | gm2 | bgm2 | yt | ww_io
+def _vmap(vars_, pts, conv):
+    return [[[name, vid], conv(p)] for (name, vid), p in zip(vars_, pts)]
+
+
+def pinocchio_pkey_to_json(pk, n, mid_vars, all_vars):
+    """mid_vars: (name, id) of circuit.mids in Var.Map order; all_vars: every variable (the domain of v_all / w_all)."""
+    g1, g2 = bytes(pk.g1), bytes(pk.g2)
+    k, m = len(mid_vars), len(all_vars)
+    assert len(g1) == 96 * (5 * k + (n + 1) + 2 * m + 7) and len(g2) == 192 * (2 * k + (n + 1) + 2)
+    c1 = lambda i: G1.to_compressed_bytes(g1[96 * i:96 * i + 96])
+    c2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
+    r1 = lambda o, cnt: [c1(o + i) for i in range(cnt)]
+    r2 = lambda o, cnt: [c2(o + i) for i in range(cnt)]
+    o_si, o_va = 5 * k, 5 * k + n + 1
+    o_wa = o_va + m
+    o_t = o_wa + m
+    o_si2 = 2 * k
+    o_t2 = o_si2 + n + 1
+    ident = lambda x: x
+    return dumps({"vv": _vmap(mid_vars, r1(0, k), ident), "ww": _vmap(mid_vars, r2(0, k), ident), "yy": _vmap(mid_vars, r1(k, k), ident),
+                  "vav": _vmap(mid_vars, r1(2 * k, k), ident), "waw": _vmap(mid_vars, r2(k, k), ident), "yay": _vmap(mid_vars, r1(3 * k, k), ident),
+                  "si": r1(o_si, n + 1), "bvwy": _vmap(mid_vars, r1(4 * k, k), ident), "si2": r2(o_si2, n + 1),
+                  "vt": c1(o_t), "wt": c2(o_t2), "yt": c1(o_t + 1), "vavt": c1(o_t + 2), "wawt": c2(o_t2 + 1), "yayt": c1(o_t + 3),
+                  "vbt": c1(o_t + 4), "wbt": c1(o_t + 5), "ybt": c1(o_t + 6),
+                  "v_all": _vmap(all_vars, r1(o_va, m), ident), "w_all": _vmap(all_vars, r1(o_wa, m), ident)})
+
+
+def pinocchio_pkey_of_json(data):
+    """-> (pinocchio.PKey, n, mid_vars, all_vars)"""
+    from .pinocchio import PKey
+    import numpy as np
+    d = loads(data)
+    vars_of = lambda f: [(b[0][0].decode("latin-1"), b[0][1]) for b in d[f]]
+    m1 = lambda f: [g1_of_json(b[1]) for b in d[f]]
+    m2 = lambda f: [g2_of_json(b[1]) for b in d[f]]
+    mid_vars, all_vars = vars_of("vv"), vars_of("v_all")
+    for f in ("ww", "yy", "vav", "waw", "yay", "bvwy"):
+        assert vars_of(f) == mid_vars, "Pinocchio pkey: the I_mid maps must share one domain"
+    assert vars_of("w_all") == all_vars
+    g1 = (m1("vv") + m1("yy") + m1("vav") + m1("yay") + m1("bvwy") + [g1_of_json(x) for x in d["si"]] + m1("v_all") + m1("w_all")
+          + [g1_of_json(d[f]) for f in ("vt", "yt", "vavt", "yayt", "vbt", "wbt", "ybt")])
+    g2 = m2("ww") + m2("waw") + [g2_of_json(x) for x in d["si2"]] + [g2_of_json(d["wt"]), g2_of_json(d["wawt"])]
+    return (PKey(np.frombuffer(b"".join(g1), dtype=np.uint8), np.frombuffer(b"".join(g2), dtype=np.uint8)), len(d["si"]) - 1, mid_vars, all_vars)
+
+
+def pinocchio_vkey_to_json(vk, io_vars):
+    g1, g2 = bytes(vk.g1), bytes(vk.g2)
+    k = len(io_vars)
+    assert len(g1) == 96 * (3 + 2 * k) and len(g2) == 192 * (6 + k)
+    c1 = lambda i: G1.to_compressed_bytes(g1[96 * i:96 * i + 96])
+    c2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
+    ident = lambda x: x
+    return dumps({"one": c1(0), "one2": c2(0), "av": c2(1), "aw": c1(1), "ay": c2(2), "gm2": c2(3), "bgm": c1(2), "bgm2": c2(4), "yt": c2(5),
+                  "vv_io": _vmap(io_vars, [c1(3 + i) for i in range(k)], ident), "ww_io": _vmap(io_vars, [c2(6 + i) for i in range(k)], ident),
+                  "yy_io": _vmap(io_vars, [c1(3 + k + i) for i in range(k)], ident)})
+
+
+def pinocchio_vkey_of_json(data):
+    from .pinocchio import VKey
+    import numpy as np
+    d = loads(data)
+    io_vars = [(b[0][0].decode("latin-1"), b[0][1]) for b in d["vv_io"]]
+    assert [(b[0][0].decode("latin-1"), b[0][1]) for b in d["ww_io"]] == io_vars and [(b[0][0].decode("latin-1"), b[0][1]) for b in d["yy_io"]] == io_vars
+    g1 = [g1_of_json(d["one"]), g1_of_json(d["aw"]), g1_of_json(d["bgm"])] + [g1_of_json(b[1]) for b in d["vv_io"]] + [g1_of_json(b[1]) for b in d["yy_io"]]
+    g2 = [g2_of_json(d[f]) for f in ("one2", "av", "ay", "gm2", "bgm2", "yt")] + [g2_of_json(b[1]) for b in d["ww_io"]]
+    return VKey(np.frombuffer(b"".join(g1), dtype=np.uint8), np.frombuffer(b"".join(g2), dtype=np.uint8)), io_vars
