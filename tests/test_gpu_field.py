@@ -1,5 +1,5 @@
 """GPU parity of the base-field layer (14 x 29-bit limbs, lazy reduction, value bounds in the type):
-zk_selftest_fp evaluates 16 expressions per operand pair through the same code paths the group law uses;
+zk_selftest_fp evaluates 18 expressions per operand pair through the same code paths the group law uses;
 the expected values are Python big-integer arithmetic mod p.  Edge operands: 0, 1, p-1, values whose limbs are
 all-ones at the 29-bit boundaries, a = b, a + b = p."""
 import ctypes as C
@@ -13,6 +13,7 @@ from zukelang_amd import _lib
 
 pytestmark = pytest.mark.gpu
 p = P.P
+NOUT = 18
 
 
 def le48(x):
@@ -38,11 +39,11 @@ def operands():
 def test_field_battery_matches_big_integers():
     a, b = operands()
     n = len(a)
-    out = np.zeros(16 * 48 * n, dtype=np.uint8)
+    out = np.zeros(NOUT * 48 * n, dtype=np.uint8)
     _lib.check(_lib.lib().zk_selftest_fp(b"".join(le48(x) for x in a), b"".join(le48(x) for x in b), C.c_size_t(n),
                                          out.ctypes.data_as(C.POINTER(C.c_uint8))))
     raw = out.tobytes()
-    get = lambda i, k: int.from_bytes(raw[48 * (16 * i + k):48 * (16 * i + k + 1)], "little")
+    get = lambda i, k: int.from_bytes(raw[48 * (NOUT * i + k):48 * (NOUT * i + k + 1)], "little")
     inv = lambda x: pow(x, p - 2, p)
     for i in range(n):
         x, y = a[i], b[i]
@@ -64,3 +65,7 @@ def test_field_battery_matches_big_integers():
         dif = ((s0 * t0 - s1 * t1) % p, (s0 * t1 + s1 * t0) % p)
         c = i & 1
         assert (get(i, 12), get(i, 13), get(i, 14)) == (mul[c], sqr[c], dif[c]), (i, "fp2 lane pair")
+        # lockstep inversion (csrc/fp_inv.cuh): base field, and Fp2 on the lane pair: 1 / (x0 + x1 u) = (x0 - x1 u) / (x0^2 + x1^2)
+        assert get(i, 16) == inv(x), (i, "fe_inv_fast", hex(x))
+        nrm = inv((x0 * x0 + x1 * x1) % p)
+        assert get(i, 17) == ((x0 * nrm) % p, (-x1 * nrm) % p)[c], (i, "fp2 fe_inv_fast")

@@ -125,3 +125,90 @@ def test_msm_skewed_bucket_loads(kind):
     expect = O.g1_mul(O.g1_generator(), O.fr_dot(bytes(ks), bytes(scalars)))
     for c in (0, 8, 15):
         assert bytes(G1.apply_powers(scalars, bases, c)) == expect, (kind, c)
+
+
+# ---- the resident-key machinery (window tables, one bucket set, BATCH-AFFINE halving rounds) driven through zk_msm_g1/g2
+@pytest.fixture
+def resident_path(monkeypatch):
+    """ZK_MSM_API_PRECOMP=1 sends zk_msm_* through the kernels a proving key uses; ZK_MSM_BA_ROUNDS forces the number of
+    batch-affine rounds (auto would pick 0 for base sets this small)."""
+    def use(rounds):
+        monkeypatch.setenv("ZK_MSM_API_PRECOMP", "1")
+        monkeypatch.setenv("ZK_MSM_BA_ROUNDS", str(rounds))
+    return use
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 3, 6])
+def test_batch_affine_edge_cases(resident_path, rounds):
+    """dx = 0 in every flavour (csrc/msm_ba.cuh): P + P (doubling inside the shared inversion), P + (-P) (identity, then identity
+    operands in the next round), duplicated and negated bases under equal digits, identity bases (filtered by the sort), odd runs."""
+    resident_path(rounds)
+    g = O.g1_generator()
+    p5 = O.g1_mul(g, frb(5))
+    m5 = O.g1_mul(g, frb(P.R - 5))
+    inf = bytes([0x40]) + bytes(95)
+    cases = [
+        (p5 * 8, [7] * 8),                                   # all equal: doubling chain 2P, 4P, 8P
+        (p5 * 7, [7] * 7),                                   # ... with odd leftovers
+        ((p5 + m5) * 4, [9] * 8),                            # P, -P under the same digit: everything cancels
+        ((p5 + m5) * 3 + p5, [9] * 7),                       # cancels except one
+        (p5 * 3 + m5 * 3 + g + inf + p5, [3, 3, P.R - 3, 3, 3, P.R - 3, 11, 5, 3]),      # sign of the digit against sign of the base
+        (p5 * 6 + inf + g, [7, 7, P.R - 7, 0, 1, P.R - 1, 12345, 0x8000]),
+        (inf * 5 + g, [1, 2, 3, 4, 5, 6]),                   # identity bases never enter a bucket
+        (p5 + p5, [1, P.R - 1]),                             # P + (-P) through the recoded digits
+    ]
+    for bases, scalars in cases:
+        sc = b"".join(frb(s) for s in scalars)
+        rc, ref = O.g1_msm_naive(bases, sc)
+        assert rc == 0
+        for c in (3, 4, 8):
+            assert bytes(G1.apply_powers(sc, bases, c)) == ref, (rounds, c, scalars)
+
+
+@pytest.mark.parametrize("G,naive,n,c,rounds", [(G1, O.g1_msm_naive, 600, 4, 5), (G1, O.g1_msm_naive, 257, 3, 9), (G1, O.g1_msm_naive, 1000, 8, 2),
+                                                (G2, O.g2_msm_naive, 200, 4, 4), (G2, O.g2_msm_naive, 65, 3, 7)])
+def test_batch_affine_matches_naive_oracle(resident_path, G, naive, n, c, rounds):
+    resident_path(rounds)
+    ks = RC.random_fr_bytes(n, 7000 + n)
+    bases = G.of_Fr(ks)
+    scalars = RC.random_fr_bytes(n, 8000 + n)
+    rc, ref = naive(bytes(bases), bytes(scalars))
+    assert rc == 0
+    assert bytes(G.apply_powers(scalars, bases, c)) == ref
+
+
+def test_batch_affine_g2_edge_cases(resident_path):
+    resident_path(3)
+    g = O.g2_generator()
+    q = O.g2_mul(g, frb(9))
+    mq = O.g2_mul(g, frb(P.R - 9))
+    inf = bytes([0x40]) + bytes(191)
+    for bases, scalars in ((q * 8, [5] * 8), ((q + mq) * 4, [5] * 8), (q * 3 + mq * 2 + inf + g, [3, 3, 3, 3, P.R - 3, 9, 2])):
+        sc = b"".join(frb(s) for s in scalars)
+        rc, ref = O.g2_msm_naive(bases, sc)
+        assert rc == 0
+        for c in (3, 5):
+            assert bytes(G2.apply_powers(sc, bases, c)) == ref, (c, scalars)
+
+
+@pytest.mark.parametrize("kind", ["boolean_heavy", "all_equal"])
+def test_batch_affine_skewed_bucket_loads(resident_path, kind):
+    """One bucket swallowing most of the digits: the rounds halve it like any other run and the XYZZ finisher (worklist
+    fix-up) takes what the fixed number of rounds leaves."""
+    resident_path(4)
+    n = 1 << 13
+    ks = RC.random_fr_bytes(n, 601)
+    bases = G1.of_Fr(ks)
+    rng = np.random.Generator(np.random.PCG64(9))
+    if kind == "boolean_heavy":
+        vals = np.zeros((n, 32), dtype=np.uint8)
+        vals[:, 0] = rng.integers(0, 2, size=n, dtype=np.uint8)
+        full = np.frombuffer(bytes(RC.random_fr_bytes(n, 602)), dtype=np.uint8).reshape(n, 32)
+        pick = rng.random(n) < 0.1
+        vals[pick] = full[pick]
+    else:
+        vals = np.tile(np.frombuffer(P.fr_to_bytes(0x1234567890ABCDEF1234567890ABCDEF), dtype=np.uint8), (n, 1))
+    scalars = np.ascontiguousarray(vals).reshape(-1)
+    expect = O.g1_mul(O.g1_generator(), O.fr_dot(bytes(ks), bytes(scalars)))
+    for c in (8, 13):
+        assert bytes(G1.apply_powers(scalars, bases, c)) == expect, (kind, c)

@@ -20,6 +20,7 @@ struct MsmBases {
     uint32_t nw = 0;         // windows
     bool precomp = false;    // table holds 2^(c*j) * P_i for j < nw at [j*n + i]; one bucket set
     DevBuf table;            // affine Montgomery points
+    DevBuf ident;            // precomp: one byte per point, 1 = the base is the identity (the sort never files it into a bucket)
 };
 
 struct MsmWorkspace {
@@ -34,12 +35,22 @@ struct MsmWorkspace {
     uint32_t nbuckets = 0;      // total bucket slots (windows * 2^(c-1) in classic mode)
     uint32_t chunk = 0;         // sorted entries per accumulate thread
     uint64_t nthreads = 0;
+    // batch-affine rounds (resident keys with enough points per bucket): R = ba_rounds halvings before the XYZZ accumulate
+    uint32_t ba_rounds = 0;
+    uint64_t ba_max_entries = 0;          // upper bound of sorted entries this workspace will see (non-zero scalars x windows)
+    DevBuf ba_offs;                       // R arrays of nbuckets + 1 offsets: round r (1-based) at (r - 1) * (nbuckets + 1)
+    DevBuf ba_e[2];                       // ping-pong entry arrays of raw affine points: E_1 -> [0], E_2 -> [1], E_3 -> [0], ...
+    uint64_t ba_cap[2] = {0, 0};          // their capacities in points
+    // what the accumulate and the reduction of the CURRENT product read (set by msm_sort_accumulate*)
+    const uint32_t* red_offsets = nullptr;
+    uint32_t red_chunk = 0;
 };
 
 uint32_t msm_auto_window(uint64_t n, bool precomp);
 int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
 int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
-int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b);
+// max_nonzero: upper bound of the non-zero scalars this workspace's products ever carry (0 = all of b.n): sizes the batch-affine buffers
+int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero = 0);
 // d_scalars: n canonical (non-Montgomery) Fr, 32 B each, on device.  d_result: one XYZZ point.
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_result_xyzz, hipStream_t s);
 // the same in two halves: sort + bucket accumulation per MSM, then ONE chain of reduction launches for up to 8 MSMs
@@ -59,8 +70,13 @@ struct AccJobs {
     uint8_t* buckets[MAX_ACC_JOBS];
     uint8_t* head[MAX_ACC_JOBS];
     uint8_t* tail[MAX_ACC_JOBS];
+    const uint8_t* pts[MAX_ACC_JOBS];       // raw = true: the entries are affine points (raw limb layout) instead of table references
 };
-int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s);
+int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s, bool raw = false);
+// Batch-affine halving rounds (msm_ba.cuh / msm_ba.hip) between the sort and the accumulate: `rounds` launches over the jobs'
+// sorted references, leaving the entry array of the last round in ws[i]->ba_e[(rounds - 1) & 1] and its offsets in ba_offs.
+struct MsmWorkspace;
+int msm_batch_affine_rounds(const MsmBases& b, MsmWorkspace* const* ws, uint32_t count, uint32_t rounds, hipStream_t s);
 // XYZZ (device) -> uncompressed bytes (host); count points
 int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_t* host_out, hipStream_t s);
 // same, asynchronous: device XYZZ -> device bytes (no allocation, no synchronization)

@@ -134,6 +134,18 @@ template <class F> __global__ void k_precompute(uint8_t* table, uint64_t n, uint
     }
 }
 
+// flags[i] = 1 iff base i is the identity (its table entries 2^(cj) P are the identity for every window, and only those:
+// neither curve has points of even order)
+template <class F> __global__ void k_ident_flags(uint8_t* flags, const uint8_t* table, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int B = FieldOps<F>::WORDS * 8;
+    const uint4* q = reinterpret_cast<const uint4*>(table + B * i);
+    uint32_t o = 0;
+    for (int k = 0; k < B / 16; k++) { const uint4 x = q[k]; o |= x.x | x.y | x.z | x.w; }
+    flags[i] = o == 0 ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ digits
 // Signed c-bit digits d_j in [-(2^(c-1) - 1), 2^(c-1)] with sum_j d_j 2^(cj) = s.  Adding the constant
 // K = sum_j (2^(c-1) - 1) 2^(cj) turns the recoding into plain base-2^c digit extraction:
@@ -143,12 +155,14 @@ struct DigitArgs {
     uint64_t n;
     uint32_t c, nw, precomp, nb_per_window;
     uint32_t K[9];         // the recoding constant, 288 bits
+    const uint8_t* ident;  // precomp: 1 = base i is the identity: it never enters a bucket (nullptr: no filter)
 };
 FF_INLINE bool digit_of(const uint32_t* __restrict__ scalars, uint64_t i, uint32_t j, const DigitArgs& a, uint32_t& key, uint32_t& val) {
     const uint32_t* sp = scalars + 8 * i;
     uint4 lo = reinterpret_cast<const uint4*>(sp)[0], hi = reinterpret_cast<const uint4*>(sp)[1];
     uint32_t s[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0};
     if ((s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) == 0) return false;
+    if (a.ident && a.ident[i]) return false;
     uint64_t cy = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -351,6 +365,7 @@ struct TailJobs {
     uint32_t n1;
 };
 static constexpr uint32_t FIXUP_SERIAL_MAX = 16;
+static constexpr uint32_t BA_FINISH_CHUNK = 8;       // sorted entries per lane of the XYZZ accumulate that follows the batch-affine rounds
 template <class T> FF_INLINE void fixup_body(const TailJob& job) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint32_t* __restrict__ offsets = job.offsets;
@@ -622,6 +637,10 @@ uint32_t msm_auto_window(uint64_t n, bool precomp) {
 }
 
 template <class F> static int bases_finish(MsmBases& b, hipStream_t s) {
+    if (b.precomp) {
+        ZKCHK(b.ident.alloc(b.n));
+        hipLaunchKernelGGL(k_ident_flags<F>, grid_for(b.n, 256), dim3(256), 0, s, b.ident.as<uint8_t>(), (const uint8_t*)b.table.as<uint8_t>(), b.n);
+    }
     if (b.precomp && b.nw > 1) {
         ScopedTimer t("msm_precompute", s);
         hipLaunchKernelGGL(k_precompute<F>, grid_for(b.n, 64), dim3(64), 0, s, b.table.as<uint8_t>(), b.n, b.c, b.nw);
@@ -698,7 +717,18 @@ int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, ui
     return curve == CURVE_G1 ? bases_finish<Fp>(b, s) : bases_finish<Fp2>(b, s);
 }
 
-int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
+// Batch-affine rounds before the XYZZ accumulate: halve the runs until ~2-3 entries per bucket are left (uniform digits; the
+// XYZZ finisher takes whatever a skewed bucket still holds).  Resident keys only (one bucket set).
+static uint32_t ba_rounds_for(const MsmBases& b, uint32_t nbuckets) {
+    const int forced = getenv("ZK_MSM_BA_ROUNDS") ? atoi(getenv("ZK_MSM_BA_ROUNDS")) : -1;      // 0 = off, -1 = auto (read per workspace: tests switch it)
+    if (!b.precomp || forced == 0) return 0;
+    const uint64_t mean = b.n * b.nw / nbuckets;
+    uint32_t r = 0;
+    while (((uint64_t)8 << r) <= mean) r++;                 // mean in [8, 16) -> 1 round ... [2^(k+2), 2^(k+3)) -> k rounds
+    if (forced > 0) r = (uint32_t)forced;
+    return r > 24 ? 24 : r;
+}
+int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero) {
     w.curve = b.curve; w.c = b.c; w.nw = b.nw; w.precomp = b.precomp; w.cap_points = b.n;
     const uint32_t nbw = 1u << (b.c - 1);
     w.nbuckets = (b.precomp ? 1 : b.nw) * nbw;
@@ -727,9 +757,27 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b) {
             ZKCHK(w.wgcount.alloc(4 * (size_t)w.nbuckets * wgs));
         }
     }
+    w.ba_rounds = ba_rounds_for(b, w.nbuckets);
+    w.red_offsets = w.offsets.as<uint32_t>();
+    w.red_chunk = w.chunk;
+    uint64_t part_slots = w.nthreads;
+    if (w.ba_rounds) {
+        const uint64_t nz = max_nonzero && max_nonzero < b.n ? max_nonzero : b.n;
+        w.ba_max_entries = nz * b.nw;
+        const size_t PB = 2 * (b.curve == CURVE_G1 ? RawLayout<Fp>::ELEM : RawLayout<Fp2>::ELEM);
+        w.ba_cap[0] = (w.ba_max_entries >> 1) + w.nbuckets;
+        w.ba_cap[1] = (w.ba_max_entries >> 2) + w.nbuckets;
+        ZKCHK(w.ba_offs.alloc(4 * (size_t)w.ba_rounds * (w.nbuckets + 1)));
+        ZKCHK(w.ba_e[0].alloc(PB * w.ba_cap[0]));
+        if (w.ba_rounds > 1) ZKCHK(w.ba_e[1].alloc(PB * w.ba_cap[1]));
+        // the finisher works on what R rounds leave: short chunks (a few entries per bucket), one partial slot per chunk
+        const uint64_t left = (w.ba_max_entries >> w.ba_rounds) + w.nbuckets;
+        const uint64_t fin_threads = (left + BA_FINISH_CHUNK - 1) / BA_FINISH_CHUNK;
+        if (fin_threads > part_slots) part_slots = fin_threads;
+    }
     ZKCHK(w.buckets.alloc(XB * w.nbuckets));
-    ZKCHK(w.head.alloc(XB * w.nthreads));
-    ZKCHK(w.tail.alloc(XB * w.nthreads));
+    ZKCHK(w.head.alloc(XB * part_slots));
+    ZKCHK(w.tail.alloc(XB * part_slots));
     ZKCHK(w.worklist.alloc(4 * (size_t)(w.nbuckets + 1)));
     const DigitPlan dp = digit_plan(b.c);
     ZKCHK(w.red.alloc(XB * (size_t)(dp.nd0 + dp.nd1) * (b.precomp ? 1 : b.nw)));
@@ -756,7 +804,7 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
     }
     MsmWorkspace& w = *ws[0];
     const uint32_t nbw = 1u << (b.c - 1);
-    DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}, b.precomp ? b.ident.as<uint8_t>() : nullptr};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
         uint32_t off = j * b.c, wd = off >> 5, sh = off & 31;
@@ -789,9 +837,29 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             hipLaunchKernelGGL(k_msm_scatter, g, dim3(256), 0, s, sj, da);
         }
     }
+    uint32_t rounds = w.ba_rounds;
+    for (uint32_t i = 0; i < count; i++)
+        if (ws[i]->ba_rounds < rounds) rounds = ws[i]->ba_rounds;
     {
+        // the whole bucket-accumulation stage of the batch (batch-affine rounds + the XYZZ accumulate) is ONE timed family span
         ScopedTimer t(b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2", s, 1);
-        ZKCHK(msm_accumulate_launch(b.curve, w.nthreads, b.table.p, aj, count, w.nbuckets, w.chunk, s));
+        if (rounds) {
+            ZKCHK(msm_batch_affine_rounds(b, ws, count, rounds, s));
+            uint64_t max_entries = 0;
+            for (uint32_t i = 0; i < count; i++) {
+                MsmWorkspace& wi = *ws[i];
+                wi.red_offsets = wi.ba_offs.as<uint32_t>() + (uint64_t)(rounds - 1) * (w.nbuckets + 1);
+                wi.red_chunk = BA_FINISH_CHUNK;
+                aj.offsets[i] = wi.red_offsets;
+                aj.pts[i] = wi.ba_e[(rounds - 1) & 1].as<uint8_t>();
+                if (wi.ba_max_entries > max_entries) max_entries = wi.ba_max_entries;
+            }
+            const uint64_t left = (max_entries >> rounds) + w.nbuckets;
+            ZKCHK(msm_accumulate_launch(b.curve, (left + BA_FINISH_CHUNK - 1) / BA_FINISH_CHUNK, b.table.p, aj, count, w.nbuckets, BA_FINISH_CHUNK, s, true));
+        } else {
+            for (uint32_t i = 0; i < count; i++) { ws[i]->red_offsets = ws[i]->offsets.as<uint32_t>(); ws[i]->red_chunk = ws[i]->chunk; }
+            ZKCHK(msm_accumulate_launch(b.curve, w.nthreads, b.table.p, aj, count, w.nbuckets, w.chunk, s));
+        }
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
@@ -818,8 +886,8 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
         const MsmBases& bi = i < n1 ? *b1 : *b2;
         if (w.c != bi.c || w.precomp != bi.precomp || w.curve != bi.curve || bi.curve != (i < n1 ? CURVE_G1 : CURVE_G2))
             ZK_FAIL(ZK_ERR_ARG, "msm_reduce: workspace does not match its bases");
-        jobs.j[i] = TailJob{w.offsets.as<uint32_t>(), w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), w.worklist.as<uint32_t>(),
-                            w.red.as<uint8_t>(), w.wsum.as<uint8_t>(), (uint8_t*)(i < n1 ? outs1[i] : outs2[i - n1]), w.nbuckets, w.chunk};
+        jobs.j[i] = TailJob{w.red_offsets, w.buckets.as<uint8_t>(), w.head.as<uint8_t>(), w.tail.as<uint8_t>(), w.worklist.as<uint32_t>(),
+                            w.red.as<uint8_t>(), w.wsum.as<uint8_t>(), (uint8_t*)(i < n1 ? outs1[i] : outs2[i - n1]), w.nbuckets, w.red_chunk};
         HIPCHK(hipMemsetAsync(w.worklist.p, 0, 4, s));
         const uint64_t lanes = (uint64_t)w.nbuckets * (i < n1 ? 1 : 2);
         if (lanes > max_lanes) max_lanes = lanes;
@@ -910,7 +978,10 @@ static int msm_api(Curve curve, const uint8_t* bases, size_t nbases, const uint8
     if (!bases || !scalars) ZK_FAIL(ZK_ERR_ARG, "msm: null input");
     MsmBases b;
     MsmWorkspace w;
-    ZKCHK(msm_bases_from_bytes(b, curve, bases, nscalars, window_bits, false, c.stream));
+    // ZK_MSM_API_PRECOMP=1 runs this entry point through the resident-key machinery (window tables, one bucket set, batch-affine
+    // rounds): how the tests reach those kernels with adversarial base sets (duplicates, negations, the identity)
+    const bool precomp = getenv("ZK_MSM_API_PRECOMP") && atoi(getenv("ZK_MSM_API_PRECOMP")) != 0;
+    ZKCHK(msm_bases_from_bytes(b, curve, bases, nscalars, window_bits, precomp, c.stream));
     ZKCHK(msm_workspace_alloc(w, b));
     DevBuf sc, res, flag;
     ZKCHK(sc.alloc(32 * nscalars));

@@ -34,7 +34,9 @@ template <class F> FF_INLINE Aff<F> packed_aff_unpack(const PackedAff<F>& a, boo
     return r;
 }
 
-template <class F>
+// RAW = false: the sorted entries are table references (index | sign).  RAW = true (the finisher of the batch-affine rounds,
+// msm_ba.cuh): entry `pos` is the affine point at pts + pos * 2 * RawLayout<F>::ELEM in the raw limb layout, identity = (0, 0).
+template <class F, bool RAW>
 __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __restrict__ table, AccJobs jobs, uint32_t nb, uint32_t chunk) {
     const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
     const uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
@@ -68,17 +70,24 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
     Xyzz<F> acc = xyzz_inf<F>();
     // (G2: the products are calls, which drain outstanding loads anyway -- only the reference is fetched ahead there,
     // the 24 look-ahead registers would be spilled)
-    uint32_t v_next = sorted[pos];
+    constexpr int RB = RawLayout<F>::ELEM;
+    const uint8_t* __restrict__ pts = jobs.pts[blockIdx.y];
+    uint32_t v_next = 0;
     PackedAff<F> p_next;
-    if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+    if constexpr (!RAW) {
+        v_next = sorted[pos];
+        if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+    }
     for (; pos < end; pos++) {
         const uint32_t v = v_next;
         PackedAff<F> pk;
-        if constexpr (PAIR) pk = packed_aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
-        else pk = p_next;
-        if (pos + 1 < end) {
-            v_next = sorted[pos + 1];
-            if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+        if constexpr (!RAW) {
+            if constexpr (PAIR) pk = packed_aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
+            else pk = p_next;
+            if (pos + 1 < end) {
+                v_next = sorted[pos + 1];
+                if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+            }
         }
         if (pos == bend) {                              // run finished inside the chunk
             const bool complete = seg_start == bstart;
@@ -89,7 +98,9 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
             do { kb++; bstart = bend; bend = offsets[kb + 1]; } while (bend == bstart);   // skip empty buckets
             seg_start = pos;
         }
-        const Aff<F> p = packed_aff_unpack<F>(pk, (v >> 31) != 0);
+        Aff<F> p;
+        if constexpr (RAW) p = {load_raw_f((const F*)nullptr, pts + (uint64_t)2 * RB * pos), load_raw_f((const F*)nullptr, pts + (uint64_t)2 * RB * pos + RB)};
+        else p = packed_aff_unpack<F>(pk, (v >> 31) != 0);
         // The mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk.  G2 runs
         // as F = Fp2H, one Fp2 component per lane of a pair, which gives it the register footprint of G1.
         // Second step of the chunk (a wave-uniform test): every lane holds the identity (run border just crossed) or

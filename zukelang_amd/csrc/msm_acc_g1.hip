@@ -7,7 +7,7 @@
 
 namespace zk {
 int msm_accumulate_launch_g1(uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s) {
-    hipLaunchKernelGGL(k_msm_accumulate<Fp>, dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
+    hipLaunchKernelGGL((k_msm_accumulate<Fp, false>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }

@@ -1,5 +1,6 @@
 // Context, errors, profiling hooks and byte-level helpers of libzkmi355x.so.
 #include "ff.cuh"
+#include "fp_inv.cuh"
 #include "zk_common.h"
 
 #include <string.h>
@@ -101,7 +102,7 @@ __global__ void k_bench_mul_fp(uint32_t* out, uint32_t iters) {
 // operand pair through the SAME lazy-reduction code paths the group law uses (bounded adds / subs, products,
 // squares, fused double products, the zero test on unreduced values, inversion, full reduction, lane-pair Fp2)
 // and stores fully reduced plain integers (dense words) for comparison with host big-integer arithmetic.
-static constexpr int FP_SELFTEST_OUTS = 16;
+static constexpr int FP_SELFTEST_OUTS = 18;
 __global__ void k_fp_selftest(uint32_t* __restrict__ out, const uint32_t* __restrict__ a_words, const uint32_t* __restrict__ b_words, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;                      // n is even and pairs (2k, 2k+1) stay together: the lane-pair ops below are uniform
@@ -140,6 +141,8 @@ __global__ void k_fp_selftest(uint32_t* __restrict__ out, const uint32_t* __rest
     put(13, fp_from_mont(fe_sqr(x).v));
     put(14, fp_from_mont(fe_mul(fe_sub(x, y), fe_add(x, y)).v));
     put(15, fp_from_mont(fe_mul_inline(a, b)));
+    put(16, fp_from_mont(fe_inv_fast(fe_add(fe_dbl(a), fe_neg(a)))));                  // lockstep inversion (fp_inv.cuh) of a lazily reduced a
+    put(17, fp_from_mont(fe_inv_fast(x).v));                                            // ... and of the lane pair's Fp2 value
 }
 
 }  // namespace zk
