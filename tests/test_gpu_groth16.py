@@ -260,3 +260,31 @@ def test_prove_from_the_interchange_files():
     rc, a, b, c = q.groth16_prove(opk1, opk2, cs.mid, bytes(sol), P.fr_to_bytes(r), P.fr_to_bytes(s), 1)
     assert rc == 0 and (proof.a, proof.b, proof.c) == (a, b, c)
     prover.close()
+
+
+@pytest.mark.parametrize("n,curves", [(64, 3), (1000, 3), (1 << 14, 3), (1 << 16, 2), (1 << 16, 1)])
+def test_batch_affine_accumulation_gives_the_same_proofs(monkeypatch, n, curves):
+    """The optional batch-affine bucket accumulation (csrc/msm_ba.cuh; ZK_MSM_BA_CURVES, off by default: DESIGN.md) under the
+    proof-level parity check: same bytes as the trapdoor oracle and as the default XYZZ path, pipelined as well."""
+    cs, w = RC.iterated_cubic(n, 0xBA0000 + n)
+    rng = seeded_rng(0x5EED0BA0 + n)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, _ = Groth16.keygen(lambda: next(it), cs)
+    ref = Groth16(cs, pk)
+    monkeypatch.setenv("ZK_MSM_BA_CURVES", str(curves))
+    if n < 1 << 14:
+        monkeypatch.setenv("ZK_MSM_BA_ROUNDS", "3")          # small keys: auto would choose no rounds
+    ba = Groth16(cs, pk)
+    L, R_, Oo = csrs(cs)
+    rs = [(rng(), rng()) for _ in range(3)]
+    ba.set_witness(w)
+    for slot, (r, s) in enumerate(rs):
+        ba.prove_async(None, r, s, slot)
+    for slot, (r, s) in enumerate(rs):
+        got = ba.prove_wait(slot)
+        exp = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+        assert (got.a, got.b, got.c) == exp
+        p0 = ref.prove_rs(w, r, s)
+        assert (p0.a, p0.b, p0.c) == exp
+    ref.close(); ba.close()

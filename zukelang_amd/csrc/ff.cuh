@@ -626,16 +626,8 @@ template <int A> FF_INLINE FpWords fp_from_mont(const FpB<A>& a) {
     one.v[0] = 1;
     return fp_pack(fp_canon(fe_mul(a, one)));
 }
-// (a R)^-1 * R^3 / R = a^-1 R; inv(0) = 0
-template <int A> FF_INLINE FpB<2> fe_inv(const FpB<A>& a) {
-    const FpWords w = fp_pack(fp_canon(a));
-    FpWords iw;
-    words_inv<FpParams>(iw.w, w.w);
-    FpB<1> r3;
-#pragma unroll
-    for (int i = 0; i < FPL; i++) r3.v[i] = FP29_R3[i];
-    return fe_mul(fp_unpack(iw), r3);
-}
+// fe_inv(FpB): see fp_inv.cuh (included at the end of this header) -- the lockstep inversion serves every caller.
+template <int A> FF_INLINE FpB<2> fe_inv(const FpB<A>& a);
 
 // ------------------------------------------------------------------ Fp2 = Fp[u]/(u^2 + 1)
 template <int B> struct Fp2B {
@@ -668,10 +660,7 @@ template <int A> FF_INLINE Fp2B<4> fe_sqr(const Fp2B<A>& a) {
     const FpB<2> q = fe_mul(a.c0, a.c1);
     return {p, fe_dbl(q)};
 }
-template <int A> FF_INLINE Fp2B<4> fe_inv(const Fp2B<A>& a) {
-    const FpB<2> d = fe_inv(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
-    return {fe_mul(a.c0, d), fe_neg(fe_mul(a.c1, d))};
-}
+template <int A> FF_INLINE Fp2B<4> fe_inv(const Fp2B<A>& a);      // fp_inv.cuh
 
 // ------------------------------------------------------------------ Fp2 split over a lane pair
 // Lane 2k holds the c0 component, lane 2k+1 the c1 component of the same Fp2 value; partners trade
@@ -827,3 +816,5 @@ template <int A, int B, int C, int D> FF_INLINE FpB<2> fe_mul_sub(const FpB<A>& 
 template <class X, class Y, class Z, class W> FF_INLINE auto fe_mul_sub(const X& a, const Y& b, const Z& c, const W& d) { return fe_sub(fe_mul(a, b), fe_mul(c, d)); }
 
 }  // namespace zk
+
+#include "fp_inv.cuh"

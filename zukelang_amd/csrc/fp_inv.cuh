@@ -142,6 +142,13 @@ template <int A> FF_INLINE FpB<2> fe_inv_fast(const FpB<A>& a) {
     for (int i = 0; i < FPL; i++) r3.v[i] = FP29_R3[i];
     return fe_mul(r, r3);
 }
+// the library's fe_inv for Fp and for a whole Fp2 on one lane (to-affine conversions, key-time window tables): the same
+// inversion -- a single lane pays ~25 k instructions either way, 64 lanes at once no longer pay the slowest lane's loop counts
+template <int A> FF_INLINE FpB<2> fe_inv(const FpB<A>& a) { return fe_inv_fast(a); }
+template <int A> FF_INLINE Fp2B<4> fe_inv(const Fp2B<A>& a) {
+    const FpB<2> d = fe_inv_fast(fe_add(fe_sqr(a.c0), fe_sqr(a.c1)));
+    return {fe_mul(a.c0, d), fe_neg(fe_mul(a.c1, d))};
+}
 // lane-pair Fp2: 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2); both lanes invert the (shared) norm
 template <int A> FF_INLINE Fp2HB<4> fe_inv_fast(const Fp2HB<A>& a) {
     const FpB<2> s = fe_sqr(a.v);

@@ -720,12 +720,19 @@ int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, ui
 // Batch-affine rounds before the XYZZ accumulate: halve the runs until ~2-3 entries per bucket are left (uniform digits; the
 // XYZZ finisher takes whatever a skewed bucket still holds).  Resident keys only (one bucket set).
 static uint32_t ba_rounds_for(const MsmBases& b, uint32_t nbuckets) {
-    const int forced = getenv("ZK_MSM_BA_ROUNDS") ? atoi(getenv("ZK_MSM_BA_ROUNDS")) : -1;      // 0 = off, -1 = auto (read per workspace: tests switch it)
-    if (!b.precomp || forced == 0) return 0;
+    if (!b.precomp) return 0;
+    // ZK_MSM_BA_ROUNDS: 0 = off, k > 0 = exactly k rounds (tests, experiments), unset = auto for the curves ZK_MSM_BA_CURVES names
+    // (bit 0: G1, bit 1: G2).  Default: none -- measured on MI355X: the rounds re-read what they add from HBM, ~1 KB
+    // per G1 addition in round 0 (two random 128-byte-line gathers of each table entry), and lose to the register-resident XYZZ
+    // accumulate for G1; for G2 they break even.  Read per workspace, not cached: tests switch it.
+    const int forced = getenv("ZK_MSM_BA_ROUNDS") ? atoi(getenv("ZK_MSM_BA_ROUNDS")) : -1;
+    if (forced == 0) return 0;
+    if (forced > 0) return forced > 24 ? 24 : (uint32_t)forced;
+    const int curves = getenv("ZK_MSM_BA_CURVES") ? atoi(getenv("ZK_MSM_BA_CURVES")) : 0;
+    if (!(curves & (b.curve == CURVE_G1 ? 1 : 2))) return 0;
     const uint64_t mean = b.n * b.nw / nbuckets;
     uint32_t r = 0;
     while (((uint64_t)8 << r) <= mean) r++;                 // mean in [8, 16) -> 1 round ... [2^(k+2), 2^(k+3)) -> k rounds
-    if (forced > 0) r = (uint32_t)forced;
     return r > 24 ? 24 : r;
 }
 int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero) {
