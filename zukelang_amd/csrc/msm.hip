@@ -500,8 +500,60 @@ __global__ __launch_bounds__(DS_THREADS) void k_msm_digit_sums(TailJobs jobs, Di
     if (blockIdx.z < jobs.n1) digit_sums_body<Fp, DS_THREADS>(jobs.j[blockIdx.z], p, lds);
     else digit_sums_body<Fp2H, DS_THREADS>(jobs.j[blockIdx.z], p, lds);
 }
-// V[win][k] = sum_d d * S[win][k][d]
+// V[win][k] = sum_d d * S[win][k][d], d < cnt <= DW_POINTS, as the sum of all suffix sums: sum_{t>=1} (sum_{d>=t} S[d]).
+// A suffix scan (log2 rounds of "point d += point d + 2^r") followed by a tree sum over t = 1..cnt-1: 2 log2(DW_POINTS) = 16
+// dependent additions, every one an exchange through LDS, no doublings and no per-point double-and-add (the first version
+// multiplied each S[d] by d with 8 doublings + up to 8 additions before a 9-level tree: 25 links, 265 spilled registers).
+static constexpr uint32_t DW_POINTS = 256;
+FF_INLINE uint32_t* lane_limbs(Fp& a) { return a.v; }
+FF_INLINE uint32_t* lane_limbs(Fp2H& a) { return a.v.v; }
 template <class T, int NT> FF_INLINE void digit_weight_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
+    constexpr int XB = RawLayout<T>::XYZZ;
+    const uint8_t* __restrict__ S = job.red;
+    uint8_t* __restrict__ V = job.wsum;
+    constexpr uint32_t LP = Lanes<T>::N;
+    const uint32_t k = blockIdx.x, win = blockIdx.y, t = threadIdx.x, pt = t / LP;
+    const uint32_t cnt = k == 0 ? p.nd0 : p.nd1;
+    const uint8_t* base = S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + (k == 0 ? 0 : p.nd0));
+    const bool mine = pt < DW_POINTS;                       // G1 jobs use half of the workgroup's lanes; everyone keeps the barriers
+    Xyzz<T> acc = xyzz_inf<T>();
+    if (mine && pt >= 1 && pt < cnt) acc = xyzz_load_raw<T>(base + (uint64_t)XB * pt);
+    // rounds 0..7: suffix scan, partner = pt + 2^r;  round 8: drop point 0 (weight 0);  rounds 8..15: tree, partner = pt + 128 >> (r-8)
+    for (uint32_t r = 0; r < 16; r++) {
+        const bool scan = r < 8;
+        const uint32_t step = scan ? (1u << r) : (DW_POINTS / 2) >> (r - 8);
+        if (r == 8 && pt == 0) acc = xyzz_inf<T>();
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+            for (int l = 0; l < FPL; l++) {
+                lds[l][t] = lane_limbs(acc.x)[l]; lds[FPL + l][t] = lane_limbs(acc.y)[l];
+                lds[2 * FPL + l][t] = lane_limbs(acc.zz)[l]; lds[3 * FPL + l][t] = lane_limbs(acc.zzz)[l];
+            }
+        }
+        __syncthreads();
+        const bool act = mine && (scan ? pt + step < DW_POINTS : pt < step);
+        if (act) {
+            Xyzz<T> q;
+            const uint32_t src = t + step * LP;
+#pragma unroll
+            for (int l = 0; l < FPL; l++) {
+                lane_limbs(q.x)[l] = lds[l][src]; lane_limbs(q.y)[l] = lds[FPL + l][src];
+                lane_limbs(q.zz)[l] = lds[2 * FPL + l][src]; lane_limbs(q.zzz)[l] = lds[3 * FPL + l][src];
+            }
+            xyzz_add_impl(acc, q);
+        }
+    }
+    if (t < LP) xyzz_store_raw<T>(V + (uint64_t)XB * (2 * win + k), acc);
+}
+__global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
+    __shared__ uint32_t lds[LANE_POINT_WORDS][DW_THREADS];
+    if (blockIdx.z < jobs.n1) digit_weight_body<Fp, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
+    else digit_weight_body<Fp2H, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
+}
+// windows above 16 bits (config 3's sweep): more than DW_POINTS digit values per half -- every point multiplies its digit sums by
+// their weights (double-and-add) and sums them before the tree.  Not on the default path (c <= 16).
+template <class T, int NT> FF_INLINE void digit_weight_wide_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint8_t* __restrict__ S = job.red;
     uint8_t* __restrict__ V = job.wsum;
@@ -519,10 +571,10 @@ template <class T, int NT> FF_INLINE void digit_weight_body(const TailJob& job, 
     block_tree_sum<T, NT>(acc, lds);
     if (threadIdx.x < LP) xyzz_store_raw<T>(V + (uint64_t)XB * (2 * win + k), acc);
 }
-__global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
+__global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight_wide(TailJobs jobs, DigitPlan p) {
     __shared__ uint32_t lds[LANE_POINT_WORDS][DW_THREADS];
-    if (blockIdx.z < jobs.n1) digit_weight_body<Fp, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
-    else digit_weight_body<Fp2H, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
+    if (blockIdx.z < jobs.n1) digit_weight_wide_body<Fp, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
+    else digit_weight_wide_body<Fp2H, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
 }
 // W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one point).
 // The result leaves in the DENSE, fully reduced layout (it is an output of the library).
@@ -911,7 +963,8 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 4 values; G1: 8)
     const uint32_t per_wg = (n2 ? DS_THREADS / 2 : DS_THREADS) / DS_GROUP;
     hipLaunchKernelGGL(k_msm_digit_sums, dim3((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count), dim3(DS_THREADS), 0, s, jobs, dp);
-    hipLaunchKernelGGL(k_msm_digit_weight, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
+    if (dp.nd0 <= DW_POINTS && dp.nd1 <= DW_POINTS) hipLaunchKernelGGL(k_msm_digit_weight, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
+    else hipLaunchKernelGGL(k_msm_digit_weight_wide, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
     hipLaunchKernelGGL(k_msm_final, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb);
     HIPCHK(hipGetLastError());
     return ZK_OK;
