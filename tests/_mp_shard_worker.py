@@ -88,6 +88,41 @@ def main():
                 a = O.g1_add(a, part[:96]); c = O.g1_add(c, part[96:192]); b = O.g2_add(b, part[192:])
             ej = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rs[j][0]), P.fr_to_bytes(rs[j][1]))
             assert (a, b, c) == ej, "rank %d: distributed-Fr group proof %d differs" % (rank, j)
+        # the RCCL branch of exchange_slices (all_to_all_single with per-destination splits) has never run on hardware: drive its
+        # split arithmetic here with an emulation of the collective on top of gloo, full and clipped (non-zero prefix) bounds alike
+        import torch
+        from zukelang_amd.groth16 import clip_bounds
+        real_backend, real_a2a = dist.get_backend, getattr(dist, "all_to_all_single")
+
+        def fake_all_to_all_single(out, inp, out_splits, in_splits):
+            blobs = [None] * world
+            dist.all_gather_object(blobs, (bytes(inp.numpy().tobytes()), list(in_splits)))
+            pos = 0
+            for j, (data, splits) in enumerate(blobs):
+                start = sum(splits[:rank])
+                assert splits[rank] == out_splits[j], "split mismatch between sender %d and receiver %d" % (j, rank)
+                assert sum(splits) == len(data), "sender %d: splits do not cover its input" % j
+                if out_splits[j]:
+                    out[pos:pos + out_splits[j]] = torch.frombuffer(bytearray(data[start:start + splits[rank]]), dtype=torch.uint8)
+                pos += out_splits[j]
+            assert pos == out.numel()
+        try:
+            dist.get_backend = lambda *a, **k: "nccl"
+            dist.all_to_all_single = fake_all_to_all_single
+            for vec, bounds in ((va, b1), (vb, b2), (va, clip_bounds(b1, 3 + n + 2)), (va, clip_bounds(b1, 1)), (vc, clip_bounds(b1, p1 - 1))):
+                mine_b = bounds[rank]
+                got = exchange_slices(torch.from_numpy(np.frombuffer(frs(vec), dtype=np.uint8).copy()), bounds, rank, world)
+                # the same exchange through the gloo branch is the expectation: rank j's vector is msm_scalar_vectors(..., rs[j])
+                exp = b""
+                for j in range(world):
+                    vj = msm_scalar_vectors(n, RC.fr_ints(v), RC.fr_ints(ww), RC.fr_ints(h), w, cs.mid, *rs[j])
+                    src = vj[0] if vec is va else (vj[1] if vec is vc else vj[2])
+                    exp += frs(src[mine_b[0]:mine_b[1]])
+                assert bytes(got.numpy().tobytes()) == exp, "rank %d: all_to_all split arithmetic" % rank
+            # the A vector really is zero beyond its prefix: clipping loses nothing
+            assert not any(va[3 + n + 2:])
+        finally:
+            dist.get_backend, dist.all_to_all_single = real_backend, real_a2a
         # collective error agreement: a failure only ONE rank sees reaches every rank before the next collective
         from zukelang_amd.groth16 import agree_on_status
         assert agree_on_status(0) == 0

@@ -130,8 +130,12 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
         // falls off a cliff beyond (24 streams x 1 ms of 1-workgroup kernels: 72 ms, scripts/proto/concurrency.hip),
         // so queues are better spent on MORE PROOFS in flight than on the three MSMs of one proof
         // (2^16: 3.9 ms/proof with 8 x 3 streams, 2.9 ms with 15 x 1).  ZK_SLOT_STREAMS=3 restores the fork.
+        // Slot 0 -- the slot of the synchronous zk_groth16_prove -- keeps two more streams and forks onto them while it is the ONLY
+        // proof in flight: the G2 product's latency-bound reduction chain then runs beside the G1 products instead of in front of
+        // them (single-proof latency; with other proofs in flight it stays on one stream like every other slot).
         const char* ss = getenv("ZK_SLOT_STREAMS");
-        if (getenv("ZK_SERIAL_STREAMS") || !ss || atoi(ss) < 3) {
+        const bool want3 = ss ? atoi(ss) >= 3 : idx == 0;
+        if (getenv("ZK_SERIAL_STREAMS") || !want3) {
             sl->s1 = sl->s2 = sl->s0;
             sl->serial = true;
         } else {
@@ -223,13 +227,20 @@ static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const ui
 // that slice ((hi1-lo1), (hi1-lo1), (hi2-lo2) elements).  {C on s0, B on s1, A on s2} -> affine bytes (or raw
 // XYZZ partial sums) -> pinned host buffer.
 static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC, const void* dB, bool raw) {
+    // fork onto the slot's extra streams only while no other proof is in flight on this key (and never when ZK_SLOT_STREAMS forces it)
+    bool serial = sl.serial;
+    if (!serial && !getenv("ZK_SLOT_STREAMS"))
+        for (uint32_t i = 0; i < MAX_SLOTS; i++)
+            if (k.slots[i] && k.slots[i].get() != &sl && k.slots[i]->busy) serial = true;
     char* res = sl.results.as<char>();
     char* out = sl.out_dev.as<char>();
     const size_t g1b = xyzz_bytes(CURVE_G1);
-    HIPCHK(hipEventRecord(sl.fork, sl.s0));
-    HIPCHK(hipStreamWaitEvent(sl.s1, sl.fork, 0));
-    HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
-    if (sl.serial) {
+    if (!serial) {
+        HIPCHK(hipEventRecord(sl.fork, sl.s0));
+        HIPCHK(hipStreamWaitEvent(sl.s1, sl.fork, 0));
+        HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
+    }
+    if (serial) {
         // one stream: sort + accumulate (A and C together: same bases), then ALL reductions as one chain of launches
         ZKCHK(msm_sort_accumulate(k.g2, sl.wsB, dB, sl.s0));
         MsmWorkspace* ws[2] = {&sl.wsA, &sl.wsC};

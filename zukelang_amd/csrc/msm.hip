@@ -467,12 +467,17 @@ struct DigitPlan {
 // workgroup -- 2-4 buckets per lane, 6 levels -- finishes sooner but keeps four times as many waves busy for two thirds
 // of that time; with a dozen proofs in flight SIMD time is what counts.)  NT threads hold NT / lanes points.
 static constexpr uint32_t DS_GROUP = 16;
+// ... G2 (lane pairs: an addition is ~27 us on a lone wave against ~13 us in G1) takes 32 points per digit value: 4-8 serial
+// additions + 5 tree levels instead of 8-16 + 4, so the mixed-curve launch does not wait for the G2 chain twice as long
+template <class T> struct DsGroup { static constexpr uint32_t N = 16; };
+template <> struct DsGroup<Fp2H> { static constexpr uint32_t N = 32; };
 static constexpr int DS_THREADS = 128, DW_THREADS = 512;
 template <class T, int NT> FF_INLINE void digit_sums_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint8_t* __restrict__ buckets = job.buckets;
     const uint32_t* __restrict__ offsets = job.offsets;
     uint8_t* __restrict__ S = job.red;
+    constexpr uint32_t DS_GROUP = DsGroup<T>::N;
     constexpr uint32_t LP = Lanes<T>::N, PER_WG = NT / LP / DS_GROUP;
     const uint32_t win = blockIdx.y, pt = threadIdx.x / LP, sub = pt / DS_GROUP, lane = pt % DS_GROUP;
     if (blockIdx.x * PER_WG >= p.nd0 + p.nd1) return;             // whole workgroup (the launch is sized for the smaller PER_WG)
@@ -736,6 +741,7 @@ int proof_points_to_bytes_dev(const void* d_g1, uint32_t n1, const uint32_t* off
     ProofOffsets off{};
     for (uint32_t i = 0; i < n1; i++) off.g1[i] = off1[i];
     for (uint32_t i = 0; i < n2; i++) off.g2[i] = off2[i];
+    ScopedTimer t("proof_to_bytes", s);
     hipLaunchKernelGGL(k_proof_to_bytes, dim3(n1 + n2), dim3(64), 0, s, (const uint8_t*)d_g1, n1, (const uint8_t*)d_g2, off, (uint8_t*)d_out);
     HIPCHK(hipGetLastError());
     return ZK_OK;
@@ -957,15 +963,27 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     ScopedTimer t(fam, s);
     dim3 gf = grid_for(max_lanes, 128);
     gf.z = count;
-    hipLaunchKernelGGL(k_msm_fixup, gf, dim3(128), 0, s, jobs);
-    hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
+    {
+        ScopedTimer t1("msm_reduce:fixup", s);
+        hipLaunchKernelGGL(k_msm_fixup, gf, dim3(128), 0, s, jobs);
+        hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
+    }
     const DigitPlan dp = digit_plan(b.c);
-    // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 4 values; G1: 8)
-    const uint32_t per_wg = (n2 ? DS_THREADS / 2 : DS_THREADS) / DS_GROUP;
-    hipLaunchKernelGGL(k_msm_digit_sums, dim3((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count), dim3(DS_THREADS), 0, s, jobs, dp);
-    if (dp.nd0 <= DW_POINTS && dp.nd1 <= DW_POINTS) hipLaunchKernelGGL(k_msm_digit_weight, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
-    else hipLaunchKernelGGL(k_msm_digit_weight_wide, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
-    hipLaunchKernelGGL(k_msm_final, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb);
+    // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 2 values; G1: 8)
+    const uint32_t per_wg = n2 ? DS_THREADS / 2 / DsGroup<Fp2H>::N : DS_THREADS / DsGroup<Fp>::N;
+    {
+        ScopedTimer t2("msm_reduce:digit_sums", s);
+        hipLaunchKernelGGL(k_msm_digit_sums, dim3((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count), dim3(DS_THREADS), 0, s, jobs, dp);
+    }
+    {
+        ScopedTimer t3("msm_reduce:digit_weight", s);
+        if (dp.nd0 <= DW_POINTS && dp.nd1 <= DW_POINTS) hipLaunchKernelGGL(k_msm_digit_weight, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
+        else hipLaunchKernelGGL(k_msm_digit_weight_wide, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
+    }
+    {
+        ScopedTimer t4("msm_reduce:final", s);
+        hipLaunchKernelGGL(k_msm_final, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb);
+    }
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }

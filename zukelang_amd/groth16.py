@@ -115,10 +115,17 @@ def all_gather_bytes(part, world):
     return np.ascontiguousarray(torch.cat(out).cpu().numpy())
 
 
+def clip_bounds(bounds, nz):
+    """Slices [lo, hi) cut to the non-zero prefix [0, nz) of a scalar vector (the A vector of a Groth16 proof is zero beyond
+    a | d1 | b1 | ti1: groth16.ml:128-134 touches no other key point): a rank whose slice lies beyond it exchanges nothing."""
+    return [(min(lo, nz), min(hi, nz)) for lo, hi in bounds]
+
+
 def exchange_slices(full, bounds, rank, world, out=None):
     """The exchange step of the distributed Fr stage: every rank holds the scalar vector of ONE proof
     over the whole base pool (`full`: uint8, 32 B per element) and needs slice [lo_rank, hi_rank) of EVERY
-    rank's vector.  Returns `world` blocks of this rank's slice length, in rank order.
+    rank's vector.  Returns `world` blocks of this rank's slice length, in rank order.  `bounds` may be clipped
+    (clip_bounds): elements outside every slice are simply not shipped.
     RCCL (backend nccl): one all-to-all with per-destination splits, device to device over xGMI.
     gloo (CPU tests, single-GPU rehearsal): every rank gathers every vector and keeps its slice."""
     import torch
@@ -128,7 +135,9 @@ def exchange_slices(full, bounds, rank, world, out=None):
     if dist.get_backend() == "nccl":
         if out is None:
             out = torch.empty(world * mine, dtype=torch.uint8, device=full.device)
-        dist.all_to_all_single(out, full, [mine] * world, [32 * (b - a) for a, b in bounds])
+        # input: the slices in rank order are the contiguous prefix [bounds[0].lo, bounds[-1].hi) of the vector
+        first, last = 32 * bounds[0][0], 32 * bounds[-1][1]
+        dist.all_to_all_single(out, full[first:last], [mine] * world, [32 * (b - a) for a, b in bounds])
         return out
     t = full.detach().cpu() if isinstance(full, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(full, dtype=np.uint8).copy())
     outs = [torch.empty_like(t) for _ in range(world)]
@@ -424,9 +433,14 @@ class GroupProver:
         dev = torch.device("cuda", torch.cuda.current_device())
         u8 = dict(dtype=torch.uint8, device=dev)
         self.len1, self.len2 = 32 * (self.hi1 - self.lo1), 32 * (self.hi2 - self.lo2)
+        # the A vector is zero beyond a | d1 | b1 | ti1[n+2] (or the n Lagrange points): only that prefix travels (-28 % volume)
+        self.nzA = 3 + (prover.circuit.n + 2)
+        self.boundsA = clip_bounds(self.bounds1, self.nzA)
+        self.lenA = 32 * (self.boundsA[self.rank][1] - self.boundsA[self.rank][0])
         # per owned proof of the round: the owner's full vectors A, C, B and the received slices [world][slice]
         self.full = [[torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p2, **u8)] for _ in range(self.K)]
         self.recv = [[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.K)]
+        self.recvA = [torch.zeros(W * self.lenA, **u8) for _ in range(self.K)]      # compact landing buffer of the clipped A slices
         self.count = 0                              # proofs handled so far: proof i of the job belongs to rank i % world
         prover.reserve_slots(self.batch + self.K)
         torch.cuda.current_stream().synchronize()
@@ -460,7 +474,10 @@ class GroupProver:
                 _lib.check(worst)
             raise _lib.ZkError(worst, "a peer rank failed in the Fr stage of this round")
         for k in range((count + self.world - 1) // self.world):       # every rank takes part in every exchange of the round
-            for i, bounds in ((0, self.bounds1), (1, self.bounds1), (2, self.bounds2)):
+            exchange_slices(self.full[k][0], self.boundsA, self.rank, self.world, out=self.recvA[k])
+            if self.lenA:       # [world][lenA] -> the head of each owner's [len1] block; the tail stays zero (never written)
+                self.recv[k][0].view(self.world, self.len1)[:, :self.lenA].copy_(self.recvA[k].view(self.world, self.lenA))
+            for i, bounds in ((1, self.bounds1), (2, self.bounds2)):
                 exchange_slices(self.full[k][i], bounds, self.rank, self.world, out=self.recv[k][i])
         self.torch.cuda.current_stream().synchronize()        # the slices have landed before the library's streams read them
 
