@@ -97,7 +97,11 @@ typedef struct {
  *   g1: a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid[n_mid]   (ltd_mid in Var.Map key order)
  *   g2: b2 | d2 | ti2[n+2]
  *   mid[k] != 0  <=>  variable k is in Dom(ltd_mid) (= circuit.mids, groth16.ml:74-79).
- * Uploads once, precomputes the per-n tables of the Fr stage, returns a handle. */
+ * Uploads once, precomputes the per-n tables of the Fr stage, returns a handle.
+ * Base points (here, in zk_msm_g1/g2 and in the Pinocchio upload) are checked for a canonical encoding and the curve equation
+ * (ZK_ERR_ARG / ZK_ERR_NOT_ON_CURVE) and are otherwise TRUSTED to lie in the prime-order subgroup G1 / G2, as every point an
+ * OCaml host obtained from Bls12_381.G1/G2 does (of_bytes_exn / of_compressed_bytes_exn reject anything else, curve.ml:199-212).
+ * The entry points that take points from outside -- zk_g1/g2_decompress, zk_pairing_*, zk_*_verify -- do check the subgroup. */
 int zk_groth16_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                          const uint8_t* mid /* m */, const uint8_t* pk_g1, size_t pk_g1_points,
                          const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);

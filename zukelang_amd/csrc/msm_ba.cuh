@@ -162,6 +162,9 @@ struct BaJobs {
     uint64_t cap[MAX_ACC_JOBS];              // capacity of dst in points (a lane never writes beyond it)
 };
 
+#ifndef BA_OCC
+#define BA_OCC 2
+#endif
 enum BaKind : int { BA_ADD = 0, BA_DBL = 1, BA_COPY1 = 2, BA_COPY2 = 3, BA_INF = 4 };
 
 // operands of one output item
@@ -215,7 +218,7 @@ FF_INLINE int ba_classify(const BaItem<F, FIRST>& it, const typename BaTypes<F>:
 }
 
 template <class F, bool FIRST>
-__global__ __launch_bounds__(128, 2) void k_ba_round(const uint8_t* __restrict__ table, BaJobs jobs, uint32_t nb, uint32_t L) {
+__global__ __launch_bounds__(128, BA_OCC) void k_ba_round(const uint8_t* __restrict__ table, BaJobs jobs, uint32_t nb, uint32_t L) {
     using T = typename BaTypes<F>::T;
     constexpr bool PAIR = std::is_same<F, Fp2H>::value;
     constexpr int PB = BaLayout<F>::POINT, CB = BaLayout<F>::COORD;
