@@ -5,7 +5,7 @@ Workload = Groth16 prove of the synthetic iterated-cubic R1CS wit
 the witness already resident in HBM.  A STEP = `--proofs-per-step` (16) consecutive proofs of the pipelined prover
 (`--inflight` proofs in flight, one HIP stream each; the pipeline is NOT drained between steps), so that the default
 20 steps are >= 0.5 s of timed GPU work.  N = 1: n = 2^16 constraints (BASELINE.json configs[1]) is the headline
-`value`; the same run then times the other single-GPU configurations (2^18, 2^20 = config 3's size, optionally 2^22 =
+`value`; the same run then times the other single-GPU configurations (2^18, 2^20 = config 3's size, 2^22 =
 config 4's size on one GPU, and Pinocchio 2^18 = config 5) and reports them under `other_workloads`, each with its own
 parity check.  N > 1: proofs of n = 2^16 * N constraints (BASELINE config 4 = --log-n 19 at N = 8) whose three
 multi-scalar products are sharded by base points over the ranks (one process per GPU).  Proofs go in rounds: rank j runs
@@ -355,7 +355,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps")
     ap.add_argument("--proofs-per-step", type=int, default=16)
     ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU of the headline workload")
-    ap.add_argument("--sizes", default="18,20", help="one GPU: further log2 sizes timed in the same run and reported under other_workloads ('' = none; add 22 for config 4's size: ~2 min of host-side key generation)")
+    ap.add_argument("--sizes", default="18,20,22", help="one GPU: further log2 sizes timed in the same run and reported under other_workloads ('' = none; '' = none)")
     ap.add_argument("--no-pinocchio", action="store_true", help="skip the Pinocchio 2^18 workload (config 5) of the default run")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs): same as --sizes '' --no-pinocchio")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel summary of a rocprofv3 --pmc collection (the *_counter_collection.csv of one pass).
 
-usage: pmc_summary.py <counter_collection.csv> [--proofs N] [--skip-first K] [--json out.json]
+usage: pmc_summary.py <counter_collection.csv> [--proofs N | --steady KERNEL] [--json out.json]
+
+--steady KERNEL: count only dispatches from the first dispatch of KERNEL on (the first kernel of the first proof, e.g.
+k_fr_to_mont_flag2: key set-up launches the same NTT kernels and would blur the per-proof figures) and take the number of
+KERNEL dispatches as the number of proofs.
 
 Kernel names are shortened to the function name; values are summed per kernel over the run and divided by the
 number of proofs (launch counts that are not a multiple of N belong to set-up kernels: they are listed as they are).
@@ -27,8 +31,16 @@ def main():
     proofs = int(args[args.index("--proofs") + 1]) if "--proofs" in args else 1
     out_json = args[args.index("--json") + 1] if "--json" in args else None
     acc = OrderedDict()
+    steady = args[args.index("--steady") + 1] if "--steady" in args else None
     with open(path, newline="") as f:
-        for row in csv.DictReader(f):
+        rows = sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"]))
+    if steady:
+        first = next(i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == steady)
+        rows = rows[first:]
+        counters = {r["Counter_Name"] for r in rows}
+        proofs = sum(1 for r in rows if short(r["Kernel_Name"]) == steady) // max(1, len(counters))
+    if True:
+        for row in rows:
             k = (short(row["Kernel_Name"]), row["Counter_Name"])
             e = acc.setdefault(k, {"sum": 0.0, "launches": 0, "grid": 0, "vgpr": int(row["VGPR_Count"]), "agpr": int(row["Accum_VGPR_Count"]),
                                    "scratch": int(row["Scratch_Size"]), "lds": int(row["LDS_Block_Size"])})

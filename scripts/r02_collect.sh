@@ -15,10 +15,10 @@ for st in "$@"; do
       timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o run -- python bench.py --no-cpu-baseline --inflight 1 --steps 10 > $O/bench1_under_rocprofv3.json 2> $O/stats1.err || { tail -20 $O/stats1.err; exit 1; };;
     pmc) for c in FETCH_SIZE WRITE_SIZE; do echo "== pmc $c"
         timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python bench.py --no-cpu-baseline --inflight 1 --steps 6 --warmup 1 --settle 0 > $O/pmc_$c.json 2> $O/pmc_$c.err || { tail -20 $O/pmc_$c.err; exit 1; }
-        python scripts/pmc_summary.py $O/pmc_$c/run_counter_collection.csv --proofs $PROOFS --json $O/pmc_$c.summary.json > $O/pmc_$c.txt; done;;
+        python scripts/pmc_summary.py $O/pmc_$c/run_counter_collection.csv --steady k_fr_to_mont_flag2 --json $O/pmc_$c.summary.json > $O/pmc_$c.txt; done;;
     valu) echo "== pmc SQ_INSTS_VALU"
         timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d $O/pmc_valu -o run -- python bench.py --no-cpu-baseline --inflight 1 --steps 6 --warmup 1 --settle 0 > $O/pmc_valu.json 2> $O/pmc_valu.err || { tail -20 $O/pmc_valu.err; exit 1; }
-        python scripts/pmc_summary.py $O/pmc_valu/run_counter_collection.csv --proofs $PROOFS > $O/pmc_valu.txt; head -16 $O/pmc_valu.txt;;
+        python scripts/pmc_summary.py $O/pmc_valu/run_counter_collection.csv --steady k_fr_to_mont_flag2 > $O/pmc_valu.txt; head -16 $O/pmc_valu.txt;;
     *) echo "unknown stage $st"; exit 2;;
   esac
 done

@@ -12,6 +12,8 @@
 #pragma once
 #include "ff.cuh"
 
+#include <type_traits>
+
 namespace zk {
 
 // F is the AT-REST coordinate type (Fp = FpB<64>, Fp2, Fp2H: value bound 64 p, see ff.cuh): struct members
@@ -94,6 +96,24 @@ template <class F> FF_INLINE Xyzz<F> xyzz_dbl_aff(const Aff<F>& p) {
     const auto Y3 = fe_mul_sub(M, fe_sub(S, X3), W, p.y);
     return {X3, Y3, V, W};
 }
+// The equal-x case of a mixed addition (P + P or P + (-P)): a doubling's worth of code that a bucket loop meets once in 2^381
+// additions unless the bases repeat.  Out of line, operands through private memory (copies: the caller's accumulator stays in
+// registers), so the hot loop does not pay its register pressure.
+template <class F> __device__ __noinline__ void xyzz_madd_equal_x_fn(Xyzz<F>* out, const Aff<F>* q, int same_y) {
+    if (same_y) *out = xyzz_dbl_aff(*q);
+    else *out = xyzz_inf<F>();
+}
+template <class F> FF_INLINE void xyzz_madd_equal_x(Xyzz<F>& acc, const Aff<F>& q, bool same_y) {
+    if constexpr (std::is_same<F, Fp2H>::value) {      // the lane-pair G2 loop runs at the register limit: keep the cold path out of it
+        Xyzz<F> t;
+        const Aff<F> qc = q;
+        xyzz_madd_equal_x_fn<F>(&t, &qc, same_y ? 1 : 0);
+        acc = t;
+    } else {
+        if (same_y) acc = xyzz_dbl_aff(q);
+        else acc = xyzz_inf<F>();
+    }
+}
 // madd-2008-s: acc += q (q affine)
 template <class F> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) {
     if (aff_is_inf(q)) return;
@@ -106,8 +126,7 @@ template <class F> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) 
     const auto P = fe_sub(U2, acc.x);
     const auto R = fe_sub(S2, acc.y);
     if (fe_is_zero(P)) {
-        if (fe_is_zero(R)) acc = xyzz_dbl_aff(q);
-        else acc = xyzz_inf<F>();
+        xyzz_madd_equal_x(acc, q, fe_is_zero(R));
         return;
     }
     const auto PP = fe_sqr(P);
@@ -131,8 +150,7 @@ template <class F> FF_INLINE void xyzz_mmadd_impl(Xyzz<F>& acc, const Aff<F>& q)
     const auto P = fe_sub(q.x, acc.x);
     const auto R = fe_sub(q.y, acc.y);
     if (fe_is_zero(P)) {
-        if (fe_is_zero(R)) acc = xyzz_dbl_aff(q);
-        else acc = xyzz_inf<F>();
+        xyzz_madd_equal_x(acc, q, fe_is_zero(R));
         return;
     }
     const auto PP = fe_sqr(P);
