@@ -275,7 +275,8 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
            "group_batch": group.batch if group is not None else None}
     if group is not None:
         # exchange volume per proof and rank (device to device over xGMI): three scalar vectors, 32 B per element
-        res["exchange"] = {"all_to_all_bytes_per_proof_sent_by_owner": 32 * (2 * p1 + p2), "all_gather_bytes_per_proof_per_rank": 768,
+        res["exchange"] = {"all_to_all_bytes_per_proof_sent_by_owner": 32 * (min(group.nzA, p1) + p1 + p2),      # A: only its non-zero prefix travels
+                           "all_gather_bytes_per_proof_per_rank": 768,
                            "slice_points_g1": [hi - lo for lo, hi in group.bounds1],
                            "slice_points_g2": [hi - lo for lo, hi in group.bounds2]}
     prover.close()

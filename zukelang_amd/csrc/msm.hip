@@ -817,7 +817,8 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
         // every workgroup zeroes and flushes nbuckets counters: give it >= 4 pairs per counter to amortise that
         uint64_t wgs = maxN / (4 * (uint64_t)w.nbuckets);
         if (wgs > 256) wgs = 256;
-        if (wgs >= 64) {                                    // below that too few workgroups: the global-atomic path is cheaper
+        static const uint64_t min_wgs = getenv("ZK_SORT_MIN_WGS") ? (uint64_t)atoll(getenv("ZK_SORT_MIN_WGS")) : 64;      // tuning knob
+        if (wgs >= min_wgs) {                               // below that too few workgroups: the global-atomic path is cheaper
             w.sort_wgs = (uint32_t)wgs;
             ZKCHK(w.wgcount.alloc(4 * (size_t)w.nbuckets * wgs));
         }
