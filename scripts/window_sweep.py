@@ -16,7 +16,7 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 rows = []
 print("%4s %12s %10s %8s  %s" % ("c", "constr/s", "ms/proof", "parity", "kernel ms per proof (one proof in flight)"))
 for c in cs:
-    env = dict(os.environ, ZK_MSM_WINDOW=str(c))
+    env = dict(os.environ, ZK_MSM_WINDOW=str(c))      # (the per-kernel column comes from bench.py's un-overlapped one-proof pass)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", str(log_n), "--steps", "1", "--proofs-per-step", "12", "--warmup", "0",
                           "--inflight", "6", "--settle", "2", "--headline-only", "--no-cpu-baseline"], env=env, capture_output=True, text=True, cwd=ROOT)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]

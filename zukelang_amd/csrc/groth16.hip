@@ -229,6 +229,7 @@ static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const ui
 static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC, const void* dB, bool raw) {
     // fork onto the slot's extra streams only while no other proof is in flight on this key (and never when ZK_SLOT_STREAMS forces it)
     bool serial = sl.serial;
+    if (ctx().profiling >= 2) serial = true;      // the per-family event timers want un-overlapped launches (bench.py's one-proof-in-flight pass)
     if (!serial && !getenv("ZK_SLOT_STREAMS"))
         for (uint32_t i = 0; i < MAX_SLOTS; i++)
             if (k.slots[i] && k.slots[i].get() != &sl && k.slots[i]->busy) serial = true;
