@@ -338,7 +338,9 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
 
 def summarize(res, world, peak_products, traffic, lagrange):
     """Public form of one Groth16 workload result: throughput, latency, both accumulate rooflines, whole-prove HBM fraction."""
-    windows = 255 // int(os.environ.get("ZK_MSM_WINDOW", "16")) + 1        # resident keys: c = 16 from 2^16 points up
+    # the key's window width (groth16.hip upload): 20 bits from 2^21 points in the rank's G1 pool, 16 below (from 2^16 constraints up)
+    cbits = int(os.environ.get("ZK_MSM_WINDOW", "20" if res["p1"] // world >= 1 << 21 else "16"))
+    windows = 255 // cbits + 1
     key = "groth16_2^%d" % res["log_n"] + ("_lagrange" if lagrange else "")
     roofs = roofline_objects(res["fam_timed"], res["nproofs"], res["fam_alone"], res["n_alone"], res["pairs"], world, windows, peak_products, traffic, key)
     out = {k: res[k] for k in ("log_n", "constraints", "variables", "value", "unit", "ms_per_proof", "timed_s", "timed_proofs", "proofs_in_flight",
@@ -346,6 +348,7 @@ def summarize(res, world, peak_products, traffic, lagrange):
     out["prove_algorithmic_bytes_per_constraint"] = 928
     out["prove_hbm_frac"] = 928.0 * res["constraints"] / (res["ms_per_proof"] * 1e-3) / 1e9 / HBM_PEAK_GBS / world
     out["roofline_g1"], out["roofline_g2"] = roofs.get("g1"), roofs.get("g2")
+    out["msm_window_bits"] = cbits
     return out, roofs
 
 

@@ -239,7 +239,7 @@ def test_config3_window_sweep_is_parity_checked():
             os.environ["ZK_MSM_WINDOW"] = old
 
 
-SWEEP_WINDOWS = (12, 14, 15)
+SWEEP_WINDOWS = (12, 14, 15, 17, 20)      # 17, 20: beyond the LDS histogram -- the two-level counting sort
 
 
 def test_prove_from_the_interchange_files():

@@ -181,8 +181,14 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     k.lo1 = k.p1 * rank / world; k.hi1 = k.p1 * (rank + 1) / world;
     k.lo2 = k.p2 * rank / world; k.hi2 = k.p2 * (rank + 1) / world;
     if (k.hi1 == k.lo1 || k.hi2 == k.lo2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: more ranks than key points");
-    ZKCHK(msm_bases_from_bytes(k.g1, CURVE_G1, pk_g1 + 96 * k.lo1, k.hi1 - k.lo1, 0, true, c.stream));
-    ZKCHK(msm_bases_from_bytes(k.g2, CURVE_G2, pk_g2 + 192 * k.lo2, k.hi2 - k.lo2, 0, true, c.stream));
+    // ONE window width per key (both pools: their bucket reductions then go out as one chain of launches).  From 2^21 points
+    // in this rank's G1 pool (n >= ~2^19.6 on one GPU) 20-bit windows: 13 instead of 16 digits per scalar pay for the 16x
+    // bucket count and the two-level sort (measured, profiles/r02_window_sweep_*.json: +7.5 % at 2^20, +12 % at 2^22, -2 % at
+    // 2^19, -16 % at 2^18).  ZK_MSM_WINDOW overrides (config 3's sweep).
+    uint32_t cw = 0;
+    if (!getenv("ZK_MSM_WINDOW")) cw = (k.hi1 - k.lo1) >= ((uint64_t)1 << 21) ? 20 : msm_auto_window(k.hi1 - k.lo1, true);
+    ZKCHK(msm_bases_from_bytes(k.g1, CURVE_G1, pk_g1 + 96 * k.lo1, k.hi1 - k.lo1, cw, true, c.stream));
+    ZKCHK(msm_bases_from_bytes(k.g2, CURVE_G2, pk_g2 + 192 * k.lo2, k.hi2 - k.lo2, cw, true, c.stream));
     ZKCHK(k.mid_idx.alloc(4 * (size_t)(k.n_mid ? k.n_mid : 1)));
     if (k.n_mid) HIPCHK(hipMemcpyAsync(k.mid_idx.p, mids.data(), 4 * (size_t)k.n_mid, hipMemcpyHostToDevice, c.stream));
     ZKCHK(k.wit_resident.alloc(32 * (size_t)m));

@@ -28,6 +28,11 @@ struct MsmWorkspace {
     DevBuf worklist;                      // [0] = count, then bucket ids whose fix-up needs a whole workgroup
     DevBuf wgcount;                       // LDS-privatised sort: [workgroup][bucket] counts, then ranks
     uint32_t sort_wgs = 0;               // 0 = global-atomic path
+    // more than 2^15 buckets (windows above 16 bits): two-level counting sort -- level 1 files (bucket, reference) records into
+    // 512 coarse bins with the LDS-privatised sort above, level 2 sorts every bin by its fine bucket bits in ONE workgroup's LDS
+    uint32_t sort_fine_bits = 0;         // 0 = single level
+    DevBuf sorted2;                       // level-1 output: 8-byte records (bucket id, reference)
+    DevBuf coarse;                        // level-1 counts | offsets | cursor of the coarse bins (3 x (bins + 1) words)
     uint64_t cap_points = 0;
     uint32_t c = 0, nw = 0;
     bool precomp = false;

@@ -156,6 +156,7 @@ struct DigitArgs {
     uint32_t c, nw, precomp, nb_per_window;
     uint32_t K[9];         // the recoding constant, 288 bits
     const uint8_t* ident;  // precomp: 1 = base i is the identity: it never enters a bucket (nullptr: no filter)
+    uint32_t coarse_shift;  // two-level sort, level 1: histogram / rank by bucket >> coarse_shift and emit (bucket, reference) records
     uint32_t alias_windows; // EXPERIMENT (ZK_EXPERIMENT_TABLE_ALIAS=1, results WRONG): every window reads window 0's table entries --
                             // same additions, same number of gathers, 1/16 of the table footprint: what the 16x table traffic costs
 };
@@ -227,6 +228,7 @@ struct SortJobs {
     uint32_t* cursor[MAX_SORT_JOBS];
     uint32_t* sorted[MAX_SORT_JOBS];
     uint32_t* wgcount[MAX_SORT_JOBS];
+    uint2* sorted2[MAX_SORT_JOBS];         // two-level sort: level-1 records
 };
 __global__ void k_msm_count(SortJobs jobs, DigitArgs a) {
     const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(SortJobs jobs, 
     for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
         uint32_t key = 0, val = 0;
         const bool ok = digit_of(scalars, g % a.n, (uint32_t)(g / a.n), a, key, val);
-        (void)wave_aggregated_add(hist, ok, key);
+        (void)wave_aggregated_add(hist, ok, key >> a.coarse_shift);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) wgcount[(uint64_t)wg * nb + b] = hist[b];   // [workgroup][bucket]: coalesced
@@ -284,8 +286,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(SortJobs jobs
     for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
         uint32_t key = 0, val = 0;
         const bool ok = digit_of(scalars, g % a.n, (uint32_t)(g / a.n), a, key, val);
-        const uint32_t pos = wave_aggregated_add(cur, ok, key);
-        if (ok) sorted[pos] = val;
+        const uint32_t pos = wave_aggregated_add(cur, ok, key >> a.coarse_shift);
+        if (ok) {
+            if (a.coarse_shift) jobs.sorted2[blockIdx.y][pos] = make_uint2(key, val);
+            else sorted[pos] = val;
+        }
     }
 }
 // Column scan of the [workgroup][bucket] count matrix: one lane per bucket walks down the workgroups
@@ -331,6 +336,63 @@ __global__ __launch_bounds__(1024) void k_scan(SortJobs jobs, uint32_t nb) {
         run += counts[k];
     }
     if (t == 1023) offsets[nb] = part[1023];
+}
+
+// ---- two-level sort, level 2: ONE workgroup per coarse bin.  The bin's records are consecutive (level 1); the workgroup counts
+// their fine bucket bits in LDS, scans the counts (these ARE the final bucket offsets: bin start + exclusive prefix -- no global
+// atomic, no separate scan launch), and scatters the references with LDS cursors.  A bin that swallowed a skewed share of the
+// digits (boolean-heavy witnesses) is simply a longer loop for its workgroup: the per-record work is a few instructions.
+static constexpr uint32_t SORT_MAX_FINE = 4096;
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint32_t fine_bits, uint32_t nbins, uint32_t nb) {
+    const uint2* __restrict__ rec = jobs.sorted2[blockIdx.y];
+    const uint32_t* __restrict__ coff = jobs.cursor[blockIdx.y];          // coarse offsets (level 1 left them in its cursor array)
+    uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
+    uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
+    __shared__ uint32_t cnt[SORT_MAX_FINE];
+    __shared__ uint32_t part[SORT_THREADS];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x, nf = 1u << fine_bits, fm = nf - 1;
+    const uint32_t lo = coff[bin], hi = coff[bin + 1];
+    for (uint32_t f = t; f < nf; f += SORT_THREADS) cnt[f] = 0;
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += SORT_THREADS) {          // whole waves keep the ballots of wave_aggregated_add valid
+        const uint32_t i = base + t;
+        const bool ok = i < hi;
+        const uint32_t key = ok ? rec[i].x & fm : 0;
+        (void)wave_aggregated_add(cnt, ok, key);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..nf): every thread owns nf / SORT_THREADS consecutive counters (1..4)
+    const uint32_t per = (nf + SORT_THREADS - 1) / SORT_THREADS;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < per; k++) { const uint32_t f = t * per + k; if (f < nf) s += cnt[f]; }
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = lo + part[t] - s;
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t f = t * per + k;
+        if (f < nf) {
+            const uint32_t c = cnt[f];
+            offsets[(uint64_t)bin * nf + f] = run;
+            cnt[f] = run;                                  // becomes the bucket's cursor
+            run += c;
+        }
+    }
+    if (bin == nbins - 1 && t == 0) offsets[nb] = hi;
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += SORT_THREADS) {
+        const uint32_t i = base + t;
+        const bool ok = i < hi;
+        uint2 r = make_uint2(0, 0);
+        if (ok) r = rec[i];
+        const uint32_t pos = wave_aggregated_add(cnt, ok, r.x & fm);
+        if (ok) sorted[pos] = r.y;
+    }
 }
 
 // ------------------------------------------------------------------ accumulate: msm_acc.hip
@@ -471,15 +533,17 @@ struct DigitPlan {
 static constexpr uint32_t DS_GROUP = 16;
 // ... G2 (lane pairs: an addition is ~27 us on a lone wave against ~13 us in G1) takes 32 points per digit value: 4-8 serial
 // additions + 5 tree levels instead of 8-16 + 4, so the mixed-curve launch does not wait for the G2 chain twice as long
-template <class T> struct DsGroup { static constexpr uint32_t N = 16; };
-template <> struct DsGroup<Fp2H> { static constexpr uint32_t N = 32; };
+// WIDE (windows above 16 bits: a digit value sums 513-2048 buckets): 64 points per value for both curves, i.e. 8-32 serial
+// additions + 6 tree levels instead of 32-128 + 4
+template <class T, bool WIDE> struct DsGroup { static constexpr uint32_t N = WIDE ? 64 : 16; };
+template <bool WIDE> struct DsGroup<Fp2H, WIDE> { static constexpr uint32_t N = WIDE ? 64 : 32; };
 static constexpr int DS_THREADS = 128, DW_THREADS = 512;
-template <class T, int NT> FF_INLINE void digit_sums_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
+template <class T, int NT, bool WIDE> FF_INLINE void digit_sums_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint8_t* __restrict__ buckets = job.buckets;
     const uint32_t* __restrict__ offsets = job.offsets;
     uint8_t* __restrict__ S = job.red;
-    constexpr uint32_t DS_GROUP = DsGroup<T>::N;
+    constexpr uint32_t DS_GROUP = DsGroup<T, WIDE>::N;
     constexpr uint32_t LP = Lanes<T>::N, PER_WG = NT / LP / DS_GROUP;
     const uint32_t win = blockIdx.y, pt = threadIdx.x / LP, sub = pt / DS_GROUP, lane = pt % DS_GROUP;
     if (blockIdx.x * PER_WG >= p.nd0 + p.nd1) return;             // whole workgroup (the launch is sized for the smaller PER_WG)
@@ -502,10 +566,10 @@ template <class T, int NT> FF_INLINE void digit_sums_body(const TailJob& job, Di
     block_tree_sum<T, NT, DS_GROUP>(acc, lds);
     if (valid && lane == 0) xyzz_store_raw<T>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
 }
-__global__ __launch_bounds__(DS_THREADS) void k_msm_digit_sums(TailJobs jobs, DigitPlan p) {
+template <bool WIDE> __global__ __launch_bounds__(DS_THREADS) void k_msm_digit_sums(TailJobs jobs, DigitPlan p) {
     __shared__ uint32_t lds[LANE_POINT_WORDS][DS_THREADS];
-    if (blockIdx.z < jobs.n1) digit_sums_body<Fp, DS_THREADS>(jobs.j[blockIdx.z], p, lds);
-    else digit_sums_body<Fp2H, DS_THREADS>(jobs.j[blockIdx.z], p, lds);
+    if (blockIdx.z < jobs.n1) digit_sums_body<Fp, DS_THREADS, WIDE>(jobs.j[blockIdx.z], p, lds);
+    else digit_sums_body<Fp2H, DS_THREADS, WIDE>(jobs.j[blockIdx.z], p, lds);
 }
 // V[win][k] = sum_d d * S[win][k][d], d < cnt <= DW_POINTS, as the sum of all suffix sums: sum_{t>=1} (sum_{d>=t} S[d]).
 // A suffix scan (log2 rounds of "point d += point d + 2^r") followed by a tree sum over t = 1..cnt-1: 2 log2(DW_POINTS) = 16
@@ -815,7 +879,18 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     ZKCHK(w.cursor.alloc(4 * (size_t)(w.nbuckets + 1)));
     ZKCHK(w.sorted.alloc(4 * (size_t)maxN));
     w.sort_wgs = 0;
-    if (b.precomp && w.nbuckets <= SORT_MAX_BUCKETS) {
+    w.sort_fine_bits = 0;
+    static constexpr uint32_t COARSE_BINS = 512;
+    if (b.precomp && w.nbuckets > SORT_MAX_BUCKETS && w.nbuckets / COARSE_BINS <= SORT_MAX_FINE && maxN >= ((uint64_t)1 << 22) &&
+        !(getenv("ZK_SORT_TWO_LEVEL") && atoi(getenv("ZK_SORT_TWO_LEVEL")) == 0)) {
+        // windows above 16 bits: two levels (ZK_SORT_TWO_LEVEL=0 falls back to the global-atomic sort, for A/B)
+        w.sort_fine_bits = ceil_log2(w.nbuckets / COARSE_BINS);
+        uint64_t wgs = maxN / (4 * (uint64_t)COARSE_BINS);
+        w.sort_wgs = (uint32_t)(wgs > 256 ? 256 : wgs);
+        ZKCHK(w.wgcount.alloc(4 * (size_t)COARSE_BINS * w.sort_wgs));
+        ZKCHK(w.sorted2.alloc(8 * (size_t)maxN));
+        ZKCHK(w.coarse.alloc(4 * (size_t)3 * (COARSE_BINS + 1)));
+    } else if (b.precomp && w.nbuckets <= SORT_MAX_BUCKETS) {
         // every workgroup zeroes and flushes nbuckets counters: give it >= 4 pairs per counter to amortise that
         uint64_t wgs = maxN / (4 * (uint64_t)w.nbuckets);
         if (wgs > 256) wgs = 256;
@@ -862,18 +937,18 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
     for (uint32_t i = 0; i < count; i++) {
         MsmWorkspace& w = *ws[i];
         if (w.c != b.c || w.precomp != b.precomp || w.curve != b.curve || w.cap_points < b.n || w.nbuckets != ws[0]->nbuckets || w.chunk != ws[0]->chunk ||
-            w.sort_wgs != ws[0]->sort_wgs)
+            w.sort_wgs != ws[0]->sort_wgs || w.sort_fine_bits != ws[0]->sort_fine_bits)
             ZK_FAIL(ZK_ERR_ARG, "msm: workspace does not match bases");
         sj.scalars[i] = (const uint32_t*)d_scalars[i];
         sj.counts[i] = w.counts.as<uint32_t>(); sj.offsets[i] = w.offsets.as<uint32_t>(); sj.cursor[i] = w.cursor.as<uint32_t>();
-        sj.sorted[i] = w.sorted.as<uint32_t>(); sj.wgcount[i] = w.wgcount.as<uint32_t>();
+        sj.sorted[i] = w.sorted.as<uint32_t>(); sj.wgcount[i] = w.wgcount.as<uint32_t>(); sj.sorted2[i] = w.sorted2.as<uint2>();
         aj.offsets[i] = w.offsets.as<uint32_t>(); aj.sorted[i] = w.sorted.as<uint32_t>();
         aj.buckets[i] = w.buckets.as<uint8_t>(); aj.head[i] = w.head.as<uint8_t>(); aj.tail[i] = w.tail.as<uint8_t>();
     }
     MsmWorkspace& w = *ws[0];
     const uint32_t nbw = 1u << (b.c - 1);
     DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}, b.precomp ? b.ident.as<uint8_t>() : nullptr,
-                 (getenv("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(getenv("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u};
+                 0u, (getenv("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(getenv("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
         uint32_t off = j * b.c, wd = off >> 5, sh = off & 31;
@@ -889,7 +964,27 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
     }
     {
         ScopedTimer t("msm_sort", s);
-        if (w.sort_wgs) {
+        if (w.sort_fine_bits) {
+            // level 1 over the coarse bins (its counts / offsets / cursor live in `coarse`), level 2 writes the real offsets and references
+            const uint32_t bins = w.nbuckets >> w.sort_fine_bits;
+            SortJobs l1 = sj;
+            for (uint32_t i = 0; i < count; i++) {
+                uint32_t* c3 = ws[i]->coarse.as<uint32_t>();
+                l1.counts[i] = c3; l1.offsets[i] = c3 + (bins + 1); l1.cursor[i] = c3 + 2 * (bins + 1);
+            }
+            DigitArgs d1 = da;
+            d1.coarse_shift = w.sort_fine_bits;
+            const uint64_t total = b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
+            hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
+            dim3 gc = grid_for(bins, 256);
+            gc.y = count;
+            hipLaunchKernelGGL(k_sort_colscan, gc, dim3(256), 0, s, l1, bins, w.sort_wgs);
+            hipLaunchKernelGGL(k_scan, dim3(count), dim3(1024), 0, s, l1, bins);
+            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
+            SortJobs l2 = sj;
+            for (uint32_t i = 0; i < count; i++) l2.cursor[i] = l1.offsets[i];          // the coarse offsets (k_scan wrote offsets = cursor; the scatter advanced neither: it ranks in LDS)
+            hipLaunchKernelGGL(k_sort_fine, dim3(bins, count), dim3(SORT_THREADS), 0, s, l2, w.sort_fine_bits, bins, w.nbuckets);
+        } else if (w.sort_wgs) {
             const uint64_t total = b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
             hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
             dim3 gc = grid_for(w.nbuckets, 256);
@@ -974,10 +1069,14 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     }
     const DigitPlan dp = digit_plan(b.c);
     // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 2 values; G1: 8)
-    const uint32_t per_wg = n2 ? DS_THREADS / 2 / DsGroup<Fp2H>::N : DS_THREADS / DsGroup<Fp>::N;
+    const bool wide = dp.nd0 > DW_POINTS;
+    const uint32_t per_wg = wide ? (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, true>::N : DS_THREADS / DsGroup<Fp, true>::N)
+                                 : (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, false>::N : DS_THREADS / DsGroup<Fp, false>::N);
     {
         ScopedTimer t2("msm_reduce:digit_sums", s);
-        hipLaunchKernelGGL(k_msm_digit_sums, dim3((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count), dim3(DS_THREADS), 0, s, jobs, dp);
+        const dim3 gd((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count);
+        if (wide) hipLaunchKernelGGL(k_msm_digit_sums<true>, gd, dim3(DS_THREADS), 0, s, jobs, dp);
+        else hipLaunchKernelGGL(k_msm_digit_sums<false>, gd, dim3(DS_THREADS), 0, s, jobs, dp);
     }
     {
         ScopedTimer t3("msm_reduce:digit_weight", s);
