@@ -9,17 +9,26 @@ usage: make_pmc_traffic.py <fetch.summary.json> <write.summary.json> <workload k
 import json
 import sys
 
-FAMILY = {   # kernel (short name) -> bench.py family, per-proof kernels only
-    "k_msm_accumulate<FpB<64>, false>": "msm_accumulate_g1", "k_msm_accumulate<Fp2HB<64>, false>": "msm_accumulate_g2",
-    "k_msm_accumulate<FpB<64>, true>": "msm_accumulate_g1", "k_msm_accumulate<Fp2HB<64>, true>": "msm_accumulate_g2",
-    "k_ba_round<FpB<64>, true>": "msm_accumulate_g1", "k_ba_round<FpB<64>, false>": "msm_accumulate_g1", "k_ba_plan": "msm_accumulate",
-    "k_ba_round<Fp2HB<64>, true>": "msm_accumulate_g2", "k_ba_round<Fp2HB<64>, false>": "msm_accumulate_g2",
-    "k_msm_count": "msm_sort", "k_msm_scatter": "msm_sort", "k_scan": "msm_sort", "k_sort_count_lds": "msm_sort", "k_sort_scatter_lds": "msm_sort", "k_sort_colscan": "msm_sort",
-    "k_msm_fixup": "msm_reduce", "k_msm_fixup_big": "msm_reduce", "k_msm_digit_sums": "msm_reduce", "k_msm_digit_weight": "msm_reduce", "k_msm_final": "msm_reduce",
-    "k_proof_to_bytes": "proof_to_bytes", "k_groth16_scalars": "groth16_scalars",
-    "k_ntt_pass<false>": "ntt", "k_ntt_pass<true>": "ntt", "k_ntt_mid": "ntt", "k_tree_levels_fused": "ntt",
-    "k_spmv": "fr_pointwise", "k_check_r1cs": "fr_pointwise", "k_fr_to_mont_flag2": "fr_pointwise", "k_scale_pad": "fr_pointwise", "k_scale_pad2": "fr_pointwise", "k_reverse_pad": "fr_pointwise",
-}
+PREFIX = [   # kernel name prefix -> bench.py family, per-proof kernels only (first match wins)
+    ("k_msm_accumulate<FpB", "msm_accumulate_g1"), ("k_msm_accumulate<Fp2HB", "msm_accumulate_g2"),
+    ("k_ba_round<FpB", "msm_accumulate_g1"), ("k_ba_round<Fp2HB", "msm_accumulate_g2"), ("k_ba_plan", "msm_accumulate_g1"),
+    ("k_msm_count", "msm_sort"), ("k_msm_scatter", "msm_sort"), ("k_scan", "msm_sort"), ("k_sort_", "msm_sort"),
+    ("k_msm_fixup", "msm_reduce"), ("k_msm_digit_", "msm_reduce"), ("k_msm_final", "msm_reduce"),
+    ("k_proof_to_bytes", "proof_to_bytes"), ("k_groth16_scalars", "groth16_scalars"),
+    ("k_ntt_", "ntt"), ("k_tree_levels_fused", "ntt"),
+    ("k_spmv", "fr_pointwise"), ("k_check_r1cs", "fr_pointwise"), ("k_fr_to_mont_flag2", "fr_pointwise"), ("k_scale_pad", "fr_pointwise"), ("k_reverse_pad", "fr_pointwise"),
+]
+
+
+class _Family(dict):
+    def __contains__(self, k):
+        return any(k.startswith(p) for p, _ in PREFIX)
+
+    def __getitem__(self, k):
+        return next(f for p, f in PREFIX if k.startswith(p))
+
+
+FAMILY = _Family()
 
 
 def main():

@@ -566,7 +566,7 @@ template <class T, int NT, bool WIDE> FF_INLINE void digit_sums_body(const TailJ
     block_tree_sum<T, NT, DS_GROUP>(acc, lds);
     if (valid && lane == 0) xyzz_store_raw<T>(S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + b), acc);
 }
-template <bool WIDE> __global__ __launch_bounds__(DS_THREADS) void k_msm_digit_sums(TailJobs jobs, DigitPlan p) {
+template <bool WIDE> __global__ __launch_bounds__(DS_THREADS, WIDE ? 2 : 1) void k_msm_digit_sums(TailJobs jobs, DigitPlan p) {
     __shared__ uint32_t lds[LANE_POINT_WORDS][DS_THREADS];
     if (blockIdx.z < jobs.n1) digit_sums_body<Fp, DS_THREADS, WIDE>(jobs.j[blockIdx.z], p, lds);
     else digit_sums_body<Fp2H, DS_THREADS, WIDE>(jobs.j[blockIdx.z], p, lds);
