@@ -39,8 +39,9 @@ def main():
         f = fetch.get(k, {}).get("FETCH_SIZE", {})
         w = write.get(k, {}).get("WRITE_SIZE", {})
         lp = f.get("launches_per_proof", w.get("launches_per_proof", 0))
-        if k not in FAMILY or abs(lp - round(lp)) > 1e-6 or lp == 0:
-            continue            # set-up kernels (launch counts that are not per proof)
+        if k not in FAMILY or lp == 0:
+            continue            # not a per-proof kernel (the summaries are taken with --steady: key set-up is already excluded; a launch count
+                                # that is not an integer only means that slot 0 ran some proofs forked over three streams and some not)
         fb, wb = f.get("per_proof", 0.0) * 1024, w.get("per_proof", 0.0) * 1024
         kernels[k] = {"launches_per_proof": lp, "FETCH_SIZE_bytes_per_proof": fb, "WRITE_SIZE_bytes_per_proof": wb, "hbm_bytes_per_proof": 2 * fb + wb,
                       "hbm_bytes_per_launch": (2 * fb + wb) / lp, "family": FAMILY[k]}
