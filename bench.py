@@ -155,6 +155,12 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     it = iter(toxic)
     pk, _vk = Groth16.keygen(lambda: next(it), cs, lagrange=lagrange)
     prover = Groth16(cs, pk, rank, world, lagrange=lagrange)
+    derive_s = None
+    if args.derive_lagrange and world == 1 and not lagrange:
+        # the key stays the reference's (tau powers); the library derives its Lagrange form on the device, once (zk_groth16_pk_derive_lagrange)
+        t_d = time.perf_counter()
+        prover.derive_lagrange()
+        derive_s = time.perf_counter() - t_d
     prover.set_witness(w)
     pps = args.proofs_per_step
     nproofs = steps * pps
@@ -268,7 +274,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     res = {"log_n": log_n, "constraints": n, "variables": cs.m, "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3,
            "ms_per_step": dt / steps * 1e3, "timed_s": dt, "timed_proofs": nproofs, "proofs_in_flight": group.batch if group is not None else depth,
            "single_proof_latency_ms": None if lat is None else lat * 1e3, "single_proof_value": None if lat is None else n / lat,
-           "setup_s": round(setup_s, 1), "parity": parity, "pairs": pairs, "p1": p1, "p2": p2,
+           "setup_s": round(setup_s, 1), "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "parity": parity, "pairs": pairs, "p1": p1, "p2": p2,
            "fam_timed": fam_timed, "fam_alone": fam_alone, "n_alone": n_alone, "nproofs": nproofs,
            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_alone.items())},
            "proof_compressed_hex": proof.to_compressed().hex() if proof is not None else None,
@@ -344,7 +350,7 @@ def summarize(res, world, peak_products, traffic, lagrange):
     key = "groth16_2^%d" % res["log_n"] + ("_lagrange" if lagrange else "")
     roofs = roofline_objects(res["fam_timed"], res["nproofs"], res["fam_alone"], res["n_alone"], res["pairs"], world, windows, peak_products, traffic, key)
     out = {k: res[k] for k in ("log_n", "constraints", "variables", "value", "unit", "ms_per_proof", "timed_s", "timed_proofs", "proofs_in_flight",
-                               "single_proof_latency_ms", "single_proof_value", "setup_s", "parity", "kernel_ms_per_proof")}
+                               "single_proof_latency_ms", "single_proof_value", "setup_s", "derive_lagrange_s", "parity", "kernel_ms_per_proof")}
     out["prove_algorithmic_bytes_per_constraint"] = 928
     out["prove_hbm_frac"] = 928.0 * res["constraints"] / (res["ms_per_proof"] * 1e-3) / 1e9 / HBM_PEAK_GBS / world
     out["roofline_g1"], out["roofline_g2"] = roofs.get("g1"), roofs.get("g2")
@@ -367,6 +373,8 @@ def main():
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
                     "not the reference's key format -- the default and the headline use the tau-power key)")
+    ap.add_argument("--derive-lagrange", action="store_true", help="one GPU: after uploading the reference-format key, derive its Lagrange form on the device "
+                    "(zk_groth16_pk_derive_lagrange, once per key, untimed) and prove from that")
     ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (the simpler, slower scheme)")
     ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
     ap.add_argument("--inflight", type=int, default=12, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")

@@ -114,6 +114,15 @@ int zk_groth16_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* 
 int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                                   const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
                                   const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
+/* Turns an uploaded key in the REFERENCE's format (tau powers, zk_groth16_pk_upload) into the Lagrange form above ON THE DEVICE and without
+ * tau: [l_i(tau)] = V^-T [tau^k] is the transposed interpolation map applied to the key's own points (NTTs "in the exponent" over the
+ * subproduct tree of the QAP's points, QAP.ml:84,92; csrc/lagrange_derive.hip).  O(n log^2 n) scalar multiplications ONCE per key
+ * (seconds at 2^16 constraints, minutes at 2^20); afterwards every prove entry point runs the three-convolution Fr stage.  Proof bytes do
+ * not change.  Single-GPU keys only; no proof may be in flight. */
+int zk_groth16_pk_derive_lagrange(uint64_t handle);
+/* The key's resident base pool (group 1 or 2) as uncompressed points, in pool order: what was uploaded, or the derived Lagrange-form pool.
+ * out == NULL: only *count. */
+int zk_groth16_pool_points(uint64_t handle, int group, uint8_t* out, size_t capacity_points, size_t* count);
 int zk_groth16_pk_free(uint64_t handle);
 
 /* Groth16.prove rng qap pkey sol with r, s supplied by the caller in the order the reference

@@ -288,3 +288,34 @@ def test_batch_affine_accumulation_gives_the_same_proofs(monkeypatch, n, curves)
         p0 = ref.prove_rs(w, r, s)
         assert (p0.a, p0.b, p0.c) == exp
     ref.close(); ba.close()
+
+
+@pytest.mark.parametrize("maker", [lambda: RC.readme_circuit(3), lambda: RC.iterated_cubic(2, 5), lambda: RC.iterated_cubic(4, 6), lambda: RC.iterated_cubic(6, 9),
+                                   lambda: RC.iterated_cubic(16, 7), lambda: RC.iterated_cubic(100, 10), lambda: RC.iterated_cubic(1024, 11)])
+def test_lagrange_bases_derived_in_the_exponent(maker):
+    """zk_groth16_pk_derive_lagrange: from a key in the REFERENCE's format (tau powers) the device derives [l_i(tau)]_1, [l_i(tau)]_2 and the
+    shifted-domain h bases WITHOUT tau (transposed interpolation in the exponent, csrc/lagrange_derive.hip).  They must equal, byte for byte, what
+    a keygen that knows tau emits (Groth16.keygen(..., lagrange=True): exponents computed on the host, points from the fixed-base kernel), and the
+    proofs must not change."""
+    cs, w = maker()
+    rng = seeded_rng(0x5EED0D01)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, vk = Groth16.keygen(lambda: next(it), cs, lagrange=True)
+    prover = Groth16(cs, pk)                                    # the tau-power pools only
+    r, s = rng(), rng()
+    before = prover.prove_rs(w, r, s)
+    assert bytes(prover.pool_points(1)) == bytes(pk.g1) and bytes(prover.pool_points(2)) == bytes(pk.g2)
+    prover.derive_lagrange()
+    assert bytes(prover.pool_points(1)) == bytes(pk.lag_g1)
+    assert bytes(prover.pool_points(2)) == bytes(pk.lag_g2)
+    after = prover.prove_rs(w, r, s)
+    L, R_, Oo = csrs(cs)
+    exp = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    assert (after.a, after.b, after.c) == (before.a, before.b, before.c) == exp
+    w_bad = list(w)
+    w_bad[1] = (w_bad[1] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        prover.prove_rs(w_bad, r, s)
+    prover.derive_lagrange()                                    # idempotent
+    prover.close()

@@ -163,4 +163,6 @@ template <int A> FF_INLINE Fp2HB<4> fe_inv_fast(const Fp2HB<A>& a) {
     return {r};
 }
 
+template <int A> FF_INLINE Fp2HB<4> fe_inv(const Fp2HB<A>& a) { return fe_inv_fast(a); }
+
 }  // namespace zk

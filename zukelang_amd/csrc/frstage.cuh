@@ -41,6 +41,9 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_witness_canonica
 int frstage_init_lagrange(FrStage& f, hipStream_t s);     // after frstage_init
 int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_witness_canonical, hipStream_t s);
 
+// subproduct-tree tables over the points offset .. offset + n2 - 1 (plain Montgomery form, see frstage.hip)
+int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pntt, DevBuf& q, hipStream_t s);
+
 // a*b via NTT on device (Montgomery in/out); out must hold na+nb-1 elements
 int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, void* d_out, hipStream_t s);
 

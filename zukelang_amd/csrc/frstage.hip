@@ -151,10 +151,10 @@ __global__ void k_invfact(uint32_t* invfact, uint32_t* alt, const uint32_t* pref
     }
 }
 // leaves of the subproduct tree: q0[s] = -s   (Q_{0,s} = X - s, leading 1 implicit)
-__global__ void k_tree_leaves(uint32_t* q, uint32_t n2) {
+__global__ void k_tree_leaves(uint32_t* q, uint32_t n2, uint32_t offset) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n2) return;
-    fe_store<FrParams>(q + 8 * s, fe_neg(fe_from_u32<FrParams>(s)));
+    fe_store<FrParams>(q + 8 * s, fe_neg(fe_from_u32<FrParams>(s + offset)));
 }
 // scratch[node*2len + j] = j < len ? q[node*len + j] : (j == len ? 1 : 0)    (monic, padded to 2 len)
 __global__ void k_tree_expand(uint32_t* scratch, const uint32_t* q, uint32_t log_len, uint64_t total2) {
@@ -331,6 +331,33 @@ static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t leve
     return ZK_OK;
 }
 
+// Tables of the subproduct tree over the points offset .. offset + n2 - 1: level l (0-based) holds, for every node of 2^(l+1)
+// points, NTT_{2^(l+1)} of the (monic, padded) subproduct of its LEFT half, times 2^-(l+1) -- plain Montgomery form, transform-domain
+// (bit-reversed) order, n2 entries per level at pntt + l * n2.  `q` returns the root product (low n2 coefficients, monic).
+// offset 0: the prover's basis conversion; offset n: the h bases of a derived Lagrange-form key (lagrange_derive.hip).
+int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pntt, DevBuf& q, hipStream_t s) {
+    DevBuf N, prod, scale;
+    ZKCHK(ntt_ensure_twiddles(log_n2 + 1));
+    ZKCHK(q.alloc(32 * (size_t)n2));
+    ZKCHK(N.alloc(32 * (size_t)2 * n2));
+    ZKCHK(prod.alloc(32 * (size_t)n2));
+    ZKCHK(scale.alloc(32));
+    hipLaunchKernelGGL(k_tree_leaves, g1d(n2), dim3(256), 0, s, FRP(q), n2, offset);
+    for (uint32_t l = 0; l < log_n2; l++) {
+        // N = NTT_{2^(l+1)} of every level-l node (monic, padded): 2*n2 entries
+        hipLaunchKernelGGL(k_tree_expand, g1d(2 * (uint64_t)n2), dim3(256), 0, s, FRP(N), (const uint32_t*)FRP(q), l, 2 * (uint64_t)n2);
+        ZKCHK(ntt_forward(N.p, 2 * (uint64_t)n2, l + 1, s));
+        hipLaunchKernelGGL(k_inv_pow2_of, dim3(1), dim3(64), 0, s, FRP(scale), l + 1);
+        hipLaunchKernelGGL(k_tree_pair, g1d(n2), dim3(256), 0, s, (uint32_t*)pntt + 8 * (uint64_t)l * n2, FRP(prod), (const uint32_t*)FRP(N),
+                           (const uint32_t*)FRP(scale), l + 1, (uint64_t)n2);
+        ZKCHK(ntt_inverse(prod.p, n2, l + 1, true, s));
+        hipLaunchKernelGGL(k_tree_unwrap, g1d(n2 >> (l + 1)), dim3(256), 0, s, FRP(prod), l + 1, (uint64_t)(n2 >> (l + 1)));
+        HIPCHK(hipMemcpyAsync(q.p, prod.p, 32 * (size_t)n2, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));       // N, prod, scale die here
+    return ZK_OK;
+}
+
 int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, hipStream_t s) {
     if (n < 2 || n > (1u << 24)) ZK_FAIL(ZK_ERR_ARG, "constraint count must be in [2, 2^24]");
     if (m == 0) ZK_FAIL(ZK_ERR_ARG, "no variables");
@@ -366,23 +393,8 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     }
     // ---- subproduct tree, bottom-up.  q holds Q_{l,node} (low 2^l coefficients, monic), n2 entries per level.
     {
-        DevBuf q, N, prod, scale;
-        ZKCHK(q.alloc(32 * (size_t)n2));
-        ZKCHK(N.alloc(32 * (size_t)2 * n2));
-        ZKCHK(prod.alloc(32 * (size_t)n2));
-        ZKCHK(scale.alloc(32));
-        hipLaunchKernelGGL(k_tree_leaves, g1d(n2), dim3(256), 0, s, FRP(q), n2);
-        for (uint32_t l = 0; l < f.log_n2; l++) {
-            // N = NTT_{2^(l+1)} of every level-l node (monic, padded): 2*n2 entries
-            hipLaunchKernelGGL(k_tree_expand, g1d(2 * (uint64_t)n2), dim3(256), 0, s, FRP(N), (const uint32_t*)FRP(q), l, 2 * (uint64_t)n2);
-            ZKCHK(ntt_forward(N.p, 2 * (uint64_t)n2, l + 1, s));
-            hipLaunchKernelGGL(k_inv_pow2_of, dim3(1), dim3(64), 0, s, FRP(scale), l + 1);
-            hipLaunchKernelGGL(k_tree_pair, g1d(n2), dim3(256), 0, s, FRP(f.pntt) + 8 * (uint64_t)l * n2, FRP(prod), (const uint32_t*)FRP(N),
-                               (const uint32_t*)FRP(scale), l + 1, (uint64_t)n2);
-            ZKCHK(ntt_inverse(prod.p, n2, l + 1, true, s));
-            hipLaunchKernelGGL(k_tree_unwrap, g1d(n2 >> (l + 1)), dim3(256), 0, s, FRP(prod), l + 1, (uint64_t)(n2 >> (l + 1)));
-            HIPCHK(hipMemcpyAsync(q.p, prod.p, 32 * (size_t)n2, hipMemcpyDeviceToDevice, s));
-        }
+        DevBuf q;
+        ZKCHK(frstage_tree_tables(n2, f.log_n2, 0, f.pntt.p, q, s));
         ZKCHK(fr_to_factor(f.pntt.p, (uint64_t)n2 * f.log_n2, s));
         // ---- Z = prod_{i<n} (X - i)
         if (n == n2) {

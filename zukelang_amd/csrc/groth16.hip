@@ -103,6 +103,8 @@ __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __rest
     }
 }
 
+int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, DevBuf& out_g1, DevBuf& out_g2, hipStream_t s);   // lagrange_derive.hip
+
 static int key_lookup(uint64_t handle, Groth16Key** out) {
     auto it = g_keys.find(handle);
     if (it == g_keys.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Groth16 key handle");
@@ -154,6 +156,11 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
     return ZK_OK;
 }
 
+// The key's window width (see upload): one per key, 20 bits from 2^21 points in the G1 pool.
+static uint32_t key_window(uint64_t g1_points) {
+    if (getenv("ZK_MSM_WINDOW")) return 0;          // bases_setup reads it
+    return g1_points >= ((uint64_t)1 << 21) ? 20 : msm_auto_window(g1_points, true);
+}
 static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
                   const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank,
                   uint32_t world, uint64_t* handle, bool lagrange = false) {
@@ -185,8 +192,7 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     // in this rank's G1 pool (n >= ~2^19.6 on one GPU) 20-bit windows: 13 instead of 16 digits per scalar pay for the 16x
     // bucket count and the two-level sort (measured, profiles/r02_window_sweep_*.json: +7.5 % at 2^20, +12 % at 2^22, -2 % at
     // 2^19, -16 % at 2^18).  ZK_MSM_WINDOW overrides (config 3's sweep).
-    uint32_t cw = 0;
-    if (!getenv("ZK_MSM_WINDOW")) cw = (k.hi1 - k.lo1) >= ((uint64_t)1 << 21) ? 20 : msm_auto_window(k.hi1 - k.lo1, true);
+    const uint32_t cw = key_window(k.hi1 - k.lo1);
     ZKCHK(msm_bases_from_bytes(k.g1, CURVE_G1, pk_g1 + 96 * k.lo1, k.hi1 - k.lo1, cw, true, c.stream));
     ZKCHK(msm_bases_from_bytes(k.g2, CURVE_G2, pk_g2 + 192 * k.lo2, k.hi2 - k.lo2, cw, true, c.stream));
     ZKCHK(k.mid_idx.alloc(4 * (size_t)(k.n_mid ? k.n_mid : 1)));
@@ -318,6 +324,50 @@ int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const 
 int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
                                   const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
     return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, handle, true);
+}
+int zk_groth16_pk_derive_lagrange(uint64_t handle) {
+    Groth16Key* kp;
+    ZKCHK(key_lookup(handle, &kp));
+    Groth16Key& k = *kp;
+    if (k.lagrange) return ZK_OK;
+    if (k.world != 1) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_derive_lagrange: sharded keys hold only a slice of the powers");
+    for (uint32_t i = 0; i < MAX_SLOTS; i++)
+        if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_derive_lagrange: a proof is in flight on this key");
+    HIPCHK(hipDeviceSynchronize());
+    Ctx& c = ctx();
+    DevBuf n1, n2;
+    // window 0 of the resident tables IS the key as uploaded (dense affine, pool order)
+    ZKCHK(groth16_derive_lagrange_pools(k.fr, k.g1.table.as<uint8_t>(), k.n_mid, k.g2.table.as<uint8_t>(), n1, n2, c.stream));
+    for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();          // workspaces are sized for the old pools
+    const uint64_t p1n = 3 + (uint64_t)k.n + (k.n - 1) + k.n_mid, p2n = 2 + (uint64_t)k.n;
+    k.g1 = MsmBases();
+    k.g2 = MsmBases();
+    const uint32_t cw = key_window(p1n);
+    ZKCHK(msm_bases_from_device_affine(k.g1, CURVE_G1, n1.p, p1n, cw, true, c.stream));
+    ZKCHK(msm_bases_from_device_affine(k.g2, CURVE_G2, n2.p, p2n, cw, true, c.stream));
+    ZKCHK(frstage_init_lagrange(k.fr, c.stream));
+    k.lagrange = true;
+    k.p1 = p1n; k.p2 = p2n; k.lo1 = 0; k.hi1 = p1n; k.lo2 = 0; k.hi2 = p2n;
+    HIPCHK(hipStreamSynchronize(c.stream));
+    Slot* sl;
+    ZKCHK(slot_get(k, 0, &sl));
+    return ZK_OK;
+}
+int zk_groth16_pool_points(uint64_t handle, int group, uint8_t* out, size_t capacity_points, size_t* count) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (group != 1 && group != 2) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pool_points: group must be 1 or 2");
+    const MsmBases& b = group == 1 ? k->g1 : k->g2;
+    if (count) *count = b.n;
+    if (!out) return ZK_OK;
+    if (capacity_points < b.n) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pool_points: buffer too small");
+    Ctx& c = ctx();
+    DevBuf bytes;
+    ZKCHK(bytes.alloc(aff_bytes(b.curve) * b.n));
+    ZKCHK(points_affine_to_bytes(b.curve, bytes.p, b.table.p, b.n, c.stream));
+    HIPCHK(hipMemcpyAsync(out, bytes.p, aff_bytes(b.curve) * b.n, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return ZK_OK;
 }
 int zk_groth16_pk_free(uint64_t handle) {
     auto it = g_keys.find(handle);

@@ -1,0 +1,268 @@
+// Lagrange-form bases DERIVED from a proving key in the reference's format (tau powers), on the device, without tau.
+//
+// A key an OCaml `keygen` emits (src/groth16/groth16.ml:45-108) holds [tau^k]_1, [tau^k]_2 and [tau^k Z(tau)/delta]_1; the
+// prover then needs the MONOMIAL coefficients of v, w, h and pays the O(n log^2 n) basis conversion per proof (frstage.hip).
+// With [l_i(tau)]_1, [l_i(tau)]_2 (l_i: Lagrange basis of the QAP's points 0..n-1, QAP.ml:84,92) and [lambda_t(tau) Z(tau)/delta]_1
+// (lambda_t: basis of n..2n-2) it needs only VALUES (scope row f4: three convolutions per proof).  Those bases are a linear
+// image of the key's own points: with V_ik = i^k, sum_k a_k [tau^k] = sum_i y_i [l_i(tau)] for every polynomial forces
+//     [tau^k] = sum_i i^k [l_i(tau)],   i.e.   L = V^-T P .
+// The prover's Fr stage factors V^-1 = T . E (values -> Newton coefficients E = Conv_alt . D(1/i!); Newton -> monomial T over
+// the subproduct tree), hence
+//     L = D(1/i!) . Conv_alt^T . T^T . P :
+// the TRANSPOSED tree top-down (every node of 2^l points: upper half <- middle product of the node with the subproduct of its
+// left half, lower half unchanged), one correlation with alt[j] = (-1)^j / j!, one scaling -- the very polynomial products of the
+// basis conversion, applied to GROUP ELEMENTS: every product is a radix-2 NTT "in the exponent" whose butterflies multiply a point
+// by a 255-bit twiddle.  O(n log^2 n) scalar multiplications, ONCE per key: seconds at 2^16, minutes at 2^20.  The h bases use the
+// same code on the tree of the shifted points n..2n-2.  scripts/proto/lagrange_derive_model.py is the integer model of the algebra;
+// tests compare the derived pools byte for byte with what a keygen that knows tau emits (Groth16.keygen(..., lagrange=True)).
+#include "ec.cuh"
+#include "frstage.cuh"
+#include "msm.cuh"
+
+#include <type_traits>
+
+namespace zk {
+
+static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
+template <class T> struct LaneCount { static constexpr uint32_t N = RawLayout<T>::LANES; };
+
+// ---- scalar (canonical Fr, 8 words in memory) times point, MSB first; complete formulas (identity, equal operands)
+template <class T> FF_INLINE Xyzz<T> xyzz_mul_scalar(const Xyzz<T>& p, const uint32_t* __restrict__ k) {
+    Xyzz<T> acc = xyzz_inf<T>();
+    bool started = false;                                  // wave-uniform leading zero words are skipped
+    for (int w = 7; w >= 0; w--) {
+        const uint32_t bits = k[w];
+        if (!started && __ballot(bits != 0) == 0) continue;
+        started = true;
+        for (int b = 31; b >= 0; b--) {
+            acc = xyzz_dbl_impl(acc);
+            if ((bits >> b) & 1u) xyzz_add_impl(acc, p);
+        }
+    }
+    return acc;
+}
+FF_INLINE Fp neg_coord(const Fp& y) { return Fp(fp_canon(fe_neg(y))); }
+FF_INLINE Fp2H neg_coord(const Fp2H& y) { return Fp2H(fp_canon(fe_neg(y).v)); }
+
+// ---- conversions between the key's dense affine points and the raw XYZZ working arrays
+template <class T> __global__ void k_aff_to_raw(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t count, uint64_t total) {
+    constexpr int AB = FieldOps<T>::WORDS * 8, XB = RawLayout<T>::XYZZ;
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N;
+    if (i >= total) return;
+    Xyzz<T> q = xyzz_inf<T>();
+    if (i < count) q = xyzz_from_aff(aff_load<T>(src + AB * i));
+    xyzz_store_raw<T>(dst + XB * i, q);
+}
+template <class T> __global__ void k_raw_to_aff(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t count) {
+    constexpr int AB = FieldOps<T>::WORDS * 8, XB = RawLayout<T>::XYZZ;
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N;
+    if (i >= count) return;
+    aff_store<T>(dst + AB * i, xyzz_to_aff(xyzz_load_raw<T>(src + XB * i)));
+}
+
+// ---- one radix-2 stage over the whole array (independent blocks of 2h points): forward = DIF (natural -> bit-reversed),
+// inverse = DIT (bit-reversed -> natural, unscaled) -- the conventions of ntt.hip, so the Fr tables line up.  tw[h + j] = w_2h^(+-j).
+template <class T, bool INVERSE>
+__global__ __launch_bounds__(128) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t pairs) {
+    constexpr int XB = RawLayout<T>::XYZZ;
+    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N;
+    if (b >= pairs) return;
+    const uint64_t h = (uint64_t)1 << log_h, j = b & (h - 1), e = ((b >> log_h) << (log_h + 1)) | j;
+    Xyzz<T> u = xyzz_load_raw<T>(pts + XB * e), v = xyzz_load_raw<T>(pts + XB * (e + h));
+    const uint32_t* w = tw + 8 * (h + j);
+    if (INVERSE) {
+        if (log_h) v = xyzz_mul_scalar(v, w);              // span 2: the twiddle is 1 (wave-uniform test)
+        Xyzz<T> x = u;
+        xyzz_add_impl(x, v);
+        v.y = neg_coord(v.y);
+        xyzz_add_impl(u, v);
+        xyzz_store_raw<T>(pts + XB * e, x);
+        xyzz_store_raw<T>(pts + XB * (e + h), u);
+    } else {
+        Xyzz<T> x = u;
+        xyzz_add_impl(x, v);
+        v.y = neg_coord(v.y);
+        xyzz_add_impl(u, v);                                // u - v
+        if (log_h) u = xyzz_mul_scalar(u, w);
+        xyzz_store_raw<T>(pts + XB * e, x);
+        xyzz_store_raw<T>(pts + XB * (e + h), u);
+    }
+}
+// pts[i] <- tab[i] * pts[i]
+template <class T> __global__ __launch_bounds__(128) void k_g_tabmul(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tab, uint64_t total) {
+    constexpr int XB = RawLayout<T>::XYZZ;
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N;
+    if (i >= total) return;
+    const Xyzz<T> p = xyzz_load_raw<T>(pts + XB * i);
+    xyzz_store_raw<T>(pts + XB * i, xyzz_mul_scalar(p, tab + 8 * i));
+}
+// the transposed tree step of a level: arr[node * N + h + j] = work[node * N + j], j < h = N / 2 (the lower halves stay)
+__global__ void k_g_upper_from(uint4* __restrict__ arr, const uint4* __restrict__ work, uint32_t log_N, uint64_t total_vec, uint32_t vec_per_point) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_vec) return;
+    const uint64_t p = g / vec_per_point, N = (uint64_t)1 << log_N, h = N >> 1;
+    if ((p & (N - 1)) < h) return;
+    arr[g] = work[g - h * vec_per_point];
+}
+
+// ---- Fr-side tables (canonical integers: they multiply points, not field elements)
+FF_INLINE uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? __brev(x) >> (32 - bits) : 0; }
+// out[p] = canonical( tab[base + br(N - br(q))] * scale ),  p = base + q, q < N = 2^log_N: the table at the NEGATED frequency
+// (a correlation is a product with the transform at the inverse roots), in the transform-domain order of the data
+__global__ void k_tab_neg_canon(uint32_t* __restrict__ out, const uint32_t* __restrict__ tab, uint32_t log_N, uint64_t total, const uint32_t* __restrict__ scale) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const uint32_t N = 1u << log_N, q = (uint32_t)(p & (N - 1));
+    const uint32_t k = bitrev(q, log_N), kn = (N - k) & (N - 1), qn = bitrev(kn, log_N);
+    Fr x = fe_load<FrParams>(tab + 8 * (p - q + qn));
+    if (scale) x = fe_mul(x, fe_load<FrParams>(scale));
+    fe_store<FrParams>(out + 8 * p, fe_from_mont(x));
+}
+// alt[j] = (-1)^j / j! for j < n2, 0 up to total (Montgomery)
+__global__ void k_alt_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ invfact, uint32_t n2, uint64_t total) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    Fr x = fe_zero<FrParams>();
+    if (j < n2) {
+        x = fe_load<FrParams>(invfact + 8 * j);
+        if (j & 1) x = fe_neg(x);
+    }
+    fe_store<FrParams>(out + 8 * j, x);
+}
+__global__ void k_inv_pow2_mont(uint32_t* out, uint32_t k) {   // 2^-k (Montgomery)
+    if (blockIdx.x || threadIdx.x) return;
+    Fr half = fe_inv(fe_from_u32<FrParams>(2)), acc = fe_one<FrParams>();
+    for (uint32_t i = 0; i < k; i++) acc = fe_mul(acc, half);
+    fe_store<FrParams>(out, acc);
+}
+// canonical twiddle heap: tw[2^(k-1) + j] = w_{2^k}^(+-j) (as k_gen_twiddles of ntt.hip, plain integers)
+__device__ static const uint32_t LD_OMEGA_MONT[8] = {0x0c17f47cu, 0x9cab6d5cu, 0xfd4b71e5u, 0x1ce1e93du, 0x471dd505u, 0x0d6db230u, 0x743a3b6au, 0x3f0ee990u};
+__device__ static const uint32_t LD_OMEGA_INV_MONT[8] = {0xb3082d19u, 0x55a9e082u, 0xc7dc4a13u, 0x082f90b2u, 0xc76b052cu, 0x76ce3accu, 0x6e54185du, 0x15c39d95u};
+__global__ void k_twiddles_canon(uint32_t* tw, uint32_t log_k, int inverse) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (uint64_t)1 << log_k;
+    if (i >= total || i == 0) return;
+    const uint32_t k = 64 - __builtin_clzll(i);
+    const uint32_t j = (uint32_t)(i - ((uint64_t)1 << (k - 1)));
+    const uint32_t e = j << (32 - k);
+    Fr base, acc = fe_one<FrParams>();
+#pragma unroll
+    for (int l = 0; l < 8; l++) base.v[l] = inverse ? LD_OMEGA_INV_MONT[l] : LD_OMEGA_MONT[l];
+    for (int b = 0; b < 32; b++) {
+        if ((e >> b) & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+    }
+    fe_store<FrParams>(tw + 8 * i, fe_from_mont(acc));
+}
+
+// ---- the derivation of one set of bases
+struct DeriveTables {
+    uint32_t n2 = 0, log_n2 = 0;
+    DevBuf tree;          // log_n2 levels x n2 canonical scalars, negated frequency, level l (node size 2^l) at (l - 1) * n2
+    DevBuf alt;           // 2 n2 canonical scalars: NTT of alt at the negated frequency, times 1 / (2 n2)
+    DevBuf invfact;       // n2 canonical scalars 1 / i!
+    DevBuf tw_f, tw_i;    // canonical twiddle heaps up to 2 n2
+};
+static int derive_tables_build(DeriveTables& t, const FrStage& f, uint32_t offset, hipStream_t s) {
+    const uint32_t n2 = f.n2, lg = f.log_n2, S = 2 * n2, lgS = lg + 1;
+    t.n2 = n2; t.log_n2 = lg;
+    ZKCHK(t.tree.alloc(32 * (size_t)n2 * (lg ? lg : 1)));
+    ZKCHK(t.alt.alloc(32 * (size_t)S));
+    ZKCHK(t.invfact.alloc(32 * (size_t)n2));
+    ZKCHK(t.tw_f.alloc(32 * (size_t)S));
+    ZKCHK(t.tw_i.alloc(32 * (size_t)S));
+    {
+        DevBuf mont, q;
+        ZKCHK(mont.alloc(32 * (size_t)n2 * (lg ? lg : 1)));
+        ZKCHK(frstage_tree_tables(n2, lg, offset, mont.p, q, s));
+        for (uint32_t l = 1; l <= lg; l++)
+            hipLaunchKernelGGL(k_tab_neg_canon, g1d(n2), dim3(256), 0, s, t.tree.as<uint32_t>() + 8 * (uint64_t)(l - 1) * n2,
+                               (const uint32_t*)(mont.as<uint32_t>() + 8 * (uint64_t)(l - 1) * n2), l, (uint64_t)n2, (const uint32_t*)nullptr);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    {
+        DevBuf a, sc;
+        ZKCHK(a.alloc(32 * (size_t)S));
+        ZKCHK(sc.alloc(32));
+        hipLaunchKernelGGL(k_alt_kernel, g1d(S), dim3(256), 0, s, a.as<uint32_t>(), (const uint32_t*)f.invfact.as<uint32_t>(), n2, (uint64_t)S);
+        ZKCHK(ntt_forward(a.p, S, lgS, s));
+        hipLaunchKernelGGL(k_inv_pow2_mont, dim3(1), dim3(64), 0, s, sc.as<uint32_t>(), lgS);
+        hipLaunchKernelGGL(k_tab_neg_canon, g1d(S), dim3(256), 0, s, t.alt.as<uint32_t>(), (const uint32_t*)a.as<uint32_t>(), lgS, (uint64_t)S, (const uint32_t*)sc.as<uint32_t>());
+        ZKCHK(fr_from_mont(t.invfact.p, f.invfact.p, n2, s));
+        hipLaunchKernelGGL(k_twiddles_canon, g1d(S), dim3(256), 0, s, t.tw_f.as<uint32_t>(), lgS, 0);
+        hipLaunchKernelGGL(k_twiddles_canon, g1d(S), dim3(256), 0, s, t.tw_i.as<uint32_t>(), lgS, 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return ZK_OK;
+}
+
+template <class T> static int gntt(uint8_t* pts, uint64_t total, uint32_t log_len, bool inverse, const DeriveTables& t, hipStream_t s) {
+    const uint64_t pairs = total / 2;
+    const dim3 g = g1d(pairs * LaneCount<T>::N, 128);
+    for (uint32_t st = 0; st < log_len; st++) {
+        const uint32_t log_h = inverse ? st : log_len - 1 - st;
+        if (inverse) hipLaunchKernelGGL((k_gntt_stage<T, true>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_i.as<uint32_t>(), log_h, pairs);
+        else hipLaunchKernelGGL((k_gntt_stage<T, false>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_f.as<uint32_t>(), log_h, pairs);
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+// src: n dense affine points [x^k], k < n (device);  dst: n dense affine points, the Lagrange-form bases of the tables' points
+template <class T> static int derive_set(const DeriveTables& t, const uint8_t* d_src, uint32_t n, uint8_t* d_dst, hipStream_t s) {
+    constexpr size_t XB = RawLayout<T>::XYZZ;
+    constexpr uint32_t LP = LaneCount<T>::N;
+    const uint32_t n2 = t.n2, S = 2 * n2;
+    DevBuf A, W;
+    ZKCHK(A.alloc(XB * S));
+    ZKCHK(W.alloc(XB * (size_t)n2));
+    hipLaunchKernelGGL(k_aff_to_raw<T>, g1d((uint64_t)n2 * LP), dim3(256), 0, s, A.as<uint8_t>(), d_src, (uint64_t)n, (uint64_t)n2);
+    // T^T: top level first
+    for (uint32_t l = t.log_n2; l >= 1; l--) {
+        HIPCHK(hipMemcpyAsync(W.p, A.p, XB * (size_t)n2, hipMemcpyDeviceToDevice, s));
+        ZKCHK(gntt<T>(W.as<uint8_t>(), n2, l, false, t, s));
+        hipLaunchKernelGGL(k_g_tabmul<T>, g1d((uint64_t)n2 * LP, 128), dim3(128), 0, s, W.as<uint8_t>(), (const uint32_t*)(t.tree.as<uint32_t>() + 8 * (uint64_t)(l - 1) * n2), (uint64_t)n2);
+        ZKCHK(gntt<T>(W.as<uint8_t>(), n2, l, true, t, s));
+        const uint32_t vpp = (uint32_t)(XB / 16);
+        hipLaunchKernelGGL(k_g_upper_from, g1d((uint64_t)n2 * vpp), dim3(256), 0, s, A.as<uint4>(), (const uint4*)W.as<uint4>(), l, (uint64_t)n2 * vpp, vpp);
+    }
+    // the n-point problem is the leading block: entries from n on drop out; zero padding to the convolution size
+    HIPCHK(hipMemsetAsync(A.as<uint8_t>() + XB * (size_t)n, 0, XB * (size_t)(S - n), s));
+    // Conv_alt^T: correlation with alt through a cyclic transform of size 2 n2
+    ZKCHK(gntt<T>(A.as<uint8_t>(), S, t.log_n2 + 1, false, t, s));
+    hipLaunchKernelGGL(k_g_tabmul<T>, g1d((uint64_t)S * LP, 128), dim3(128), 0, s, A.as<uint8_t>(), (const uint32_t*)t.alt.as<uint32_t>(), (uint64_t)S);
+    ZKCHK(gntt<T>(A.as<uint8_t>(), S, t.log_n2 + 1, true, t, s));
+    // D(1/i!)
+    hipLaunchKernelGGL(k_g_tabmul<T>, g1d((uint64_t)n * LP, 128), dim3(128), 0, s, A.as<uint8_t>(), (const uint32_t*)t.invfact.as<uint32_t>(), (uint64_t)n);
+    hipLaunchKernelGGL(k_raw_to_aff<T>, g1d((uint64_t)n * LP, 128), dim3(128), 0, s, d_dst, (const uint8_t*)A.as<uint8_t>(), (uint64_t)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return ZK_OK;
+}
+
+// Pools of a key in the reference's layout (device, dense affine)  g1 = a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid,  g2 = b2 | d2 | ti2[n+2]
+// -> the Lagrange-form pools  g1' = a | d1 | b1 | [l_i]_1 (n) | [lambda_t Z/delta]_1 (n-1) | ltd_mid,  g2' = b2 | d2 | [l_i]_2 (n)  (device, dense affine).
+int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, DevBuf& out_g1, DevBuf& out_g2, hipStream_t s) {
+    const uint32_t n = f.n;
+    const uint64_t p1n = 3 + (uint64_t)n + (n - 1) + n_mid, p2n = 2 + (uint64_t)n;
+    ZKCHK(out_g1.alloc(96 * p1n));
+    ZKCHK(out_g2.alloc(192 * p2n));
+    const uint64_t o_ti = 3, o_tz = 3 + ((uint64_t)n + 2), o_lt = o_tz + (n - 1);
+    HIPCHK(hipMemcpyAsync(out_g1.p, d_g1, 96 * 3, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(out_g1.as<uint8_t>() + 96 * (3 + (uint64_t)n + (n - 1)), d_g1 + 96 * o_lt, 96 * n_mid, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(out_g2.p, d_g2, 192 * 2, hipMemcpyDeviceToDevice, s));
+    {
+        ScopedTimer tm("lagrange_derive", s);
+        DeriveTables t0;
+        ZKCHK(derive_tables_build(t0, f, 0, s));
+        ZKCHK(derive_set<Fp>(t0, d_g1 + 96 * o_ti, n, out_g1.as<uint8_t>() + 96 * 3, s));
+        ZKCHK(derive_set<Fp2H>(t0, d_g2 + 192 * 2, n, out_g2.as<uint8_t>() + 192 * 2, s));
+    }
+    if (n > 1) {
+        DeriveTables tn;                       // the points n .. 2n-2 of the h values
+        ZKCHK(derive_tables_build(tn, f, n, s));
+        ZKCHK(derive_set<Fp>(tn, d_g1 + 96 * o_tz, n - 1, out_g1.as<uint8_t>() + 96 * (3 + (uint64_t)n), s));
+    }
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -259,6 +259,19 @@ class Groth16:
         _lib.check(rc)
         self.handle = h
 
+    def derive_lagrange(self):
+        """Turns the uploaded reference-format key into its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key,
+        O(n log^2 n) scalar multiplications, no tau needed); the proofs stay byte-identical, the per-proof basis conversion disappears."""
+        _lib.check(_lib.lib().zk_groth16_pk_derive_lagrange(self.handle))
+
+    def pool_points(self, group):
+        """The resident base pool (1 = G1, 2 = G2) as uncompressed bytes, in pool order."""
+        cnt = C.c_size_t()
+        _lib.check(_lib.lib().zk_groth16_pool_points(self.handle, C.c_int(group), None, C.c_size_t(0), C.byref(cnt)))
+        out = np.zeros(cnt.value * (96 if group == 1 else 192), dtype=np.uint8)
+        _lib.check(_lib.lib().zk_groth16_pool_points(self.handle, C.c_int(group), _p(out), C.c_size_t(cnt.value), C.byref(cnt)))
+        return out
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             _lib.lib().zk_groth16_pk_free(self.handle)
