@@ -143,7 +143,7 @@ def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windo
     return objs
 
 
-def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, world, dist, lagrange=False, replicated_fr=False, events=True):
+def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, world, dist, lagrange=False, replicated_fr=False, events=True, derive_upto=None):
     """Times `steps` steps of `--proofs-per-step` proofs at n = 2^log_n * world; returns the result dict (rank 0 checks parity)."""
     from zukelang_amd import r1cs as RC
     from zukelang_amd.groth16 import Groth16
@@ -156,11 +156,6 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     pk, _vk = Groth16.keygen(lambda: next(it), cs, lagrange=lagrange)
     prover = Groth16(cs, pk, rank, world, lagrange=lagrange)
     derive_s = None
-    if args.derive_lagrange and world == 1 and not lagrange:
-        # the key stays the reference's (tau powers); the library derives its Lagrange form on the device, once (zk_groth16_pk_derive_lagrange)
-        t_d = time.perf_counter()
-        prover.derive_lagrange()
-        derive_s = time.perf_counter() - t_d
     prover.set_witness(w)
     pps = args.proofs_per_step
     nproofs = steps * pps
@@ -206,67 +201,86 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
                 last = prover.prove_wait(i % depth)
         return last, (first + count - 1) % len(rs)
 
-    run(0, max(nwarm, 1))
-    sync()
-    # A box that has been idle starts in a low-power state and needs seconds of load before its clocks
-    # settle (first bench of a fresh box: 8.4 ms/proof against 2.6 ms once warm).  Untimed: keep proving
-    # until three consecutive batches are within 5 % of the best one, at most --settle seconds.
-    t_settle = time.perf_counter()
-    best, stable, batches = None, 0, 0
-    while settle > 0 and (batches < 6 if dist is not None else (time.perf_counter() - t_settle < settle and stable < 3)):
-        batches += 1          # N > 1: a fixed count, every rank must run the same number of (collective) proofs
-        t0 = time.perf_counter()
-        run(0, depth)
+    def measure(with_families):
+        """warm-up + settle, the timed region, single-proof latency (and, with_families, the un-overlapped per-family pass), the parity gate"""
+        run(0, max(nwarm, 1))
         sync()
-        bt = time.perf_counter() - t0
-        stable = stable + 1 if best is not None and bt <= 1.05 * best else 0
-        best = bt if best is None else min(best, bt)
-    # the MSM accumulate kernels are bracketed by HIP events on their own streams DURING the timed region
-    # (level 1: two recycled event records per launch; nothing synchronises)
-    _lib.check(L.zk_profile_reset())
-    _lib.check(L.zk_profile_enable(1 if events else 0))
-    t0 = time.perf_counter()
-    proof, proof_idx = run(nwarm, nproofs)
-    sync()
-    dt = time.perf_counter() - t0
-    _lib.check(L.zk_profile_enable(0))
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    fam_timed = collect_families(L, _lib, nproofs)           # accumulate kernels inside the timed region (empty with --no-live-events)
-
-    # ---- single-proof latency and every kernel family un-overlapped: one proof at a time, untimed w.r.t. `value`
-    n_alone = 4 if log_n <= 20 else 2
-    lat = None
-    fam_alone = {}
-    if world == 1:
+        # A box that has been idle starts in a low-power state and needs seconds of load before its clocks
+        # settle (first bench of a fresh box: 8.4 ms/proof against 2.6 ms once warm).  Untimed: keep proving
+        # until three consecutive batches are within 5 % of the best one, at most --settle seconds.
+        t_settle = time.perf_counter()
+        best, stable, batches = None, 0, 0
+        while settle > 0 and (batches < 6 if dist is not None else (time.perf_counter() - t_settle < settle and stable < 3)):
+            batches += 1          # N > 1: a fixed count, every rank must run the same number of (collective) proofs
+            t0 = time.perf_counter()
+            run(0, depth)
+            sync()
+            bt = time.perf_counter() - t0
+            stable = stable + 1 if best is not None and bt <= 1.05 * best else 0
+            best = bt if best is None else min(best, bt)
+        # the MSM accumulate kernels are bracketed by HIP events on their own streams DURING the timed region
+        # (level 1: two recycled event records per launch; nothing synchronises)
         _lib.check(L.zk_profile_reset())
-        prover.prove_rs(None, *rs[0])
-        t1 = time.perf_counter()
-        for i in range(n_alone):
-            prover.prove_rs(None, *rs[1 + i])
-        lat = (time.perf_counter() - t1) / n_alone
-        _lib.check(L.zk_profile_enable(2))
-        for i in range(n_alone):
-            prover.prove_rs(None, *rs[1 + i])
-        fam_alone = collect_families(L, _lib, n_alone)
+        _lib.check(L.zk_profile_enable(1 if events else 0))
+        t0 = time.perf_counter()
+        proof, proof_idx = run(nwarm, nproofs)
+        sync()
+        dt = time.perf_counter() - t0
         _lib.check(L.zk_profile_enable(0))
-        _lib.check(L.zk_profile_reset())
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        fam_timed = collect_families(L, _lib, nproofs)           # accumulate kernels inside the timed region (empty with --no-live-events)
 
-    # ---- PARITY GATE (CPU oracle, outside every timed region): the last timed proof this rank holds
-    parity = None
-    if proof is not None and not args.no_parity_gate:
-        O = oracle()
-        frs = lambda xs: bytes(RC.fr_bytes(xs))
-        csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
-        r_, s_ = rs[proof_idx]
-        t2 = time.perf_counter()
-        exp = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), frs([r_]), frs([s_]))
-        if (proof.a, proof.b, proof.c) != exp:
-            raise SystemExit("PARITY FAILURE: the last timed proof at n = 2^%d x %d differs from the oracle's trapdoor evaluation -- no throughput reported" % (log_n, world))
-        parity = {"checked": "last timed proof == oracle groth16_prove_trapdoor (exact at any n), bytes of a | b | c", "oracle_s": round(time.perf_counter() - t2, 2)}
+        # ---- single-proof latency and every kernel family un-overlapped: one proof at a time, untimed w.r.t. `value`
+        n_alone = 4 if log_n <= 20 else 2
+        lat = None
+        fam_alone = {}
+        if world == 1:
+            _lib.check(L.zk_profile_reset())
+            prover.prove_rs(None, *rs[0])
+            t1 = time.perf_counter()
+            for i in range(n_alone):
+                prover.prove_rs(None, *rs[1 + i])
+            lat = (time.perf_counter() - t1) / n_alone
+            if with_families:
+                _lib.check(L.zk_profile_enable(2))
+                for i in range(n_alone):
+                    prover.prove_rs(None, *rs[1 + i])
+                fam_alone = collect_families(L, _lib, n_alone)
+                _lib.check(L.zk_profile_enable(0))
+            _lib.check(L.zk_profile_reset())
+
+        # ---- PARITY GATE (CPU oracle, outside every timed region): the last timed proof this rank holds
+        parity = None
+        if proof is not None and not args.no_parity_gate:
+            O = oracle()
+            frs = lambda xs: bytes(RC.fr_bytes(xs))
+            csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+            r_, s_ = rs[proof_idx]
+            t2 = time.perf_counter()
+            exp = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), frs([r_]), frs([s_]))
+            if (proof.a, proof.b, proof.c) != exp:
+                raise SystemExit("PARITY FAILURE: the last timed proof at n = 2^%d x %d differs from the oracle's trapdoor evaluation -- no throughput reported" % (log_n, world))
+            parity = {"checked": "last timed proof == oracle groth16_prove_trapdoor (exact at any n), bytes of a | b | c", "oracle_s": round(time.perf_counter() - t2, 2)}
+        return dt, fam_timed, proof, lat, fam_alone, n_alone, parity
+
+    # A key in the reference's format (tau powers) can be turned into its Lagrange form ON THE DEVICE, once per key, without tau
+    # (zk_groth16_pk_derive_lagrange): the per-proof basis conversion disappears, the proofs do not change.  When asked to, the run measures
+    # the key as uploaded first, then derives (untimed, reported as derive_lagrange_s) and measures again: `value` is the second figure,
+    # `tau_power_form` keeps the first.
+    derive = derive_upto is not None and log_n <= derive_upto and world == 1 and not lagrange
+    power_form = None
+    if derive:
+        dt0, _ft, _pr, lat0, _fa, _na, par0 = measure(False)
+        power_form = {"value": n * nproofs / dt0, "ms_per_proof": dt0 / nproofs * 1e3, "single_proof_latency_ms": None if lat0 is None else lat0 * 1e3, "parity": par0 is not None}
+        t_d = time.perf_counter()
+        prover.derive_lagrange()
+        derive_s = time.perf_counter() - t_d
+        prover.reserve_slots(depth)
+    dt, fam_timed, proof, lat, fam_alone, n_alone, parity = measure(True)
 
     p1 = 3 + (n + 2) + (n - 1) + cs.n_mid
     p2 = 2 + (n + 2)
@@ -274,7 +288,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     res = {"log_n": log_n, "constraints": n, "variables": cs.m, "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3,
            "ms_per_step": dt / steps * 1e3, "timed_s": dt, "timed_proofs": nproofs, "proofs_in_flight": group.batch if group is not None else depth,
            "single_proof_latency_ms": None if lat is None else lat * 1e3, "single_proof_value": None if lat is None else n / lat,
-           "setup_s": round(setup_s, 1), "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "parity": parity, "pairs": pairs, "p1": p1, "p2": p2,
+           "setup_s": round(setup_s, 1), "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "tau_power_form": power_form, "parity": parity, "pairs": pairs, "p1": p1, "p2": p2,
            "fam_timed": fam_timed, "fam_alone": fam_alone, "n_alone": n_alone, "nproofs": nproofs,
            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_alone.items())},
            "proof_compressed_hex": proof.to_compressed().hex() if proof is not None else None,
@@ -350,7 +364,7 @@ def summarize(res, world, peak_products, traffic, lagrange):
     key = "groth16_2^%d" % res["log_n"] + ("_lagrange" if lagrange else "")
     roofs = roofline_objects(res["fam_timed"], res["nproofs"], res["fam_alone"], res["n_alone"], res["pairs"], world, windows, peak_products, traffic, key)
     out = {k: res[k] for k in ("log_n", "constraints", "variables", "value", "unit", "ms_per_proof", "timed_s", "timed_proofs", "proofs_in_flight",
-                               "single_proof_latency_ms", "single_proof_value", "setup_s", "derive_lagrange_s", "parity", "kernel_ms_per_proof")}
+                               "single_proof_latency_ms", "single_proof_value", "setup_s", "derive_lagrange_s", "tau_power_form", "parity", "kernel_ms_per_proof")}
     out["prove_algorithmic_bytes_per_constraint"] = 928
     out["prove_hbm_frac"] = 928.0 * res["constraints"] / (res["ms_per_proof"] * 1e-3) / 1e9 / HBM_PEAK_GBS / world
     out["roofline_g1"], out["roofline_g2"] = roofs.get("g1"), roofs.get("g2")
@@ -373,8 +387,9 @@ def main():
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
                     "not the reference's key format -- the default and the headline use the tau-power key)")
-    ap.add_argument("--derive-lagrange", action="store_true", help="one GPU: after uploading the reference-format key, derive its Lagrange form on the device "
-                    "(zk_groth16_pk_derive_lagrange, once per key, untimed) and prove from that")
+    ap.add_argument("--derive-lagrange-upto", type=int, default=18, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
+                    "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 7 s at 2^16, 27 s at 2^18, 2.2 min at 2^20) and "
+                    "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
     ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (the simpler, slower scheme)")
     ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
     ap.add_argument("--inflight", type=int, default=12, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
@@ -410,7 +425,8 @@ def main():
     _lib.check(L.zk_init(local_rank))
 
     head = bench_groth16(args, L, _lib, args.log_n, args.steps, args.warmup, args.inflight, args.settle, rank, world, dist,
-                         lagrange=args.lagrange_key, replicated_fr=args.replicated_fr, events=not args.no_live_events)
+                         lagrange=args.lagrange_key, replicated_fr=args.replicated_fr, events=not args.no_live_events,
+                         derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
     peak = C.c_double()
     _lib.check(L.zk_bench_field_mul(1, 2000, C.byref(peak)))       # the library's dependent-chain product benchmark on this chip, in this process
     traffic = pmc_traffic()
@@ -426,7 +442,8 @@ def main():
             infl = args.inflight if ln <= 20 else 4
             steps = max(1, (per + args.proofs_per_step - 1) // args.proofs_per_step)
             r = bench_groth16(args, L, _lib, ln, steps, 1 if ln <= 18 else 0, infl, args.settle if ln <= 18 else min(args.settle, 2.0), 0, 1, None,
-                              lagrange=args.lagrange_key, events=not args.no_live_events)
+                              lagrange=args.lagrange_key, events=not args.no_live_events,
+                              derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
             pub, _ = summarize(r, 1, peak.value, traffic, args.lagrange_key)
             pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
             others.append(pub)
@@ -467,13 +484,16 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "groth16_prove, iterated-cubic R1CS (u -> u^3+u+3), BLS12-381, key+circuit+witness resident in HBM"
-                                   + (", LAGRANGE-FORM KEY EXTENSION (not the reference key format)" if args.lagrange_key else ""),
+                                   + (", LAGRANGE-FORM KEY EXTENSION (not the reference key format)" if args.lagrange_key else "")
+                                   + (", reference-format key (tau powers) uploaded, its Lagrange form DERIVED on the device once (zk_groth16_pk_derive_lagrange); tau_power_form = the same key before the derivation" if head.get("derive_lagrange_s") is not None else ""),
                        "step": "%d consecutive proofs of the pipelined prover (pipeline not drained between steps)" % args.proofs_per_step,
                        "proofs_per_step": args.proofs_per_step, "timed_proofs": head["timed_proofs"], "timed_s": head["timed_s"],
                        "constraints": head["constraints"], "variables": head["variables"], "proofs_in_flight": head["proofs_in_flight"], "constraints_per_gpu": 1 << args.log_n,
                        "sharding": ("MSM base points over ranks; Fr stage of a proof on its owner rank + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
                                     if head["group_batch"] is not None else "MSM base points over ranks, Fr stage replicated; all-gather of 768 B partial sums + local EC reduce") if world > 1 else "single GPU",
                        "exchange": head.get("exchange"),
+                       "derive_lagrange_s": head.get("derive_lagrange_s"),      # one-time, per key, outside the timed region
+                       "tau_power_form": head.get("tau_power_form"),
                        "rehearsal_ranks_share_gpus": rehearsal,
                        "prove_algorithmic_bytes_per_constraint": 928,
                        "prove_hbm_frac": head_pub["prove_hbm_frac"]},

@@ -6,7 +6,7 @@ for rep in 1 2; do
   i=0
   for e in "$@"; do
     i=$((i+1))
-    env $e timeout -k 10 400 python bench.py --headline-only --no-cpu-baseline $ARGS > $O/ab_${i}_$rep.json 2> $O/ab_${i}_$rep.err || { tail -5 $O/ab_${i}_$rep.err; exit 1; }
+    env $e timeout -k 10 400 python bench.py --headline-only --no-cpu-baseline --derive-lagrange-upto ${DERIVE:--1} $ARGS > $O/ab_${i}_$rep.json 2> $O/ab_${i}_$rep.err || { tail -5 $O/ab_${i}_$rep.err; exit 1; }
     python -c "import json; d=json.load(open('$O/ab_${i}_$rep.json')); print('[%s] rep $rep: %.2f M/s  %.3f ms/proof  latency %.2f ms' % ('$e', d['value']/1e6, d['ms_per_proof'], d['single_proof_latency_ms']))"
   done
 done

@@ -5,7 +5,7 @@ set -o pipefail
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BARGS="--headline-only --no-cpu-baseline --no-parity-gate ${LOGN:+--log-n $LOGN}"      # LOGN=20 scripts/r02_collect.sh ... for the other sizes
+BARGS="--headline-only --no-cpu-baseline --no-parity-gate --derive-lagrange-upto ${DERIVE:--1} ${LOGN:+--log-n $LOGN}"      # LOGN=20 scripts/r02_collect.sh ... for the other sizes
 for st in "$@"; do
   case $st in
     tests) echo "== gpu tests"; timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1 || { tail -30 $O/pytest_gpu.log; exit 1; }; tail -3 $O/pytest_gpu.log;;

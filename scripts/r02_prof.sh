@@ -4,7 +4,7 @@ set -o pipefail
 TAG=$1; LN=$2; shift; shift
 O=gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="--headline-only --no-cpu-baseline --no-parity-gate --log-n $LN --inflight 1 --steps 1 --proofs-per-step 4 --warmup 0 --settle 0"
+ARGS="--headline-only --no-cpu-baseline --no-parity-gate --derive-lagrange-upto -1 --log-n $LN --inflight 1 --steps 1 --proofs-per-step 4 --warmup 0 --settle 0"
 for st in "$@"; do
   case $st in
     stats) timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python bench.py $ARGS > $O/stats.json 2> $O/stats.err || { tail -20 $O/stats.err; exit 1; }

@@ -18,7 +18,7 @@ print("%4s %12s %10s %8s  %s" % ("c", "constr/s", "ms/proof", "parity", "kernel 
 for c in cs:
     env = dict(os.environ, ZK_MSM_WINDOW=str(c))      # (the per-kernel column comes from bench.py's un-overlapped one-proof pass)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", str(log_n), "--steps", "1", "--proofs-per-step", "12", "--warmup", "0",
-                          "--inflight", "6", "--settle", "2", "--headline-only", "--no-cpu-baseline"], env=env, capture_output=True, text=True, cwd=ROOT)
+                          "--inflight", "6", "--settle", "2", "--headline-only", "--no-cpu-baseline", "--derive-lagrange-upto", "-1"], env=env, capture_output=True, text=True, cwd=ROOT)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(c, "FAILED", out.stderr[-300:])
