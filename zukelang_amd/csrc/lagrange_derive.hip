@@ -41,6 +41,42 @@ template <class T> FF_INLINE Xyzz<T> xyzz_mul_scalar(const Xyzz<T>& p, const uin
     }
     return acc;
 }
+// The same with fixed 4-bit windows: the multiples 1 P .. 15 P go to a per-lane table in device memory (7 doublings + 7 additions), then 64
+// windows of 4 doublings + ONE addition of the looked-up multiple.  With per-lane scalars the conditional addition of the bitwise form runs in
+// nearly every step of a wave (256 doublings + ~256 additions = 5 600 field products); here it is 256 + 78 (3 100 products).
+template <class T> FF_INLINE Xyzz<T> xyzz_mul_scalar_w4(const Xyzz<T>& p, const uint32_t* __restrict__ k, uint8_t* __restrict__ tab) {
+    constexpr int XB = RawLayout<T>::XYZZ;
+    xyzz_store_raw<T>(tab + XB * 1, p);
+    for (uint32_t d = 2; d < 16; d++) {
+        Xyzz<T> q;
+        if (d & 1) {
+            q = xyzz_load_raw<T>(tab + XB * (d - 1));
+            xyzz_add_impl(q, p);
+        } else {
+            q = xyzz_dbl_impl(xyzz_load_raw<T>(tab + XB * (d >> 1)));
+        }
+        xyzz_store_raw<T>(tab + XB * d, q);
+    }
+    Xyzz<T> acc = xyzz_inf<T>();
+    bool started = false;
+    for (int w = 7; w >= 0; w--) {
+        const uint32_t bits = k[w];
+        if (!started && __ballot(bits != 0) == 0) continue;
+        for (int b = 28; b >= 0; b -= 4) {
+            if (started) {
+#pragma unroll 1
+                for (int r = 0; r < 4; r++) acc = xyzz_dbl_impl(acc);
+            }
+            started = true;
+            const uint32_t dg = (bits >> b) & 15u;
+            if (dg) {
+                const Xyzz<T> q = xyzz_load_raw<T>(tab + XB * dg);
+                xyzz_add_impl(acc, q);
+            }
+        }
+    }
+    return acc;
+}
 FF_INLINE Fp neg_coord(const Fp& y) { return Fp(fp_canon(fe_neg(y))); }
 FF_INLINE Fp2H neg_coord(const Fp2H& y) { return Fp2H(fp_canon(fe_neg(y).v)); }
 
@@ -63,15 +99,16 @@ template <class T> __global__ void k_raw_to_aff(uint8_t* __restrict__ dst, const
 // ---- one radix-2 stage over the whole array (independent blocks of 2h points): forward = DIF (natural -> bit-reversed),
 // inverse = DIT (bit-reversed -> natural, unscaled) -- the conventions of ntt.hip, so the Fr tables line up.  tw[h + j] = w_2h^(+-j).
 template <class T, bool INVERSE>
-__global__ __launch_bounds__(128) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t pairs) {
+__global__ __launch_bounds__(128) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t b0, uint64_t pairs, uint8_t* __restrict__ scratch) {
     constexpr int XB = RawLayout<T>::XYZZ;
-    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N;
+    const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, b = b0 + loc;      // a slab of butterflies per launch
     if (b >= pairs) return;
+    uint8_t* tab = scratch + (uint64_t)16 * XB * loc;
     const uint64_t h = (uint64_t)1 << log_h, j = b & (h - 1), e = ((b >> log_h) << (log_h + 1)) | j;
     Xyzz<T> u = xyzz_load_raw<T>(pts + XB * e), v = xyzz_load_raw<T>(pts + XB * (e + h));
     const uint32_t* w = tw + 8 * (h + j);
     if (INVERSE) {
-        if (log_h) v = xyzz_mul_scalar(v, w);              // span 2: the twiddle is 1 (wave-uniform test)
+        if (log_h) v = xyzz_mul_scalar_w4(v, w, tab);      // span 2: the twiddle is 1 (wave-uniform test)
         Xyzz<T> x = u;
         xyzz_add_impl(x, v);
         v.y = neg_coord(v.y);
@@ -83,18 +120,28 @@ __global__ __launch_bounds__(128) void k_gntt_stage(uint8_t* __restrict__ pts, c
         xyzz_add_impl(x, v);
         v.y = neg_coord(v.y);
         xyzz_add_impl(u, v);                                // u - v
-        if (log_h) u = xyzz_mul_scalar(u, w);
+        if (log_h) u = xyzz_mul_scalar_w4(u, w, tab);
         xyzz_store_raw<T>(pts + XB * e, x);
         xyzz_store_raw<T>(pts + XB * (e + h), u);
     }
 }
 // pts[i] <- tab[i] * pts[i]
-template <class T> __global__ __launch_bounds__(128) void k_g_tabmul(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tab, uint64_t total) {
+template <class T> __global__ __launch_bounds__(128) void k_g_tabmul(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tab, uint64_t i0, uint64_t total, uint8_t* __restrict__ scratch) {
     constexpr int XB = RawLayout<T>::XYZZ;
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N;
+    const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, i = i0 + loc;
     if (i >= total) return;
     const Xyzz<T> p = xyzz_load_raw<T>(pts + XB * i);
-    xyzz_store_raw<T>(pts + XB * i, xyzz_mul_scalar(p, tab + 8 * i));
+    xyzz_store_raw<T>(pts + XB * i, xyzz_mul_scalar_w4(p, tab + 8 * i, scratch + (uint64_t)16 * XB * loc));
+}
+// scalar multiplications per launch: bounds the scratch of the window tables (16 multiples each) to 1 (G1) / 2 (G2) GiB
+static constexpr uint64_t DERIVE_SLAB = (uint64_t)1 << 18;
+template <class T> static int g_tabmul(uint8_t* pts, const uint32_t* tab, uint64_t total, uint8_t* scratch, hipStream_t s) {
+    for (uint64_t i0 = 0; i0 < total; i0 += DERIVE_SLAB) {
+        const uint64_t cnt = total - i0 < DERIVE_SLAB ? total - i0 : DERIVE_SLAB;
+        hipLaunchKernelGGL(k_g_tabmul<T>, g1d(cnt * LaneCount<T>::N, 128), dim3(128), 0, s, pts, tab, i0, total, scratch);
+    }
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
 }
 // the transposed tree step of a level: arr[node * N + h + j] = work[node * N + j], j < h = N / 2 (the lower halves stay)
 __global__ void k_g_upper_from(uint4* __restrict__ arr, const uint4* __restrict__ work, uint32_t log_N, uint64_t total_vec, uint32_t vec_per_point) {
@@ -196,13 +243,16 @@ static int derive_tables_build(DeriveTables& t, const FrStage& f, uint32_t offse
     return ZK_OK;
 }
 
-template <class T> static int gntt(uint8_t* pts, uint64_t total, uint32_t log_len, bool inverse, const DeriveTables& t, hipStream_t s) {
+template <class T> static int gntt(uint8_t* pts, uint64_t total, uint32_t log_len, bool inverse, const DeriveTables& t, uint8_t* scratch, hipStream_t s) {
     const uint64_t pairs = total / 2;
-    const dim3 g = g1d(pairs * LaneCount<T>::N, 128);
     for (uint32_t st = 0; st < log_len; st++) {
         const uint32_t log_h = inverse ? st : log_len - 1 - st;
-        if (inverse) hipLaunchKernelGGL((k_gntt_stage<T, true>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_i.as<uint32_t>(), log_h, pairs);
-        else hipLaunchKernelGGL((k_gntt_stage<T, false>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_f.as<uint32_t>(), log_h, pairs);
+        for (uint64_t b0 = 0; b0 < pairs; b0 += DERIVE_SLAB) {
+            const uint64_t cnt = pairs - b0 < DERIVE_SLAB ? pairs - b0 : DERIVE_SLAB;
+            const dim3 g = g1d(cnt * LaneCount<T>::N, 128);
+            if (inverse) hipLaunchKernelGGL((k_gntt_stage<T, true>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_i.as<uint32_t>(), log_h, b0, pairs, scratch);
+            else hipLaunchKernelGGL((k_gntt_stage<T, false>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_f.as<uint32_t>(), log_h, b0, pairs, scratch);
+        }
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
@@ -212,27 +262,29 @@ template <class T> static int derive_set(const DeriveTables& t, const uint8_t* d
     constexpr size_t XB = RawLayout<T>::XYZZ;
     constexpr uint32_t LP = LaneCount<T>::N;
     const uint32_t n2 = t.n2, S = 2 * n2;
-    DevBuf A, W;
+    DevBuf A, W, scr;
     ZKCHK(A.alloc(XB * S));
     ZKCHK(W.alloc(XB * (size_t)n2));
+    ZKCHK(scr.alloc((size_t)16 * XB * (S < DERIVE_SLAB ? S : DERIVE_SLAB)));      // one table of 16 multiples per scalar multiplication of a launch
+    uint8_t* sc = scr.as<uint8_t>();
     hipLaunchKernelGGL(k_aff_to_raw<T>, g1d((uint64_t)n2 * LP), dim3(256), 0, s, A.as<uint8_t>(), d_src, (uint64_t)n, (uint64_t)n2);
     // T^T: top level first
     for (uint32_t l = t.log_n2; l >= 1; l--) {
         HIPCHK(hipMemcpyAsync(W.p, A.p, XB * (size_t)n2, hipMemcpyDeviceToDevice, s));
-        ZKCHK(gntt<T>(W.as<uint8_t>(), n2, l, false, t, s));
-        hipLaunchKernelGGL(k_g_tabmul<T>, g1d((uint64_t)n2 * LP, 128), dim3(128), 0, s, W.as<uint8_t>(), (const uint32_t*)(t.tree.as<uint32_t>() + 8 * (uint64_t)(l - 1) * n2), (uint64_t)n2);
-        ZKCHK(gntt<T>(W.as<uint8_t>(), n2, l, true, t, s));
+        ZKCHK(gntt<T>(W.as<uint8_t>(), n2, l, false, t, sc, s));
+        ZKCHK(g_tabmul<T>(W.as<uint8_t>(), (const uint32_t*)(t.tree.as<uint32_t>() + 8 * (uint64_t)(l - 1) * n2), (uint64_t)n2, sc, s));
+        ZKCHK(gntt<T>(W.as<uint8_t>(), n2, l, true, t, sc, s));
         const uint32_t vpp = (uint32_t)(XB / 16);
         hipLaunchKernelGGL(k_g_upper_from, g1d((uint64_t)n2 * vpp), dim3(256), 0, s, A.as<uint4>(), (const uint4*)W.as<uint4>(), l, (uint64_t)n2 * vpp, vpp);
     }
     // the n-point problem is the leading block: entries from n on drop out; zero padding to the convolution size
     HIPCHK(hipMemsetAsync(A.as<uint8_t>() + XB * (size_t)n, 0, XB * (size_t)(S - n), s));
     // Conv_alt^T: correlation with alt through a cyclic transform of size 2 n2
-    ZKCHK(gntt<T>(A.as<uint8_t>(), S, t.log_n2 + 1, false, t, s));
-    hipLaunchKernelGGL(k_g_tabmul<T>, g1d((uint64_t)S * LP, 128), dim3(128), 0, s, A.as<uint8_t>(), (const uint32_t*)t.alt.as<uint32_t>(), (uint64_t)S);
-    ZKCHK(gntt<T>(A.as<uint8_t>(), S, t.log_n2 + 1, true, t, s));
+    ZKCHK(gntt<T>(A.as<uint8_t>(), S, t.log_n2 + 1, false, t, sc, s));
+    ZKCHK(g_tabmul<T>(A.as<uint8_t>(), (const uint32_t*)t.alt.as<uint32_t>(), (uint64_t)S, sc, s));
+    ZKCHK(gntt<T>(A.as<uint8_t>(), S, t.log_n2 + 1, true, t, sc, s));
     // D(1/i!)
-    hipLaunchKernelGGL(k_g_tabmul<T>, g1d((uint64_t)n * LP, 128), dim3(128), 0, s, A.as<uint8_t>(), (const uint32_t*)t.invfact.as<uint32_t>(), (uint64_t)n);
+    ZKCHK(g_tabmul<T>(A.as<uint8_t>(), (const uint32_t*)t.invfact.as<uint32_t>(), (uint64_t)n, sc, s));
     hipLaunchKernelGGL(k_raw_to_aff<T>, g1d((uint64_t)n * LP, 128), dim3(128), 0, s, d_dst, (const uint8_t*)A.as<uint8_t>(), (uint64_t)n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
