@@ -110,7 +110,8 @@ int zk_groth16_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* 
  *   g1 = a | d1 | b1 | [l_i(tau)]_1 (n) | [lambda_t(tau) Z(tau)/delta]_1 (n-1) | ltd_mid        g2 = b2 | d2 | [l_i(tau)]_2 (n)
  * with l_i the Lagrange basis of the QAP's points 0..n-1 (QAP.ml:84,92) and lambda_t that of n..2n-2.  The same
  * group elements come out (proof bytes identical), but the prover needs only VALUES of v, w, h: three convolutions
- * instead of the O(n log^2 n) basis conversion.  All prove entry points work on the handle; zk_groth16_qap_eval does not. */
+ * instead of the O(n log^2 n) basis conversion.  All prove entry points work on the handle (zk_groth16_qap_eval still runs the
+ * basis conversion: it is asked for coefficient vectors). */
 int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                                   const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
                                   const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);

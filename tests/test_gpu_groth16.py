@@ -318,4 +318,11 @@ def test_lagrange_bases_derived_in_the_exponent(maker):
     with pytest.raises(AssertionError):
         prover.prove_rs(w_bad, r, s)
     prover.derive_lagrange()                                    # idempotent
+    # QAP.eval (coefficient vectors) stays available on the derived key
+    if cs.n <= 100:
+        q = O.QAP(cs.n, cs.m, *csrs(cs))
+        rc, _p, h_ref = q.eval(frs(w))
+        v_ref, w_ref, _ = q.eval_vwy(frs(w))
+        v, ww, h = prover.qap_eval(w)
+        assert bytes(v) == v_ref and bytes(ww) == w_ref and bytes(h)[:len(h_ref)] == h_ref
     prover.close()

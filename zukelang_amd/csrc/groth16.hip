@@ -35,11 +35,14 @@ struct Slot {
     hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, done = nullptr;
     uint8_t* host = nullptr;            // pinned: proof 384 B | flag 4 B | r 32 B | s 32 B
     uint8_t* host_partial = nullptr;    // pinned: 768 B of raw partial sums (sharded mode)
+    uint8_t* wit_pinned = nullptr;      // pinned staging copy of a witness handed over as a host buffer (allocated at first use): the caller's
+                                        // buffer is read before the call returns, as the header promises, whatever memory it lives in
     bool busy = false, serial = false;
     ~Slot() {
         if (s0) { (void)hipStreamDestroy(s0); if (!serial) { (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2); } }
         if (fork) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join1); (void)hipEventDestroy(join2); (void)hipEventDestroy(done); }
         if (host) (void)hipHostFree(host);
+        if (wit_pinned) (void)hipHostFree(wit_pinned);
     }
 };
 static constexpr uint32_t MAX_SLOTS = 15;      // + the context stream = the 16 hardware queues the chip runs side by side
@@ -212,7 +215,9 @@ static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const ui
     if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call the matching _wait first");
     const void* wit = k.wit_resident.p;
     if (sol) {
-        HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, sl.s0));
+        if (!sl.wit_pinned) HIPCHK(hipHostMalloc((void**)&sl.wit_pinned, 32 * (size_t)k.m, hipHostMallocDefault));
+        memcpy(sl.wit_pinned, sol, 32 * (size_t)k.m);
+        HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sl.wit_pinned, 32 * (size_t)k.m, hipMemcpyHostToDevice, sl.s0));
         wit = sl.wit_raw.p;
     } else if (!k.have_witness) ZK_FAIL(ZK_ERR_ARG, "no witness: pass sol or call zk_groth16_set_witness first");
     memcpy(sl.host + 392, r, 32);
@@ -558,7 +563,6 @@ int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uin
     Slot* sl;
     ZKCHK(slot_get(*k, 0, &sl));
     if (sl->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: slot 0 has a proof in flight");
-    if (k->lagrange) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: a Lagrange-form key never computes coefficient vectors");
     const void* wit = k->wit_resident.p;
     if (sol) {
         HIPCHK(hipMemcpyAsync(sl->wit_raw.p, sol, 32 * (size_t)k->m, hipMemcpyHostToDevice, sl->s0));
