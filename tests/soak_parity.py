@@ -18,7 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 frb = P.fr_to_bytes
 t_end = time.time() + budget
-n_msm = n_g16 = n_pin = 0
+n_msm = n_g16 = n_pin = n_der = n_ba = 0
 while time.time() < t_end:
     # ---- MSM with duplicates, negations, identity, tiny / huge / zero scalars
     G, naive, gen, mul = rnd.choice([(G1, O.g1_msm_naive, O.g1_generator, O.g1_mul), (G2, O.g2_msm_naive, O.g2_generator, O.g2_mul)])
@@ -38,6 +38,15 @@ while time.time() < t_end:
     for c in (0, rnd.choice([2, 5, 9, 13, 16])):
         got = bytes(G.apply_powers(scalars, np.frombuffer(bases, dtype=np.uint8), c))
         assert got == ref, ("MSM mismatch", G.__name__, n, c)
+    if n_msm % 2 == 0:
+        # round 2: the same adversarial base set through the resident-key machinery (window tables, one bucket set) with batch-affine rounds
+        os.environ["ZK_MSM_API_PRECOMP"] = "1"
+        os.environ["ZK_MSM_BA_ROUNDS"] = str(rnd.choice([0, 1, 3, 6]))
+        try:
+            got = bytes(G.apply_powers(scalars, np.frombuffer(bases, dtype=np.uint8), rnd.choice([3, 4, 8])))
+        finally:
+            del os.environ["ZK_MSM_API_PRECOMP"], os.environ["ZK_MSM_BA_ROUNDS"]
+        assert got == ref, ("resident-path MSM mismatch", G.__name__, n)
     n_msm += 1
     # ---- Groth16 at a random size, both key forms
     n = 2 * rnd.randrange(1, 1500)
@@ -52,7 +61,23 @@ while time.time() < t_end:
         pr = Groth16(cs, pk, lagrange=lag)
         p = pr.prove_rs(w, r, s)
         assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch", n, lag)
+        if not lag and n_g16 % 3 == 0:
+            # round 2: the Lagrange form DERIVED on the device from the tau-power key must be the keygen's, byte for byte, and prove the same
+            pr.derive_lagrange()
+            assert bytes(pr.pool_points(1)) == bytes(pk.lag_g1) and bytes(pr.pool_points(2)) == bytes(pk.lag_g2), ("derived pools differ", n)
+            p = pr.prove_rs(w, r, s)
+            assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch after the derivation", n)
+            n_der += 1
         pr.close()
+    if n_g16 % 5 == 0:
+        # round 2: the optional batch-affine accumulation, forced rounds (small keys), both curves
+        os.environ["ZK_MSM_BA_ROUNDS"] = str(rnd.choice([1, 2, 4]))
+        pr = Groth16(cs, pk)
+        del os.environ["ZK_MSM_BA_ROUNDS"]
+        p = pr.prove_rs(w, r, s)
+        assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch with batch-affine rounds", n)
+        pr.close()
+        n_ba += 1
     n_g16 += 1
     # ---- every fourth round: Pinocchio ZK prove at a random size against the trapdoor evaluation, then the product's verifier
     if n_g16 % 4 == 0:
@@ -72,4 +97,4 @@ while time.time() < t_end:
         n_pin += 1
     if (n_msm % 10) == 0:
         print("soak: %d MSM cases, %d Groth16 cases, %d Pinocchio cases ok" % (n_msm, n_g16, n_pin), flush=True)
-print("SOAK-OK msm=%d groth16=%d pinocchio=%d" % (n_msm, n_g16, n_pin))
+print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds) pinocchio=%d" % (n_msm, n_g16, n_der, n_ba, n_pin))
