@@ -121,6 +121,10 @@ int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const
  * (seconds at 2^16 constraints, minutes at 2^20); afterwards every prove entry point runs the three-convolution Fr stage.  Proof bytes do
  * not change.  Single-GPU keys only; no proof may be in flight. */
 int zk_groth16_pk_derive_lagrange(uint64_t handle);
+/* Turns a key uploaded WHOLE (zk_groth16_pk_upload[_lagrange], possibly after zk_groth16_pk_derive_lagrange) into rank `rank`'s shard of a
+ * point-sharded multi-GPU prover: the rank keeps its contiguous slice of both pools (same slicing rule as zk_groth16_pk_upload_sharded) and
+ * from then on answers zk_groth16_prove_partial*.  How a derived Lagrange-form key reaches N GPUs: every rank uploads, derives, shards. */
+int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world);
 /* The key's resident base pool (group 1 or 2) as uncompressed points, in pool order: what was uploaded, or the derived Lagrange-form pool.
  * out == NULL: only *count. */
 int zk_groth16_pool_points(uint64_t handle, int group, uint8_t* out, size_t capacity_points, size_t* count);

@@ -161,6 +161,21 @@ def main():
         assert [i for i, x in enumerate(own) if x is not None] == mine
         for i in mine:
             assert (own[i].a, own[i].b, own[i].c) == tuple(getattr(got[i], f) for f in "abc")
+        # round 2: the derived Lagrange form on N ranks -- every rank uploads the key WHOLE, derives, keeps its shard (zk_groth16_pk_shard); the
+        # Fr stage (three convolutions) is then cheap enough to run replicated, and the only collective left is the all-gather of 768 bytes
+        dp = Groth16(cs, pk)
+        dp.derive_lagrange()
+        dp.shard(rank, world)
+        pd = dp.prove_rs(w, r, s)
+        assert (pd.a, pd.b, pd.c) == expect, "rank %d: proof from the derived + sharded key differs" % rank
+        dp.set_witness(w)
+        for slot, (rr, ss) in enumerate(rs[1:4]):
+            dp.prove_async(None, rr, ss, slot)
+        for slot, (rr, ss) in enumerate(rs[1:4]):
+            p3 = dp.prove_wait(slot)
+            e3 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
+            assert (p3.a, p3.b, p3.c) == e3, "rank %d slot %d: pipelined proof from the derived + sharded key differs" % (rank, slot)
+        dp.close()
         # an unsatisfied witness: only the OWNER of a proof sees ZK_ERR_REMAINDER (QAP.ml:134); every rank must raise
         # before the round's all-to-all instead of hanging in it, and the prover must stay usable afterwards
         w_bad = list(w)

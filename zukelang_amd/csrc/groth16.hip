@@ -358,6 +358,34 @@ int zk_groth16_pk_derive_lagrange(uint64_t handle) {
     ZKCHK(slot_get(k, 0, &sl));
     return ZK_OK;
 }
+int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
+    Groth16Key* kp;
+    ZKCHK(key_lookup(handle, &kp));
+    Groth16Key& k = *kp;
+    if (k.world != 1) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_shard: the key is sharded already");
+    if (world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_shard: bad rank / world");
+    if (world == 1) return ZK_OK;
+    for (uint32_t i = 0; i < MAX_SLOTS; i++)
+        if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_shard: a proof is in flight on this key");
+    HIPCHK(hipDeviceSynchronize());
+    Ctx& c = ctx();
+    const uint64_t lo1 = k.p1 * rank / world, hi1 = k.p1 * (rank + 1) / world, lo2 = k.p2 * rank / world, hi2 = k.p2 * (rank + 1) / world;
+    if (hi1 == lo1 || hi2 == lo2) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_shard: more ranks than key points");
+    for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();
+    // window 0 of the resident tables is the pool in order: the rank keeps its contiguous slice and builds its own window tables
+    MsmBases g1, g2;
+    const uint32_t cw = key_window(hi1 - lo1);
+    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, k.g1.table.as<uint8_t>() + 96 * lo1, hi1 - lo1, cw, true, c.stream));
+    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, k.g2.table.as<uint8_t>() + 192 * lo2, hi2 - lo2, cw, true, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    k.g1 = std::move(g1);
+    k.g2 = std::move(g2);
+    k.rank = rank; k.world = world;
+    k.lo1 = lo1; k.hi1 = hi1; k.lo2 = lo2; k.hi2 = hi2;
+    Slot* sl;
+    ZKCHK(slot_get(k, 0, &sl));
+    return ZK_OK;
+}
 int zk_groth16_pool_points(uint64_t handle, int group, uint8_t* out, size_t capacity_points, size_t* count) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));

@@ -264,6 +264,12 @@ class Groth16:
         O(n log^2 n) scalar multiplications, no tau needed); the proofs stay byte-identical, the per-proof basis conversion disappears."""
         _lib.check(_lib.lib().zk_groth16_pk_derive_lagrange(self.handle))
 
+    def shard(self, rank, world):
+        """Turns a key uploaded whole (and possibly derived into its Lagrange form) into `rank`'s shard of a point-sharded prover
+        (zk_groth16_pk_shard): afterwards prove_rs / prove_async / prove_wait run the all-gather + combine of the sharded path."""
+        _lib.check(_lib.lib().zk_groth16_pk_shard(self.handle, C.c_uint32(rank), C.c_uint32(world)))
+        self.rank, self.world = rank, world
+
     def pool_points(self, group):
         """The resident base pool (1 = G1, 2 = G2) as uncompressed bytes, in pool order."""
         cnt = C.c_size_t()
