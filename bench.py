@@ -407,7 +407,7 @@ def main():
                     "(GroupProver: all-to-all of scalar slices) instead of deriving the Lagrange form on every rank")
     ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (the simpler, slower scheme)")
     ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
-    ap.add_argument("--inflight", type=int, default=12, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
+    ap.add_argument("--inflight", type=int, default=14, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
