@@ -341,32 +341,44 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
         for i in range(max(0, count - depth), count):
             last = prover.prove_wait(i % depth)
         return last, (count - 1) % len(ds)
-    run(2 * depth)
-    _lib.check(L.zk_sync())
-    t0 = time.perf_counter()
-    proof, idx = run(nproofs)
-    _lib.check(L.zk_sync())
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    for i in range(2):
-        prover.prove_with(w, *ds[i])
-    lat = (time.perf_counter() - t1) / 2
-    parity = None
-    if not args.no_parity_gate:
-        O = oracle()
-        frs = lambda xs: bytes(RC.fr_bytes(xs))
-        csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
-        exp = O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(tox), *(frs([x]) for x in ds[idx]))
-        if proof.to_bytes() != exp:
-            raise SystemExit("PARITY FAILURE: the last timed Pinocchio proof differs from the oracle's trapdoor evaluation")
-        parity = {"checked": "last timed proof == oracle pinocchio_prove_trapdoor, 960 bytes"}
+    def measure():
+        run(2 * depth)
+        _lib.check(L.zk_sync())
+        t0 = time.perf_counter()
+        proof, idx = run(nproofs)
+        _lib.check(L.zk_sync())
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for i in range(2):
+            prover.prove_with(w, *ds[i])
+        lat = (time.perf_counter() - t1) / 2
+        parity = None
+        if not args.no_parity_gate:
+            O = oracle()
+            frs = lambda xs: bytes(RC.fr_bytes(xs))
+            csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+            exp = O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(tox), *(frs([x]) for x in ds[idx]))
+            if proof.to_bytes() != exp:
+                raise SystemExit("PARITY FAILURE: the last timed Pinocchio proof differs from the oracle's trapdoor evaluation")
+            parity = {"checked": "last timed proof == oracle pinocchio_prove_trapdoor, 960 bytes"}
+        return dt, lat, parity
+    as_uploaded, derive_s = None, None
+    if args.derive_lagrange_upto >= log_n:
+        # the key as uploaded first, then with its h pool derived for the values of h (zk_pinocchio_pk_derive_lagrange, once per key, untimed)
+        dt0, lat0, par0 = measure()
+        as_uploaded = {"value": n * nproofs / dt0, "ms_per_proof": dt0 / nproofs * 1e3, "single_proof_latency_ms": lat0 * 1e3, "parity": par0 is not None}
+        t_d = time.perf_counter()
+        prover.derive_lagrange()
+        derive_s = time.perf_counter() - t_d
+    dt, lat, parity = measure()
     prover.close()
     m_mid = cs.n_mid
     alg = 5 * 128 * m_mid + 2 * 128 * cs.m + 2 * 128 * n + 2 * 224 * m_mid + 192 * n       # 1792 n B at m_mid = m = n
     return {"workload": "pinocchio_zk_prove (BASELINE config 5), iterated-cubic R1CS, key+circuit+witness resident in HBM", "log_n": log_n, "constraints": n,
             "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3, "timed_s": dt, "timed_proofs": nproofs,
             "proofs_in_flight": depth, "single_proof_latency_ms": lat * 1e3, "single_proof_note": "one at a time, witness handed over as a host buffer",
-            "prove_algorithmic_bytes_per_constraint": alg / n, "prove_hbm_frac": alg / (dt / nproofs) / 1e9 / HBM_PEAK_GBS, "parity": parity}
+            "prove_algorithmic_bytes_per_constraint": alg / n, "prove_hbm_frac": alg / (dt / nproofs) / 1e9 / HBM_PEAK_GBS, "parity": parity,
+            "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "as_uploaded": as_uploaded}
 
 
 def summarize(res, world, peak_products, traffic, lagrange):

@@ -205,6 +205,10 @@ int zk_groth16_combine(const uint8_t* partials /* world * 768 */, uint32_t world
 int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                            const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
                            const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
+/* As zk_groth16_pk_derive_lagrange, for the evaluation key of pinocchio.ml:37-60: the powers si are turned into the Lagrange basis of the points
+ * n .. 2n-2 in the exponent (plus [Z(s)] = <si, Z>, once), so that h enters its multi-scalar product through VALUES; v(s), w(s) never needed
+ * coefficient vectors (they come from the per-variable pools).  Once per key; proofs byte-identical. */
+int zk_pinocchio_pk_derive_lagrange(uint64_t handle);
 int zk_pinocchio_pk_free(uint64_t handle);
 int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32],
                        const uint8_t dy[32], uint8_t proof[960]);

@@ -87,3 +87,37 @@ def test_pinocchio_2_18_trapdoor_and_verify():
     assert O.pinocchio_verify(bytes(G1.of_Fr(v1)), bytes(G2.of_Fr(v2)), io, proof.to_bytes())
     assert len(proof.to_compressed()) == 480
     prover.close()
+
+
+@pytest.mark.parametrize("maker", [lambda: RC.readme_circuit(3), lambda: RC.iterated_cubic(2, 4), lambda: RC.iterated_cubic(6, 9), lambda: RC.iterated_cubic(64, 10),
+                                   lambda: RC.iterated_cubic(1000, 11), lambda: RC.iterated_cubic(1 << 14, 12)])
+def test_pinocchio_derived_h_bases_give_the_same_proofs(maker):
+    """zk_pinocchio_pk_derive_lagrange: the powers si of an uploaded evaluation key (pinocchio.ml:37-60) become the Lagrange basis of the points
+    n .. 2n-2 in the exponent, h enters through its values (no basis conversion per proof).  ZK and NonZK proofs must keep their bytes: against
+    the same prover before the derivation and against the trapdoor oracle; an unsatisfied witness still raises."""
+    cs, w = maker()
+    L, R_, Oo = csrs(cs)
+    st = P.fr_stream(0x5EED0D03)
+    tox = [next(st) for _ in range(8)]
+    toxic = frs(tox)
+    it = iter(tox)
+    pk, vk = PIN.ZK.keygen(lambda: next(it), cs)
+    prover = PIN.ZK(cs, pk)
+    ds = [[next(st) for _ in range(3)] for _ in range(3)]
+    before = [prover.prove_with(w, *d).to_bytes() for d in ds]
+    prover.derive_lagrange()
+    prover.derive_lagrange()                                   # idempotent
+    for d, b in zip(ds, before):
+        got = prover.prove_with(w, *d).to_bytes()
+        assert got == b == O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), toxic, *(P.fr_to_bytes(x) for x in d))
+    assert prover.prove_with(w, 0, 0, 0).to_bytes() == O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), toxic, *(P.fr_to_bytes(0),) * 3)
+    prover.set_witness(w)
+    for slot, d in enumerate(ds):
+        prover.prove_async(*d, slot)
+    for slot, b in enumerate(before):
+        assert prover.prove_wait(slot).to_bytes() == b
+    w_bad = list(w)
+    w_bad[2] = (w_bad[2] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        prover.prove_with(w_bad, *ds[0])
+    prover.close()

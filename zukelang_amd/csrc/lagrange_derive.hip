@@ -317,4 +317,14 @@ int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_
     return ZK_OK;
 }
 
+// Pinocchio (src/pinocchio/pinocchio.ml:450: h against the powers si): d_si holds [s^k]_1, k < n - 1 (dense affine, device);
+// d_out receives [lambda_t(s)]_1, t < n - 1, lambda_t the Lagrange basis of the points n .. 2n-2 -- the bases the h VALUES multiply.
+int derive_shifted_bases_g1(const FrStage& f, const uint8_t* d_si, uint8_t* d_out, hipStream_t s) {
+    if (f.n < 2) return ZK_OK;
+    ScopedTimer tm("lagrange_derive", s);
+    DeriveTables tn;
+    ZKCHK(derive_tables_build(tn, f, f.n, s));
+    return derive_set<Fp>(tn, d_si, f.n - 1, d_out, s);
+}
+
 }  // namespace zk

@@ -50,8 +50,10 @@ struct PinKey {
     MsmBases g1[PIN_G1], g2[PIN_G2];
     DevBuf mid_idx, wit_resident;
     bool have_witness = false;
+    bool lagrange = false;              // pool 5 holds [lambda_t(s)] (n-1) | [Z(s)] | [1] | v_all | w_all instead of si (n+1) | v_all | w_all
     std::unique_ptr<PinSlot> slots[PIN_MAX_SLOTS];
 };
+int derive_shifted_bases_g1(const FrStage& f, const uint8_t* d_si, uint8_t* d_out, hipStream_t s);   // lagrange_derive.hip
 static std::map<uint64_t, std::unique_ptr<PinKey>>& g_pin = *new std::map<uint64_t, std::unique_ptr<PinKey>>;   // never destroyed (see ntt.hip)
 static uint64_t g_pin_next = 0x5000000001ull;
 static void pin_release() { g_pin.clear(); }
@@ -66,7 +68,7 @@ struct PinScalPtrs {
 // one lane per entry of the longest vector (the h pool: n + 1 + 2 m)
 __global__ void k_pinocchio_scalars(PinScalPtrs out, const uint32_t* __restrict__ h, const uint32_t* __restrict__ z,
                                     const uint32_t* __restrict__ wit_mont, const uint32_t* __restrict__ mid_idx,
-                                    const uint32_t* __restrict__ deltas, uint32_t n, uint32_t m, uint32_t n_mid) {
+                                    const uint32_t* __restrict__ deltas, uint32_t n, uint32_t m, uint32_t n_mid, uint32_t lagrange) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t ph = (uint64_t)n + 1 + 2 * (uint64_t)m;
     if (i >= ph) return;
@@ -74,7 +76,12 @@ __global__ void k_pinocchio_scalars(PinScalPtrs out, const uint32_t* __restrict_
              dy = fe_to_mont(fe_load<FrParams>(deltas + 16));
     // pool 5: h'
     Fr x;
-    if (i <= n) {
+    if (i <= n && lagrange) {
+        // derived key: h through its VALUES on n .. 2n-2 against [lambda_t(s)], then dv dw on the single point [Z(s)], -dy on [1]
+        if (i + 1 < n) x = fe_load<FrParams>(h + 8 * i);
+        else if (i + 1 == n) x = fe_mul(dv, dw);
+        else x = fe_neg(dy);
+    } else if (i <= n) {
         x = fe_mul(fe_mul(dv, dw), fe_load<FrParams>(z + 8 * i));            // dv dw Z_i
         if (i + 1 < n) x = fe_add(x, fe_load<FrParams>(h + 8 * i));          // h has n - 1 coefficients
         if (i == 0) x = fe_sub(x, dy);
@@ -160,6 +167,55 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     g_pin[*handle] = std::move(key);
     return ZK_OK;
 }
+// The h pool of an uploaded key (si | v_all | w_all) rewritten for the VALUES of h: [lambda_t(s)]_1 derived from the powers si in the exponent
+// (lagrange_derive.hip: the transposed interpolation over the points n .. 2n-2), [Z(s)]_1 = <si, Z> once, [1] = si[0].  Same pool length,
+// same proofs; the per-proof basis conversion disappears (only h ever needed coefficients: v(s), w(s) come from the per-variable pools).
+int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    PinKey& k = *kp;
+    if (k.lagrange) return ZK_OK;
+    for (uint32_t i = 0; i < PIN_MAX_SLOTS; i++)
+        if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: a proof is in flight on this key");
+    HIPCHK(hipDeviceSynchronize());
+    Ctx& c = ctx();
+    const uint32_t n = k.n;
+    const uint64_t ph = (uint64_t)n + 1 + 2 * (uint64_t)k.m;
+    MsmBases& old = k.g1[5];
+    if (old.n != ph) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: unexpected pool length");
+    DevBuf pool;
+    ZKCHK(pool.alloc(96 * ph));
+    const uint8_t* si = old.table.as<uint8_t>();                         // window 0 = the pool as uploaded
+    // [lambda_t(s)], t < n - 1
+    ZKCHK(derive_shifted_bases_g1(k.fr, si, pool.as<uint8_t>(), c.stream));
+    // [Z(s)] = sum_i Z_i [s^i]: one MSM over the n + 1 powers with the canonical coefficients of Z
+    {
+        MsmBases b;
+        MsmWorkspace w;
+        DevBuf zc, res, bytes, flag;
+        ZKCHK(msm_bases_from_device_affine(b, CURVE_G1, si, (uint64_t)n + 1, 0, false, c.stream));
+        ZKCHK(msm_workspace_alloc(w, b));
+        ZKCHK(zc.alloc(32 * ((size_t)n + 1)));
+        ZKCHK(res.alloc(xyzz_bytes(CURVE_G1)));
+        ZKCHK(bytes.alloc(96));
+        ZKCHK(flag.alloc(4));
+        ZKCHK(fr_from_mont(zc.p, k.fr.z.p, (uint64_t)n + 1, c.stream));
+        ZKCHK(msm_run(b, w, zc.p, res.p, c.stream));
+        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res.p, 1, bytes.p, c.stream));
+        HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
+        ZKCHK(points_bytes_to_affine(CURVE_G1, pool.as<uint8_t>() + 96 * (uint64_t)(n - 1), bytes.p, 1, flag.as<int>(), c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    }
+    HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * (uint64_t)n, si, 96, hipMemcpyDeviceToDevice, c.stream));                                       // [1] = si[0]
+    HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * ((uint64_t)n + 1), si + 96 * ((uint64_t)n + 1), 96 * 2 * (uint64_t)k.m, hipMemcpyDeviceToDevice, c.stream));   // v_all | w_all
+    MsmBases nb;
+    ZKCHK(msm_bases_from_device_affine(nb, CURVE_G1, pool.p, ph, old.c, true, c.stream));
+    ZKCHK(frstage_init_lagrange(k.fr, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    k.g1[5] = std::move(nb);
+    k.lagrange = true;
+    return ZK_OK;
+}
 int zk_pinocchio_pk_free(uint64_t handle) {
     auto it = g_pin.find(handle);
     if (it == g_pin.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Pinocchio key handle");
@@ -226,14 +282,15 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     } else if (!k.have_witness) ZK_FAIL(ZK_ERR_ARG, "no witness: pass sol or call zk_pinocchio_set_witness first");
     memcpy(sl.host + 992, dv, 32); memcpy(sl.host + 1024, dw, 32); memcpy(sl.host + 1056, dy, 32);
     HIPCHK(hipMemcpyAsync(sl.deltas.p, sl.host + 992, 96, hipMemcpyHostToDevice, s0));
-    ZKCHK(frstage_eval(k.fr, sl.fs, wit, s0));
+    if (k.lagrange) ZKCHK(frstage_eval_lagrange(k.fr, sl.fs, wit, s0));
+    else ZKCHK(frstage_eval(k.fr, sl.fs, wit, s0));
     PinScalPtrs ptrs;
     for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = sl.scal1[i].as<uint32_t>();
     for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = sl.scal2[i].as<uint32_t>();
     const uint64_t ph = (uint64_t)k.n + 1 + 2 * (uint64_t)k.m;
     hipLaunchKernelGGL(k_pinocchio_scalars, g1d(ph), dim3(256), 0, s0, ptrs, (const uint32_t*)sl.fs.h.as<uint32_t>(),
                        (const uint32_t*)k.fr.z.as<uint32_t>(), (const uint32_t*)sl.fs.wit.as<uint32_t>(),
-                       (const uint32_t*)k.mid_idx.as<uint32_t>(), (const uint32_t*)sl.deltas.as<uint32_t>(), k.n, k.m, k.n_mid);
+                       (const uint32_t*)k.mid_idx.as<uint32_t>(), (const uint32_t*)sl.deltas.as<uint32_t>(), k.n, k.m, k.n_mid, k.lagrange ? 1u : 0u);
     HIPCHK(hipGetLastError());
     char* res = sl.results.as<char>();
     char* out = sl.out_dev.as<char>();

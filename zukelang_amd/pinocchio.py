@@ -100,6 +100,11 @@ class _Prover:
                                                     _p(mid), _p(g1), C.c_size_t(len(g1) // 96), _p(g2), C.c_size_t(len(g2) // 192), C.byref(h)))
         self.handle = h
 
+    def derive_lagrange(self):
+        """zk_pinocchio_pk_derive_lagrange: the h pool rewritten for the values of h (bases derived from the key's own powers si on the
+        device, once); afterwards every proof skips the basis conversion.  Proof bytes do not change."""
+        _lib.check(_lib.lib().zk_pinocchio_pk_derive_lagrange(self.handle))
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             _lib.lib().zk_pinocchio_pk_free(self.handle)
