@@ -327,7 +327,8 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
     it = iter(tox)
     pk, _vk = PIN.ZK.keygen(lambda: next(it), cs)
     prover = PIN.ZK(cs, pk)
-    prover.set_witness(RC.fr_bytes(w))
+    wb = RC.fr_bytes(w)
+    prover.set_witness(wb)
     depth = inflight
     prover.reserve_slots(depth)
     ds = [[next(st) for _ in range(3)] for _ in range(16)]
@@ -350,7 +351,7 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
         for i in range(2):
-            prover.prove_with(w, *ds[i])
+            prover.prove_with(wb, *ds[i])      # the witness as 32-byte values: no Python conversion inside the latency
         lat = (time.perf_counter() - t1) / 2
         parity = None
         if not args.no_parity_gate:

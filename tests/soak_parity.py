@@ -91,6 +91,10 @@ while time.time() < t_end:
         csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
         exp = O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, b"".join(frb(x) for x in w), b"".join(frb(x) for x in tox[:8]), *(frb(x) for x in tox[8:]))
         assert proof.to_bytes() == exp, ("Pinocchio mismatch", n)
+        if n_pin % 2 == 0:
+            # round 2: the h pool rewritten on the device ([lambda_t(s)], zk_pinocchio_pk_derive_lagrange) proves the same bytes
+            prover.derive_lagrange()
+            assert prover.prove_with(w, *tox[8:]).to_bytes() == exp, ("Pinocchio mismatch after the derivation", n)
         if n <= 40:
             assert PIN.ZK.verify([w[k] for k in range(cs.m) if not cs.mid[k]], vk, proof)
         prover.close()

@@ -34,11 +34,15 @@ struct PinSlot {
     DevBuf scal1[PIN_G1], scal2[PIN_G2];
     DevBuf wit_raw, deltas, results, out_dev;
     hipStream_t st = nullptr;
-    hipEvent_t done = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;      // slot 0 only: the G2 pair and the h pool run beside the five I_mid pools while the proof is alone
+    hipEvent_t done = nullptr, fork = nullptr, join1 = nullptr, join2 = nullptr;
     uint8_t* host = nullptr;          // pinned: proof 960 B | flags 4 B | deltas 96 B
     bool busy = false;
     ~PinSlot() {
         if (st) (void)hipStreamDestroy(st);
+        if (s1) (void)hipStreamDestroy(s1);
+        if (s2) (void)hipStreamDestroy(s2);
+        if (fork) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join1); (void)hipEventDestroy(join2); }
         if (done) (void)hipEventDestroy(done);
         if (host) (void)hipHostFree(host);
     }
@@ -236,6 +240,14 @@ static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
         ZKCHK(sl->out_dev.alloc(960));
         HIPCHK(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
+        if (idx == 0 && !getenv("ZK_SERIAL_STREAMS")) {
+            // the slot of the synchronous zk_pinocchio_prove: two more streams, used only while no other proof is in flight (groth16.hip, slot 0)
+            HIPCHK(hipStreamCreateWithFlags(&sl->s1, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&sl->s2, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&sl->fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sl->join1, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&sl->join2, hipEventDisableTiming));
+        }
         HIPCHK(hipHostMalloc((void**)&sl->host, 1088, hipHostMallocDefault));
         k.slots[idx] = std::move(sl);
     }
@@ -298,35 +310,50 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     // proof byte offsets: vv 0 | ww 96 | yy 288 | h 384 | vavv 480 | waww 576 | yayy 768 | bvwy 864
     const size_t off1[PIN_G1] = {0, 288, 480, 768, 864, 384};
     const size_t off2[PIN_G2] = {96, 576};
-    // sort + bucket accumulation per MSM; the reductions of MSMs whose workspaces have the same geometry (equal pool
-    // sizes: the five pools over I_mid, the two G2 pools) go out as ONE chain of launches each
-    for (int i = 0; i < PIN_G2; i++) ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], sl.scal2[i].p, s0));
-    for (int i = 0; i < PIN_G1; i++) ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], sl.scal1[i].p, s0));
-    // reductions: every product whose pool got the same window plan goes into one mixed G1 / G2 chain of launches
-    // (from 2^16 constraints up that is all eight of them)
-    {
+    // One group of products on one stream: sort + bucket accumulation per MSM; the reductions of every product whose pool got the same
+    // window plan go out as ONE mixed G1 / G2 chain of launches (from 2^16 constraints up that is the whole group); one to-bytes launch.
+    // G1 products [lo1, hi1), G2 products [lo2, hi2).
+    auto group = [&](int lo1, int hi1, int lo2, int hi2, hipStream_t st) -> int {
+        for (int i = lo2; i < hi2; i++) ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], sl.scal2[i].p, st));
+        for (int i = lo1; i < hi1; i++) ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], sl.scal1[i].p, st));
         bool done1[PIN_G1] = {}, done2[PIN_G2] = {};
         for (;;) {
             int lead_c = -1, lead_nw = -1;
-            for (int i = 0; i < PIN_G1 && lead_c < 0; i++) if (!done1[i]) { lead_c = (int)k.g1[i].c; lead_nw = (int)k.g1[i].nw; }
-            for (int i = 0; i < PIN_G2 && lead_c < 0; i++) if (!done2[i]) { lead_c = (int)k.g2[i].c; lead_nw = (int)k.g2[i].nw; }
+            for (int i = lo1; i < hi1 && lead_c < 0; i++) if (!done1[i]) { lead_c = (int)k.g1[i].c; lead_nw = (int)k.g1[i].nw; }
+            for (int i = lo2; i < hi2 && lead_c < 0; i++) if (!done2[i]) { lead_c = (int)k.g2[i].c; lead_nw = (int)k.g2[i].nw; }
             if (lead_c < 0) break;
             MsmWorkspace *w1[PIN_G1], *w2[PIN_G2];
             void *o1[PIN_G1], *o2[PIN_G2];
             const MsmBases *b1 = nullptr, *b2 = nullptr;
             uint32_t n1 = 0, n2 = 0;
-            for (int i = 0; i < PIN_G1; i++)
+            for (int i = lo1; i < hi1; i++)
                 if (!done1[i] && (int)k.g1[i].c == lead_c && (int)k.g1[i].nw == lead_nw) { w1[n1] = &sl.ws1[i]; o1[n1] = res + i * x1; n1++; done1[i] = true; b1 = &k.g1[i]; }
-            for (int i = 0; i < PIN_G2; i++)
+            for (int i = lo2; i < hi2; i++)
                 if (!done2[i] && (int)k.g2[i].c == lead_c && (int)k.g2[i].nw == lead_nw) { w2[n2] = &sl.ws2[i]; o2[n2] = res + PIN_G1 * x1 + i * x2; n2++; done2[i] = true; b2 = &k.g2[i]; }
-            ZKCHK(msm_reduce_mixed(b1, w1, o1, n1, b2, w2, o2, n2, s0));
+            ZKCHK(msm_reduce_mixed(b1, w1, o1, n1, b2, w2, o2, n2, st));
         }
-    }
-    {
         uint32_t o1[PIN_G1], o2[PIN_G2];
-        for (int i = 0; i < PIN_G1; i++) o1[i] = (uint32_t)off1[i];
-        for (int i = 0; i < PIN_G2; i++) o2[i] = (uint32_t)off2[i];
-        ZKCHK(proof_points_to_bytes_dev(res, PIN_G1, o1, res + PIN_G1 * x1, PIN_G2, o2, out, s0));      // eight conversions, one launch
+        for (int i = lo1; i < hi1; i++) o1[i - lo1] = (uint32_t)off1[i];
+        for (int i = lo2; i < hi2; i++) o2[i - lo2] = (uint32_t)off2[i];
+        return proof_points_to_bytes_dev(res + lo1 * x1, hi1 - lo1, o1, res + PIN_G1 * x1 + lo2 * x2, hi2 - lo2, o2, out, st);
+    };
+    // fork only while this is the one proof in flight on the key (single-proof latency); with others in flight every slot keeps to one stream
+    bool forked = sl.s1 != nullptr && ctx().profiling < 2;
+    for (uint32_t i = 0; forked && i < PIN_MAX_SLOTS; i++)
+        if (k.slots[i] && k.slots[i].get() != &sl && k.slots[i]->busy) forked = false;
+    if (forked) {
+        HIPCHK(hipEventRecord(sl.fork, s0));
+        HIPCHK(hipStreamWaitEvent(sl.s1, sl.fork, 0));
+        HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
+        ZKCHK(group(0, 0, 0, PIN_G2, sl.s1));                  // the G2 pair: the longest reduction chain
+        HIPCHK(hipEventRecord(sl.join1, sl.s1));
+        ZKCHK(group(5, 6, 0, 0, sl.s2));                       // the h pool: n + 1 + 2m points
+        HIPCHK(hipEventRecord(sl.join2, sl.s2));
+        ZKCHK(group(0, 5, 0, 0, s0));                          // the five pools over I_mid
+        HIPCHK(hipStreamWaitEvent(s0, sl.join1, 0));
+        HIPCHK(hipStreamWaitEvent(s0, sl.join2, 0));
+    } else {
+        ZKCHK(group(0, PIN_G1, 0, PIN_G2, s0));                // all eight products: one chain of reductions, one to-bytes launch
     }
     HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 960, hipMemcpyDeviceToHost, s0));
     HIPCHK(hipMemcpyAsync(sl.host + 960, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, s0));
