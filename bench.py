@@ -295,13 +295,38 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
         prover.reserve_slots(depth)
     dt, fam_timed, proof, lat, fam_alone, n_alone, parity = measure(True)
 
+    # ---- context: the same job on the HOST cores with the same algorithmic freedom (oracle/fast_cpu.c: Pippenger + NTT
+    # convolutions over the Lagrange-form pools this key now holds), all threads of this process's CPU share, one proof, untimed w.r.t. `value`;
+    # its bytes must equal the GPU's last timed proof
+    cpu_fast = None
+    if world == 1 and (derive or lagrange) and log_n <= args.cpu_fast_upto and proof is not None and not args.no_cpu_baseline:
+        O = oracle()
+        frs = lambda xs: bytes(RC.fr_bytes(xs))
+        csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+        threads = len(os.sched_getaffinity(0))
+        t_k = time.perf_counter()
+        fp = O.FastGroth16(cs.n, cs.m, *csr, cs.mid, prover.pool_points(1), prover.pool_points(2), threads)
+        key_s = time.perf_counter() - t_k
+        wb = frs(w)
+        r_, s_ = rs[proof_idx]
+        t_c = time.perf_counter()
+        rc, ca, cb, cc = fp.prove(wb, frs([r_]), frs([s_]))
+        cdt = time.perf_counter() - t_c
+        fp.close()
+        if rc != 0 or (ca, cb, cc) != (proof.a, proof.b, proof.c):
+            raise SystemExit("PARITY FAILURE: the multi-threaded CPU prover and the GPU disagree at n = 2^%d" % log_n)
+        cpu_fast = {"value": n / cdt, "unit": "constraints/s", "cores": threads, "kind": "port-fast", "s_per_proof": round(cdt, 3), "key_parse_s": round(key_s, 2),
+                    "sample": "ONE proof of this workload (n = 2^%d) by oracle/fast_cpu.c: Pippenger bucket sums (XYZZ, signed digits, a slice of the points per thread) + "
+                              "NTT convolutions (Newton-basis extrapolation) over the Lagrange-form pools read back from the device, %d threads; NOT the reference's "
+                              "algorithm (that is cpu_baseline); portable C, about 1.5-2x blst's cost per field product; bytes equal to the GPU's last timed proof" % (log_n, threads)}
+
     p1 = 3 + (n + 2) + (n - 1) + cs.n_mid
     p2 = 2 + (n + 2)
     pairs = {"g1": (n + 2) + p1, "g2": p2}          # scalar-point pairs actually multiplied per proof: A (n+2) + C (the whole pool) | B
     res = {"log_n": log_n, "constraints": n, "variables": cs.m, "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3,
            "ms_per_step": dt / steps * 1e3, "timed_s": dt, "timed_proofs": nproofs, "proofs_in_flight": group.batch if group is not None else depth,
            "single_proof_latency_ms": None if lat is None else lat * 1e3, "single_proof_value": None if lat is None else n / lat,
-           "setup_s": round(setup_s, 1), "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "tau_power_form": power_form, "parity": parity, "pairs": pairs, "p1": p1, "p2": p2,
+           "setup_s": round(setup_s, 1), "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "tau_power_form": power_form, "parity": parity, "cpu_fast_context": cpu_fast, "pairs": pairs, "p1": p1, "p2": p2,
            "fam_timed": fam_timed, "fam_alone": fam_alone, "n_alone": n_alone, "nproofs": nproofs,
            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_alone.items())},
            "proof_compressed_hex": proof.to_compressed().hex() if proof is not None else None,
@@ -390,7 +415,7 @@ def summarize(res, world, peak_products, traffic, lagrange):
     key = "groth16_2^%d" % res["log_n"] + ("_lagrange" if lagrange else "")
     roofs = roofline_objects(res["fam_timed"], res["nproofs"], res["fam_alone"], res["n_alone"], res["pairs"], world, windows, peak_products, traffic, key)
     out = {k: res[k] for k in ("log_n", "constraints", "variables", "value", "unit", "ms_per_proof", "timed_s", "timed_proofs", "proofs_in_flight",
-                               "single_proof_latency_ms", "single_proof_value", "setup_s", "derive_lagrange_s", "tau_power_form", "parity", "kernel_ms_per_proof")}
+                               "single_proof_latency_ms", "single_proof_value", "setup_s", "derive_lagrange_s", "tau_power_form", "parity", "cpu_fast_context", "kernel_ms_per_proof")}
     out["prove_algorithmic_bytes_per_constraint"] = 928
     out["prove_hbm_frac"] = 928.0 * res["constraints"] / (res["ms_per_proof"] * 1e-3) / 1e9 / HBM_PEAK_GBS / world
     out["roofline_g1"], out["roofline_g2"] = roofs.get("g1"), roofs.get("g2")
@@ -409,6 +434,8 @@ def main():
     ap.add_argument("--no-pinocchio", action="store_true", help="skip the Pinocchio 2^18 workload (config 5) of the default run")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs): same as --sizes '' --no-pinocchio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-fast-upto", type=int, default=18, help="workloads of at most 2^K constraints that hold Lagrange-form pools also run ONE proof on the multi-threaded CPU "
+                    "prover of oracle/fast_cpu.c (context figure `cpu_fast_context`, BASELINE.md 3.3; ~1 s at 2^16, ~4 s at 2^18 on 16 threads); -1 = never")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the oracle comparison of the last timed proof (profiling runs only)")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
@@ -536,6 +563,7 @@ def main():
             "roofline_g1": roofs.get("g1"),
             "roofline_g2": roofs.get("g2"),
             "cpu_baseline": cpu,
+            "cpu_fast_context": head.get("cpu_fast_context"),        # same workload, host cores, Pippenger + NTT (not the reference's algorithm): context only
             "kernel_ms_per_proof": head["kernel_ms_per_proof"],
             "other_workloads": others,
             "proof_compressed_hex": head["proof_compressed_hex"],     # N > 1: rank 0 prints a proof it combined itself

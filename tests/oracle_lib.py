@@ -271,3 +271,43 @@ def pinocchio_verify(vk_g1, vk_g2, io_values, proof):
         vio = P.pt_add(vio, P.pt_mul(a, c)); wio = P.pt_add(wio, P.pt_mul(b_, c)); yio = P.pt_add(yio, P.pt_mul(d, c))
     ok &= P.pairing_product_is_one([(P.pt_add(vio, vv), P.pt_add(wio, ww)), (neg(P.pt_add(yio, yy)), one2), (neg(h), yt)])   # :418-420
     return bool(ok)
+
+
+# ---------------------------------------------------------------- fast multi-threaded CPU prover (oracle/fast_cpu.c: context baseline)
+lib.orc_fast_groth16_new.restype = C.c_void_p
+
+
+class FastGroth16:
+    """Pippenger + NTT CPU prover over the Lagrange-form key (same proof bytes as the literal oracle); `threads` host threads."""
+
+    def __init__(self, n, m, L, R, O, mid, lag_g1, lag_g2, threads=1):
+        g1 = np.ascontiguousarray(np.frombuffer(bytes(lag_g1), dtype=np.uint8) if not isinstance(lag_g1, np.ndarray) else lag_g1, dtype=np.uint8).reshape(-1)
+        g2 = np.ascontiguousarray(np.frombuffer(bytes(lag_g2), dtype=np.uint8) if not isinstance(lag_g2, np.ndarray) else lag_g2, dtype=np.uint8).reshape(-1)
+        self.h = lib.orc_fast_groth16_new(n, m, *L.args(), *R.args(), *O.args(), _b(bytes(mid)), _b(g1), C.c_size_t(len(g1) // 96),
+                                          _b(g2), C.c_size_t(len(g2) // 192), int(threads))
+        if not self.h:
+            raise ValueError("orc_fast_groth16_new: key does not have the Lagrange-form layout for this circuit")
+        self._keep = (L, R, O)
+
+    def prove(self, sol, r, s):
+        out = _buf(384)
+        rc = lib.orc_fast_groth16_prove(C.c_void_p(self.h), _b(sol), _b(r), _b(s), out)
+        b = bytes(out)
+        return rc, b[:96], b[96:288], b[288:]
+
+    def close(self):
+        if self.h:
+            lib.orc_fast_groth16_free(C.c_void_p(self.h))
+            self.h = None
+
+
+def fast_g1_msm(bases, scalars, threads=1):
+    o = _buf(96)
+    rc = lib.orc_fast_g1_msm(o, _b(bases), _b(scalars), C.c_size_t(len(scalars) // 32), int(threads))
+    return rc, bytes(o)
+
+
+def fast_g2_msm(bases, scalars, threads=1):
+    o = _buf(192)
+    rc = lib.orc_fast_g2_msm(o, _b(bases), _b(scalars), C.c_size_t(len(scalars) // 32), int(threads))
+    return rc, bytes(o)
