@@ -49,6 +49,21 @@ def oracle():
     return O
 
 
+def host_threads():
+    """Threads for the CPU context leg: this process's CPU share -- the cgroup quota when there is one, else its affinity mask, at most 64
+    (ZK_BENCH_CPU_THREADS overrides)."""
+    if os.environ.get("ZK_BENCH_CPU_THREADS"):
+        return max(1, int(os.environ["ZK_BENCH_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def pmc_traffic():
     """HBM bytes per launch per kernel family from the committed PMC collection (profiles/r02_pmc_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md says).
@@ -214,6 +229,8 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
                 last = prover.prove_wait(i % depth)
         return last, (first + count - 1) % len(rs)
 
+    last_idx = [None]
+
     def measure(with_families):
         """warm-up + settle, the timed region, single-proof latency (and, with_families, the un-overlapped per-family pass), the parity gate"""
         run(0, max(nwarm, 1))
@@ -237,6 +254,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
         _lib.check(L.zk_profile_enable(1 if events else 0))
         t0 = time.perf_counter()
         proof, proof_idx = run(nwarm, nproofs)
+        last_idx[0] = proof_idx
         sync()
         dt = time.perf_counter() - t0
         _lib.check(L.zk_profile_enable(0))
@@ -303,12 +321,12 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
         O = oracle()
         frs = lambda xs: bytes(RC.fr_bytes(xs))
         csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
-        threads = len(os.sched_getaffinity(0))
+        threads = host_threads()
         t_k = time.perf_counter()
         fp = O.FastGroth16(cs.n, cs.m, *csr, cs.mid, prover.pool_points(1), prover.pool_points(2), threads)
         key_s = time.perf_counter() - t_k
         wb = frs(w)
-        r_, s_ = rs[proof_idx]
+        r_, s_ = rs[last_idx[0]]
         t_c = time.perf_counter()
         rc, ca, cb, cc = fp.prove(wb, frs([r_]), frs([s_]))
         cdt = time.perf_counter() - t_c
