@@ -170,18 +170,20 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     it = iter(toxic)
     pk, _vk = Groth16.keygen(lambda: next(it), cs, lagrange=lagrange)
     # N > 1 with the derivation enabled for this total size: every rank uploads the key WHOLE, derives its Lagrange form (redundantly, in
-    # parallel) and keeps its shard; the Fr stage -- three convolutions then -- runs replicated, and the all-gather of the 768-byte partial
-    # sums is the only collective of a proof.  Otherwise (or with --replicated-fr / GroupProver) the key is sharded at upload as before.
+    # parallel) and keeps its shard (cut for equal work, zk_groth16_shard_range).  Otherwise (--derive-lagrange-upto -1, or a total size
+    # beyond it) the key is sharded at upload and stays in tau-power form.
     derive_s = None
     total_log = log_n + max(0, (world - 1).bit_length())
-    sharded_derived = world > 1 and derive_upto is not None and total_log <= derive_upto + 1 and not lagrange and not args.group_prover
+    sharded_derived = world > 1 and derive_upto is not None and total_log <= derive_upto + 1 and not lagrange and not args.tau_power_key
     if sharded_derived:
         prover = Groth16(cs, pk)
         t_d = time.perf_counter()
         prover.derive_lagrange()
         derive_s = time.perf_counter() - t_d
         prover.shard(rank, world)
-        replicated_fr = True
+        # default: the Fr stage of a proof runs on ONE rank (its owner) and the scalar slices travel (GroupProver: one all-to-all per
+        # vector) -- replicated, every rank would run a (2^log_n x world)-constraint Fr stage per proof beside an MSM slice that does
+        # not grow with the world size; --replicated-fr keeps the simpler scheme
     else:
         prover = Groth16(cs, pk, rank, world, lagrange=lagrange)
     prover.set_witness(w)
@@ -461,9 +463,9 @@ def main():
     ap.add_argument("--derive-lagrange-upto", type=int, default=18, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
                     "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 7 s at 2^16, 27 s at 2^18, 2.2 min at 2^20) and "
                     "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
-    ap.add_argument("--group-prover", action="store_true", help="N > 1: keep the key in tau-power form and distribute the Fr stage over the proofs of a round "
-                    "(GroupProver: all-to-all of scalar slices) instead of deriving the Lagrange form on every rank")
-    ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (the simpler, slower scheme)")
+    ap.add_argument("--tau-power-key", action="store_true", help="N > 1: keep the key in tau-power form (sharded at upload) instead of deriving the Lagrange form on every rank")
+    ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (one collective per proof: the all-gather of the 768-byte "
+                    "partial sums) instead of the default, the owner's Fr stage + an all-to-all of scalar slices (GroupProver)")
     ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
     ap.add_argument("--inflight", type=int, default=14, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
     args = ap.parse_args()
@@ -562,7 +564,9 @@ def main():
                        "step": "%d consecutive proofs of the pipelined prover (pipeline not drained between steps)" % args.proofs_per_step,
                        "proofs_per_step": args.proofs_per_step, "timed_proofs": head["timed_proofs"], "timed_s": head["timed_s"],
                        "constraints": head["constraints"], "variables": head["variables"], "proofs_in_flight": head["proofs_in_flight"], "constraints_per_gpu": 1 << args.log_n,
-                       "sharding": ("MSM base points over ranks; Fr stage of a proof on its owner rank + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
+                       "sharding": ("MSM base points over ranks (slices cut for equal work: the A prefix counts twice); "
+                                    + ("every rank derived the key's Lagrange form (derive_lagrange_s) and kept its shard; " if head.get("derive_lagrange_s") is not None else "")
+                                    + "Fr stage of a proof on its owner rank + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
                                     if head["group_batch"] is not None else
                                     ("MSM base points over ranks; every rank derived the key's Lagrange form (derive_lagrange_s) and runs the three-convolution Fr stage replicated; "
                                      "all-gather of 768 B partial sums + local EC reduce" if head.get("derive_lagrange_s") is not None else

@@ -160,8 +160,14 @@ int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uin
  * multi-scalar products as raw XYZZ Montgomery limbs: A | C (G1, 4*48 B each) | B (G2, 4*96 B).
  * EC addition is not a reduction operator of RCCL, so the host all-gathers the `world` blocks as
  * bytes (torch.distributed / ncclAllGather over xGMI) and zk_groth16_combine adds them on the
- * GPU and emits the proof.  The sum is exact: the proof bytes do not depend on `world`. */
+ * GPU and emits the proof.  The sum is exact: the proof bytes do not depend on `world`.
+ * The slices are cut for equal WORK, not equal length: the first 3 + (n+2 | n) points of the G1 pool
+ * (a | d1 | b1 | the tau basis) carry two products of a proof (A and C: groth16.ml:128-134, :147-160),
+ * the others one, so rank g holds [cut(g), cut(g+1)) with cut at equal shares of points + heavy prefix;
+ * the G2 pool is cut uniformly.  zk_groth16_shard_range is that rule (pure host arithmetic, heavy_prefix = 0
+ * for the uniform cut); zk_groth16_pool_layout reports the slices a key actually holds. */
 #define ZK_GROTH16_PARTIAL_BYTES 768
+int zk_groth16_shard_range(uint64_t points, uint64_t heavy_prefix, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi);
 int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                                  const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
                                  const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world,

@@ -175,6 +175,14 @@ def main():
             p3 = dp.prove_wait(slot)
             e3 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
             assert (p3.a, p3.b, p3.c) == e3, "rank %d slot %d: pipelined proof from the derived + sharded key differs" % (rank, slot)
+        # ... and with the DISTRIBUTED Fr stage on top of it (bench.py's default at N > 1): the owner of a proof runs the three-convolution
+        # Fr stage, the scalar slices travel (cut for equal work: the A prefix counts twice), every rank multiplies its slice
+        gd = GroupProver(dp, batch=3 if world == 2 else 4)
+        assert gd.bounds1[rank] == (gd.lo1, gd.hi1)
+        gdp = gd.prove_many(rs[:2 * world + 1])
+        for (rr, ss), pr in zip(rs[:2 * world + 1], gdp):
+            e4 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
+            assert (pr.a, pr.b, pr.c) == e4, "rank %d: a group proof from the derived + sharded key differs" % rank
         dp.close()
         # an unsatisfied witness: only the OWNER of a proof sees ZK_ERR_REMAINDER (QAP.ml:134); every rank must raise
         # before the round's all-to-all instead of hanging in it, and the prover must stay usable afterwards

@@ -92,3 +92,17 @@ def test_compress_matches_oracle():
     inf1 = bytes([0x40]) + bytes(95)
     o1 = (C.c_uint8 * 48)()
     assert lib.zk_g1_compress(inf1, o1) == 0 and bytes(o1) == bytes([0xC0]) + bytes(47)
+
+
+def test_shard_range_is_the_rule_the_host_side_mirrors():
+    """zk_groth16_shard_range (pure host arithmetic in the library) == groth16.shard_bounds, uniform and with a heavy prefix."""
+    from zukelang_amd.groth16 import shard_bounds
+    lib = _lib.lib()
+    lo, hi = C.c_uint64(), C.c_uint64()
+    for size in (13, 65545, 262147, (1 << 24) + 3):
+        for heavy in (0, 5, size // 4 + 3, size):
+            for world in (1, 2, 3, 8):
+                for rank in range(world):
+                    assert lib.zk_groth16_shard_range(C.c_uint64(size), C.c_uint64(heavy), rank, world, C.byref(lo), C.byref(hi)) == 0
+                    assert (lo.value, hi.value) == shard_bounds(size, rank, world, heavy)
+    assert lib.zk_groth16_shard_range(C.c_uint64(10), C.c_uint64(0), 2, 2, C.byref(lo), C.byref(hi)) == -1

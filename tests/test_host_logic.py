@@ -52,6 +52,13 @@ def test_shard_bounds_partition_the_pools():
             assert cuts[0][0] == 0 and cuts[-1][1] == size
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
+            # the G1 rule: the first `heavy` points count twice (products A and C), the cuts balance points + heavy prefix
+            for heavy in (0, 5, size // 4, size // 2, size):
+                cuts = [shard_bounds(size, r, world, heavy) for r in range(world)]
+                assert cuts[0][0] == 0 and cuts[-1][1] == size
+                assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+                work = [(hi - lo) + max(0, min(hi, heavy) - min(lo, heavy)) for lo, hi in cuts]
+                assert sum(work) == size + heavy and max(work) - min(work) <= 3          # one heavy point = two units
 
 
 def test_splitmix_stream_is_deterministic():

@@ -108,6 +108,21 @@ __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __rest
 
 int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, DevBuf& out_g1, DevBuf& out_g2, hipStream_t s);   // lagrange_derive.hip
 
+// Contiguous slice [lo, hi) of a pool of `points` base points for `rank` of `world`, cut for equal WORK: the first `heavy` points of the G1
+// pool (a | d1 | b1 | the tau basis) carry two products of a proof, A and C (groth16.ml:128-134 vs :147-160), every other point one, so
+// the cuts sit at equal shares of points + heavy (with uniform cuts the first ranks of an 8-way split would do twice the G1 work of the
+// others).  heavy = 0: uniform.  The rule the host side mirrors (zukelang_amd/groth16.py: shard_bounds).
+static void shard_range(uint64_t points, uint64_t heavy, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
+    if (heavy > points) heavy = points;
+    const uint64_t total = points + heavy;
+    auto cut = [&](uint64_t g) -> uint64_t {
+        const uint64_t t = (uint64_t)((unsigned __int128)total * g / world);
+        return t <= 2 * heavy ? t / 2 : t - heavy;
+    };
+    *lo = cut(rank);
+    *hi = cut((uint64_t)rank + 1);
+}
+
 static int key_lookup(uint64_t handle, Groth16Key** out) {
     auto it = g_keys.find(handle);
     if (it == g_keys.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Groth16 key handle");
@@ -188,8 +203,8 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     ZKCHK(frstage_init(k.fr, n, m, L, R, O, c.stream));
     if (lagrange) ZKCHK(frstage_init_lagrange(k.fr, c.stream));
     // contiguous pool slices per rank
-    k.lo1 = k.p1 * rank / world; k.hi1 = k.p1 * (rank + 1) / world;
-    k.lo2 = k.p2 * rank / world; k.hi2 = k.p2 * (rank + 1) / world;
+    shard_range(k.p1, 3 + nt, rank, world, &k.lo1, &k.hi1);
+    shard_range(k.p2, 0, rank, world, &k.lo2, &k.hi2);
     if (k.hi1 == k.lo1 || k.hi2 == k.lo2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: more ranks than key points");
     // ONE window width per key (both pools: their bucket reductions then go out as one chain of launches).  From 2^21 points
     // in this rank's G1 pool (n >= ~2^19.6 on one GPU) 20-bit windows: 13 instead of 16 digits per scalar pay for the 16x
@@ -369,7 +384,9 @@ int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
         if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_shard: a proof is in flight on this key");
     HIPCHK(hipDeviceSynchronize());
     Ctx& c = ctx();
-    const uint64_t lo1 = k.p1 * rank / world, hi1 = k.p1 * (rank + 1) / world, lo2 = k.p2 * rank / world, hi2 = k.p2 * (rank + 1) / world;
+    uint64_t lo1, hi1, lo2, hi2;
+    shard_range(k.p1, k.p2 + 1, rank, world, &lo1, &hi1);        // p2 + 1 = 3 + the tau basis
+    shard_range(k.p2, 0, rank, world, &lo2, &hi2);
     if (hi1 == lo1 || hi2 == lo2) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_shard: more ranks than key points");
     for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();
     // window 0 of the resident tables is the pool in order: the rank keeps its contiguous slice and builds its own window tables
@@ -481,6 +498,11 @@ int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t 
     return zk_groth16_prove_partial_wait(handle, 0, partial);
 }
 // ---- distributed Fr stage: the two halves of a proof as separate calls on caller-owned device buffers
+int zk_groth16_shard_range(uint64_t points, uint64_t heavy_prefix, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
+    if (!lo || !hi || world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_shard_range: bad argument");
+    shard_range(points, heavy_prefix, rank, world, lo, hi);
+    return ZK_OK;
+}
 int zk_groth16_pool_layout(uint64_t handle, uint64_t* p1, uint64_t* p2, uint64_t* lo1, uint64_t* hi1, uint64_t* lo2, uint64_t* hi2) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));

@@ -179,10 +179,17 @@ def msm_scalar_vectors(n, v, w, h, wit, mid, r, s):
     return scalA, scalC, scalB
 
 
-def shard_bounds(size, rank, world):
-    """Contiguous slice [lo, hi) of a base pool owned by `rank` (the same rule as the library's
-    zk_groth16_pk_upload_sharded: lo = size*rank/world)."""
-    return size * rank // world, size * (rank + 1) // world
+def shard_bounds(size, rank, world, heavy=0):
+    """Contiguous slice [lo, hi) of a base pool owned by `rank`: the library's rule (zk_groth16_shard_range), restated.  The first `heavy`
+    points count twice -- in the G1 pool a | d1 | b1 | the tau basis serve the products A and C of a proof, every other point only C -- and
+    the cuts sit at equal shares of size + heavy, so the ranks get equal work; heavy = 0 is the uniform cut (the G2 pool)."""
+    heavy = min(heavy, size)
+    total = size + heavy
+
+    def cut(g):
+        t = total * g // world
+        return t // 2 if t <= 2 * heavy else t - heavy
+    return cut(rank), cut(rank + 1)
 
 
 class Groth16:
@@ -446,14 +453,14 @@ class GroupProver:
         v = [C.c_uint64() for _ in range(6)]
         _lib.check(L.zk_groth16_pool_layout(prover.handle, *[C.byref(x) for x in v]))
         self.p1, self.p2, self.lo1, self.hi1, self.lo2, self.hi2 = (int(x.value) for x in v)
-        self.bounds1 = [shard_bounds(self.p1, g, W) for g in range(W)]
+        self.bounds1 = [shard_bounds(self.p1, g, W, self.p2 + 1) for g in range(W)]       # p2 + 1 = a | d1 | b1 | the tau basis: the A prefix
         self.bounds2 = [shard_bounds(self.p2, g, W) for g in range(W)]
         assert self.bounds1[self.rank] == (self.lo1, self.hi1) and self.bounds2[self.rank] == (self.lo2, self.hi2)
         dev = torch.device("cuda", torch.cuda.current_device())
         u8 = dict(dtype=torch.uint8, device=dev)
         self.len1, self.len2 = 32 * (self.hi1 - self.lo1), 32 * (self.hi2 - self.lo2)
         # the A vector is zero beyond a | d1 | b1 | ti1[n+2] (or the n Lagrange points): only that prefix travels (-28 % volume)
-        self.nzA = 3 + (prover.circuit.n + 2)
+        self.nzA = self.p2 + 1                       # 3 + (n + 2) tau powers, or 3 + n Lagrange points
         self.boundsA = clip_bounds(self.bounds1, self.nzA)
         self.lenA = 32 * (self.boundsA[self.rank][1] - self.boundsA[self.rank][0])
         # per owned proof of the round: the owner's full vectors A, C, B and the received slices [world][slice]
