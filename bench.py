@@ -353,7 +353,8 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
            "group_batch": group.batch if group is not None else None}
     if group is not None:
         # exchange volume per proof and rank (device to device over xGMI): three scalar vectors, 32 B per element
-        res["exchange"] = {"all_to_all_bytes_per_proof_sent_by_owner": 32 * (min(group.nzA, p1) + p1 + p2),      # A: only its non-zero prefix travels
+        res["exchange"] = {"all_to_all_bytes_per_proof_sent_by_owner": 32 * ((min(group.nzA, group.p1) if group.clipA else group.p1) + group.p1 + group.p2),      # A: clipped to its non-zero prefix only when no rank's slice gets empty
+                           "a_vector_clipped": group.clipA,
                            "all_gather_bytes_per_proof_per_rank": 768,
                            "slice_points_g1": [hi - lo for lo, hi in group.bounds1],
                            "slice_points_g2": [hi - lo for lo, hi in group.bounds2]}

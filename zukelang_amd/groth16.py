@@ -462,11 +462,18 @@ class GroupProver:
         # the A vector is zero beyond a | d1 | b1 | ti1[n+2] (or the n Lagrange points): only that prefix travels (-28 % volume)
         self.nzA = self.p2 + 1                       # 3 + (n + 2) tau powers, or 3 + n Lagrange points
         self.boundsA = clip_bounds(self.bounds1, self.nzA)
+        # ... unless that leaves a rank with an EMPTY slice (with the equal-work cuts it does from two ranks up: the prefix ends inside
+        # the first ranks' slices).  An all-to-all with zero-length blocks and an empty landing tensor is a corner of RCCL / the framework
+        # this code has never met on hardware, and a rank that fails there alone would leave its peers hanging in the collective: the A
+        # vector then travels whole, like C (+50 % exchange volume, ~2 % of a round).  The same decision on every rank.
+        self.clipA = all(hi > lo for lo, hi in self.boundsA)
+        if not self.clipA:
+            self.boundsA = self.bounds1
         self.lenA = 32 * (self.boundsA[self.rank][1] - self.boundsA[self.rank][0])
         # per owned proof of the round: the owner's full vectors A, C, B and the received slices [world][slice]
         self.full = [[torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p2, **u8)] for _ in range(self.K)]
         self.recv = [[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.K)]
-        self.recvA = [torch.zeros(W * self.lenA, **u8) for _ in range(self.K)]      # compact landing buffer of the clipped A slices
+        self.recvA = [torch.zeros(W * self.lenA if self.clipA else 0, **u8) for _ in range(self.K)]      # compact landing buffer of the clipped A slices
         self.count = 0                              # proofs handled so far: proof i of the job belongs to rank i % world
         prover.reserve_slots(self.batch + self.K)
         torch.cuda.current_stream().synchronize()
@@ -500,9 +507,12 @@ class GroupProver:
                 _lib.check(worst)
             raise _lib.ZkError(worst, "a peer rank failed in the Fr stage of this round")
         for k in range((count + self.world - 1) // self.world):       # every rank takes part in every exchange of the round
-            exchange_slices(self.full[k][0], self.boundsA, self.rank, self.world, out=self.recvA[k])
-            if self.lenA:       # [world][lenA] -> the head of each owner's [len1] block; the tail stays zero (never written)
+            if self.clipA:
+                exchange_slices(self.full[k][0], self.boundsA, self.rank, self.world, out=self.recvA[k])
+                # [world][lenA] -> the head of each owner's [len1] block; the tail stays zero (never written)
                 self.recv[k][0].view(self.world, self.len1)[:, :self.lenA].copy_(self.recvA[k].view(self.world, self.lenA))
+            else:
+                exchange_slices(self.full[k][0], self.bounds1, self.rank, self.world, out=self.recv[k][0])
             for i, bounds in ((1, self.bounds1), (2, self.bounds2)):
                 exchange_slices(self.full[k][i], bounds, self.rank, self.world, out=self.recv[k][i])
         self.torch.cuda.current_stream().synchronize()        # the slices have landed before the library's streams read them
