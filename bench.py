@@ -344,7 +344,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     p2 = 2 + (n + 2)
     pairs = {"g1": (n + 2) + p1, "g2": p2}          # scalar-point pairs actually multiplied per proof: A (n+2) + C (the whole pool) | B
     res = {"log_n": log_n, "constraints": n, "variables": cs.m, "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3,
-           "ms_per_step": dt / steps * 1e3, "timed_s": dt, "timed_proofs": nproofs, "proofs_in_flight": group.batch if group is not None else depth,
+           "ms_per_step": dt / steps * 1e3, "timed_s": dt, "timed_proofs": nproofs, "proofs_in_flight": 2 * group.batch if group is not None else depth,
            "single_proof_latency_ms": None if lat is None else lat * 1e3, "single_proof_value": None if lat is None else n / lat,
            "setup_s": round(setup_s, 1), "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "tau_power_form": power_form, "parity": parity, "cpu_fast_context": cpu_fast, "pairs": pairs, "p1": p1, "p2": p2,
            "fam_timed": fam_timed, "fam_alone": fam_alone, "n_alone": n_alone, "nproofs": nproofs,

@@ -427,9 +427,12 @@ class GroupProver:
     (groth16.ml:116-161) of all proofs of the round over its slice (that many proofs in flight, one slot each), the
     768-byte partial sums of the round travel in one all-gather, and zk_groth16_combine finishes each proof.
     Per proof and rank that is 1/world of an Fr stage plus one sharded MSM triple -- with the replicated Fr stage of
-    prove_async / prove_wait on a sharded key it is a whole Fr stage.  The next round's Fr stages are enqueued before
-    this round's MSMs are waited for; ownership rotates with the running proof count, so the ranks stay balanced when
-    `batch` is not a multiple of `world`."""
+    prove_async / prove_wait on a sharded key it is a whole Fr stage.
+    The rounds are software-pipelined over TWO sets of MSM slots: the products of round i are enqueued before those of round
+    i - 1 are waited for (and gathered, combined), and the Fr stages of round i + 1 are enqueued before either, so the GPU never
+    drains between rounds (one rank's share timed on one GPU, scripts/proto/group_emulation.py: 2.05-2.27 ms per proof at N = 2
+    with drained rounds).  Ownership rotates with the running proof count, so the ranks stay balanced when `batch` is not a
+    multiple of `world`."""
 
     MAX_SLOTS = 15
 
@@ -440,15 +443,16 @@ class GroupProver:
         self.world, self.rank = prover.world, prover.rank
         W = self.world
         if batch is None:
-            # MSM slots + Fr slots = batch + ceil(batch / W) streams <= 14: the chip runs 16 hardware queues side by side and
-            # RCCL / the framework need some
-            batch = 12
-            while batch + (batch + W - 1) // W > 14:
+            # two sets of MSM slots + Fr slots = 2 batch + ceil(batch / W) streams <= 14: the chip runs 16 hardware queues side by
+            # side and RCCL / the framework need some
+            batch = 7
+            while 2 * batch + (batch + W - 1) // W > 14:
                 batch -= 1
-        self.batch = batch                          # proofs per round; MSM slots 0..batch-1
-        self.K = (batch + W - 1) // W               # Fr stages a rank runs per round at most; Fr slots batch..batch+K-1
-        if self.batch < 1 or self.batch + self.K > self.MAX_SLOTS:
-            raise ValueError("GroupProver: batch + ceil(batch / world) must not exceed %d slots" % self.MAX_SLOTS)
+        self.batch = batch                          # proofs per round; MSM slots [0, batch) and [batch, 2 batch) alternate between rounds
+        self.K = (batch + W - 1) // W               # Fr stages a rank runs per round at most; Fr slots 2 batch .. 2 batch + K - 1
+        self.fr0 = 2 * batch
+        if self.batch < 1 or self.fr0 + self.K > self.MAX_SLOTS:
+            raise ValueError("GroupProver: 2 batch + ceil(batch / world) must not exceed %d slots" % self.MAX_SLOTS)
         L = _lib.lib()
         v = [C.c_uint64() for _ in range(6)]
         _lib.check(L.zk_groth16_pool_layout(prover.handle, *[C.byref(x) for x in v]))
@@ -459,23 +463,25 @@ class GroupProver:
         dev = torch.device("cuda", torch.cuda.current_device())
         u8 = dict(dtype=torch.uint8, device=dev)
         self.len1, self.len2 = 32 * (self.hi1 - self.lo1), 32 * (self.hi2 - self.lo2)
-        # the A vector is zero beyond a | d1 | b1 | ti1[n+2] (or the n Lagrange points): only that prefix travels (-28 % volume)
+        # the A vector is zero beyond a | d1 | b1 | ti1[n+2] (or the n Lagrange points): only that prefix needs to travel (-28 % volume) ...
         self.nzA = self.p2 + 1                       # 3 + (n + 2) tau powers, or 3 + n Lagrange points
         self.boundsA = clip_bounds(self.bounds1, self.nzA)
         # ... unless that leaves a rank with an EMPTY slice (with the equal-work cuts it does from two ranks up: the prefix ends inside
         # the first ranks' slices).  An all-to-all with zero-length blocks and an empty landing tensor is a corner of RCCL / the framework
         # this code has never met on hardware, and a rank that fails there alone would leave its peers hanging in the collective: the A
-        # vector then travels whole, like C (+50 % exchange volume, ~2 % of a round).  The same decision on every rank.
+        # vector then travels whole, like C (+50 % exchange volume, ~3 % of a round).  The same decision on every rank.
         self.clipA = all(hi > lo for lo, hi in self.boundsA)
         if not self.clipA:
             self.boundsA = self.bounds1
         self.lenA = 32 * (self.boundsA[self.rank][1] - self.boundsA[self.rank][0])
-        # per owned proof of the round: the owner's full vectors A, C, B and the received slices [world][slice]
+        # per owned proof of the round: the owner's full vectors A, C, B; the received slices [world][slice], one set per slot set
+        # (the products of round i - 1 still read theirs while the exchange of round i lands)
         self.full = [[torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p2, **u8)] for _ in range(self.K)]
-        self.recv = [[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.K)]
+        self.recv = [[[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.K)] for _ in range(2)]
         self.recvA = [torch.zeros(W * self.lenA if self.clipA else 0, **u8) for _ in range(self.K)]      # compact landing buffer of the clipped A slices
         self.count = 0                              # proofs handled so far: proof i of the job belongs to rank i % world
-        prover.reserve_slots(self.batch + self.K)
+        self.rounds_done = 0                        # parity of the slot set / landing buffers the next round uses
+        prover.reserve_slots(self.fr0 + self.K)
         torch.cuda.current_stream().synchronize()
 
     def _launch_fr(self, rnd, base):
@@ -487,17 +493,17 @@ class GroupProver:
         while t < len(rnd):
             rb, sb = fr_bytes([rnd[t][0]]), fr_bytes([rnd[t][1]])
             f = self.full[k]
-            _lib.check(_lib.lib().zk_groth16_scalars_async(self.p.handle, None, _p(rb), _p(sb), C.c_uint32(self.batch + k),
+            _lib.check(_lib.lib().zk_groth16_scalars_async(self.p.handle, None, _p(rb), _p(sb), C.c_uint32(self.fr0 + k),
                                                            C.c_void_p(f[0].data_ptr()), C.c_void_p(f[1].data_ptr()), C.c_void_p(f[2].data_ptr())))
             launched.append(k)
             k += 1
             t += self.world
         return launched
 
-    def _finish_fr_and_exchange(self, launched, count):
+    def _finish_fr_and_exchange(self, launched, count, recv):
         worst = 0
         for k in launched:                       # wait for EVERY slot launched (none stays busy), keep the most severe code
-            worst = min(worst, _lib.lib().zk_groth16_scalars_wait(self.p.handle, C.c_uint32(self.batch + k)))
+            worst = min(worst, _lib.lib().zk_groth16_scalars_wait(self.p.handle, C.c_uint32(self.fr0 + k)))
         local = worst
         worst = agree_on_status(worst)           # before the first collective of the round: all ranks raise, or none
         if worst == ZK_ERR_REMAINDER:
@@ -510,11 +516,11 @@ class GroupProver:
             if self.clipA:
                 exchange_slices(self.full[k][0], self.boundsA, self.rank, self.world, out=self.recvA[k])
                 # [world][lenA] -> the head of each owner's [len1] block; the tail stays zero (never written)
-                self.recv[k][0].view(self.world, self.len1)[:, :self.lenA].copy_(self.recvA[k].view(self.world, self.lenA))
+                recv[k][0].view(self.world, self.len1)[:, :self.lenA].copy_(self.recvA[k].view(self.world, self.lenA))
             else:
-                exchange_slices(self.full[k][0], self.bounds1, self.rank, self.world, out=self.recv[k][0])
+                exchange_slices(self.full[k][0], self.bounds1, self.rank, self.world, out=recv[k][0])
             for i, bounds in ((1, self.bounds1), (2, self.bounds2)):
-                exchange_slices(self.full[k][i], bounds, self.rank, self.world, out=self.recv[k][i])
+                exchange_slices(self.full[k][i], bounds, self.rank, self.world, out=recv[k][i])
         self.torch.cuda.current_stream().synchronize()        # the slices have landed before the library's streams read them
 
     def prove_many(self, rs_list, combine_all=True):
@@ -529,20 +535,12 @@ class GroupProver:
             bases.append(c % W)
             c += len(rnd)
         proofs = []
-        launched = self._launch_fr(rounds[0], bases[0]) if rounds else []
-        for ri, rnd in enumerate(rounds):
-            cnt, base = len(rnd), bases[ri]
-            self._finish_fr_and_exchange(launched, cnt)
-            if ri + 1 < len(rounds):
-                launched = self._launch_fr(rounds[ri + 1], bases[ri + 1])      # overlaps with this round's MSMs
-            for t in range(cnt):
-                k, owner = t // W, (base + t) % W
-                rv = self.recv[k]
-                _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(t), C.c_void_p(rv[0].data_ptr() + owner * self.len1),
-                                                          C.c_void_p(rv[1].data_ptr() + owner * self.len1), C.c_void_p(rv[2].data_ptr() + owner * self.len2)))
+
+        def collect(cnt, base, slot0):
+            """wait for the products of one round, all-gather its partial sums, combine"""
             parts = np.zeros((self.batch, 768), dtype=np.uint8)
             for t in range(cnt):
-                _lib.check(L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(t), _p(parts[t])))
+                _lib.check(L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(slot0 + t), _p(parts[t])))
             gathered = all_gather_bytes(parts.reshape(-1), W).reshape(W, self.batch, 768)        # [rank][proof]
             for t in range(cnt):
                 if not combine_all and (base + t) % W != self.rank:
@@ -553,5 +551,36 @@ class GroupProver:
                 _lib.check(L.zk_groth16_combine(_p(blk), C.c_uint32(W), _p(out)))
                 b = bytes(out)
                 proofs.append(Proof(b[:96], b[96:288], b[288:]))
+
+        launched = self._launch_fr(rounds[0], bases[0]) if rounds else []
+        pending = None                          # the round whose products are in flight: (count, base, first slot)
+        for ri, rnd in enumerate(rounds):
+            cnt, base = len(rnd), bases[ri]
+            half = self.rounds_done & 1
+            rv_set = self.recv[half]
+            try:
+                self._finish_fr_and_exchange(launched, cnt, rv_set)
+            except BaseException:
+                # every rank raises here together (agree_on_status); the previous round's products are still in flight: drain them, the
+                # slots must not stay busy (the prover remains usable), their partial sums are dropped on every rank alike
+                if pending is not None:
+                    scratch = np.zeros(768, dtype=np.uint8)
+                    for t in range(pending[0]):
+                        L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(pending[2] + t), _p(scratch))
+                raise
+            if ri + 1 < len(rounds):
+                launched = self._launch_fr(rounds[ri + 1], bases[ri + 1])      # overlaps with this round's and the previous round's products
+            slot0 = half * self.batch
+            for t in range(cnt):
+                k, owner = t // W, (base + t) % W
+                rv = rv_set[k]
+                _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(slot0 + t), C.c_void_p(rv[0].data_ptr() + owner * self.len1),
+                                                          C.c_void_p(rv[1].data_ptr() + owner * self.len1), C.c_void_p(rv[2].data_ptr() + owner * self.len2)))
+            self.rounds_done += 1
+            if pending is not None:
+                collect(*pending)               # the previous round: its products ran while this round's Fr stages and exchange did
+            pending = (cnt, base, slot0)
+        if pending is not None:
+            collect(*pending)
         self.count = c
         return proofs
