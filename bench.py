@@ -461,8 +461,8 @@ def main():
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
                     "not the reference's key format -- the default and the headline use the tau-power key)")
-    ap.add_argument("--derive-lagrange-upto", type=int, default=18, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
-                    "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 7 s at 2^16, 27 s at 2^18, 2.2 min at 2^20) and "
+    ap.add_argument("--derive-lagrange-upto", type=int, default=20, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
+                    "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.7 s at 2^16, 9.5 s at 2^18, 45 s at 2^20, 3.6 min at 2^22) and "
                     "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
     ap.add_argument("--tau-power-key", action="store_true", help="N > 1: keep the key in tau-power form (sharded at upload) instead of deriving the Lagrange form on every rank")
     ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (one collective per proof: the all-gather of the 768-byte "

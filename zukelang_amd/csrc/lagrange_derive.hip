@@ -16,6 +16,7 @@
 // same code on the tree of the shifted points n..2n-2.  scripts/proto/lagrange_derive_model.py is the integer model of the algebra;
 // tests compare the derived pools byte for byte with what a keygen that knows tau emits (Groth16.keygen(..., lagrange=True)).
 #include "ec.cuh"
+#include "endo_consts.cuh"
 #include "frstage.cuh"
 #include "msm.cuh"
 
@@ -26,25 +27,106 @@ namespace zk {
 static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
 template <class T> struct LaneCount { static constexpr uint32_t N = RawLayout<T>::LANES; };
 
-// ---- scalar (canonical Fr, 8 words in memory) times point, MSB first; complete formulas (identity, equal operands)
-template <class T> FF_INLINE Xyzz<T> xyzz_mul_scalar(const Xyzz<T>& p, const uint32_t* __restrict__ k) {
-    Xyzz<T> acc = xyzz_inf<T>();
-    bool started = false;                                  // wave-uniform leading zero words are skipped
+// ---- scalar (canonical Fr, 8 words in memory) times point, complete formulas (identity, equal operands).  Fixed 4-bit windows: the
+// multiples 1 P .. 15 P go to a per-lane table in device memory (7 doublings + 7 additions), then every window costs 4 doublings + ONE
+// addition of the looked-up multiple per sub-scalar (with per-lane scalars the conditional addition of a bitwise ladder would run in nearly
+// every step of a wave).  Round-2 history: bitwise 5 600 field products per multiplication, one 255-bit scalar in 64 windows 3 300
+// (4.2 s / 15.8 s / 77 s at 2^16 / 2^18 / 2^20 for a key's three sets), split through the endomorphisms 2 300 on G1 and 1 700 Fp2
+// products on G2 (2.7 s / 9.5 s / 45 s).
+// The scalar is split through the curve's endomorphisms (Gallant-Lambert-Vanstone on G1, Galbraith-Lin-Scott on G2): the doublings are
+// what a 255-bit scalar costs (256 x 9 of 3 300 field products), and they are shared between the sub-scalars of
+//   G1:  k = q z^2 + t  =>  k P = (t + q) P + q phi(P),   phi(x, y) = (beta x, y) = [z^2 - 1] (x, y)          2 scalars of <= 129 bits
+//   G2:  k = sum_i k_i |z|^i  =>  k P = sum_i (-1)^i k_i psi^i(P),   psi(x, y) = (cx conj x, cy conj y) = [z] (x, y)      4 scalars of 64 bits
+// (z = -0xd201000000010000; r = z^4 - z^2 + 1, p = z mod r).  ONE table of the multiples 1 P .. 15 P as before; the image of an entry under
+// phi / psi^i costs one / two products by constants (scripts/gen_endo_consts.py derives and CHECKS them against first-principles
+// arithmetic).  132 doublings + ~62 additions on G1, 64 + ~60 on G2.  The split is a bitwise long division per lane (~600 steps of a few
+// integer instructions: the cost of a handful of field products).
+FF_INLINE void glv_split_g1(const uint32_t* __restrict__ k, uint32_t a[5], uint32_t b[4]) {
+    const uint64_t d0 = (uint64_t)ENDO_Z2[0] | ((uint64_t)ENDO_Z2[1] << 32), d1 = (uint64_t)ENDO_Z2[2] | ((uint64_t)ENDO_Z2[3] << 32);
+    uint64_t r0 = 0, r1 = 0;
+    uint32_t q[8];
+#pragma unroll 1
     for (int w = 7; w >= 0; w--) {
         const uint32_t bits = k[w];
-        if (!started && __ballot(bits != 0) == 0) continue;
-        started = true;
-        for (int b = 31; b >= 0; b--) {
-            acc = xyzz_dbl_impl(acc);
-            if ((bits >> b) & 1u) xyzz_add_impl(acc, p);
+        uint32_t qw = 0;
+#pragma unroll 1
+        for (int bt = 31; bt >= 0; bt--) {
+            const uint64_t top = r1 >> 63;
+            r1 = (r1 << 1) | (r0 >> 63);
+            r0 = (r0 << 1) | ((bits >> bt) & 1u);
+            const bool ge = top || r1 > d1 || (r1 == d1 && r0 >= d0);
+            if (ge) {
+                const uint64_t br = r0 < d0 ? 1u : 0u;
+                r0 -= d0;
+                r1 = r1 - d1 - br;
+            }
+            qw = (qw << 1) | (ge ? 1u : 0u);
         }
+        q[w] = qw;
     }
-    return acc;
+    // k < r < z^4: the quotient has 128 bits; a = t + q has at most 129
+    uint64_t c = 0;
+    const uint32_t t[4] = {(uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32)};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        b[i] = q[i];
+        c += (uint64_t)t[i] + q[i];
+        a[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    a[4] = (uint32_t)c;
 }
-// The same with fixed 4-bit windows: the multiples 1 P .. 15 P go to a per-lane table in device memory (7 doublings + 7 additions), then 64
-// windows of 4 doublings + ONE addition of the looked-up multiple.  With per-lane scalars the conditional addition of the bitwise form runs in
-// nearly every step of a wave (256 doublings + ~256 additions = 5 600 field products); here it is 256 + 78 (3 100 products).
-template <class T> FF_INLINE Xyzz<T> xyzz_mul_scalar_w4(const Xyzz<T>& p, const uint32_t* __restrict__ k, uint8_t* __restrict__ tab) {
+FF_INLINE void gls_split_g2(const uint32_t* __restrict__ k, uint64_t d[4]) {
+    const uint64_t z = (uint64_t)ENDO_Z[0] | ((uint64_t)ENDO_Z[1] << 32);
+    uint32_t cur[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cur[i] = k[i];
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        uint64_t r = 0;
+#pragma unroll 1
+        for (int w = 7 - 2 * it; w >= 0; w--) {          // the dividend loses 64 bits per round
+            const uint32_t bits = cur[w];
+            uint32_t qw = 0;
+#pragma unroll 1
+            for (int bt = 31; bt >= 0; bt--) {
+                const uint64_t top = r >> 63;
+                r = (r << 1) | ((bits >> bt) & 1u);
+                const bool ge = top || r >= z;
+                if (ge) r -= z;
+                qw = (qw << 1) | (ge ? 1u : 0u);
+            }
+            cur[w] = qw;
+        }
+        d[it] = r;
+    }
+    d[3] = (uint64_t)cur[0] | ((uint64_t)cur[1] << 32);
+}
+FF_INLINE FpB<1> endo_limbs(const uint32_t* __restrict__ c) {
+    FpB<1> r;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) r.v[i] = c[i];
+    return r;
+}
+// the table entry under phi
+FF_INLINE void endo_apply_g1(Xyzz<Fp>& q) { q.x = Fp(fe_mul(q.x, endo_limbs(ENDO_BETA))); }
+// the table entry under (-1)^i psi^i, i = 1..3 (lane pair: this lane holds component pair_comp() of every coordinate)
+FF_INLINE void endo_apply_g2(Xyzz<Fp2H>& q, int i) {
+    const uint32_t comp = pair_comp();
+    const bool flip = (i & 1) && comp;                   // conj^i negates the c1 component for odd i
+    const Fp2HB<1> cx{endo_limbs(ENDO_PSI_X[i - 1][comp])}, cy{endo_limbs(ENDO_PSI_Y[i - 1][comp])};
+    auto conj = [&](const Fp2H& a) -> Fp2HB<128> {
+        const FpB<128> n = fe_neg(a.v), p = a.v;
+        return {fp_select(flip, p, n)};
+    };
+    q.x = Fp2H(fe_mul(conj(q.x), cx));
+    q.y = Fp2H(fe_mul(conj(q.y), cy));
+    if (i & 1) {
+        q.zz = Fp2H(fp_canon(conj(q.zz).v));
+        q.zzz = Fp2H(fp_canon(conj(q.zzz).v));
+    }
+}
+template <class T> FF_INLINE void window_table(const Xyzz<T>& p, uint8_t* __restrict__ tab) {
     constexpr int XB = RawLayout<T>::XYZZ;
     xyzz_store_raw<T>(tab + XB * 1, p);
     for (uint32_t d = 2; d < 16; d++) {
@@ -57,20 +139,60 @@ template <class T> FF_INLINE Xyzz<T> xyzz_mul_scalar_w4(const Xyzz<T>& p, const 
         }
         xyzz_store_raw<T>(tab + XB * d, q);
     }
-    Xyzz<T> acc = xyzz_inf<T>();
+}
+FF_INLINE Xyzz<Fp> xyzz_mul_scalar_endo(const Xyzz<Fp>& p, const uint32_t* __restrict__ k, uint8_t* __restrict__ tab) {
+    constexpr int XB = RawLayout<Fp>::XYZZ;
+    window_table<Fp>(p, tab);
+    uint32_t a[5], b[4];
+    glv_split_g1(k, a, b);
+    Xyzz<Fp> acc = xyzz_inf<Fp>();
     bool started = false;
-    for (int w = 7; w >= 0; w--) {
-        const uint32_t bits = k[w];
-        if (!started && __ballot(bits != 0) == 0) continue;
-        for (int b = 28; b >= 0; b -= 4) {
-            if (started) {
 #pragma unroll 1
-                for (int r = 0; r < 4; r++) acc = xyzz_dbl_impl(acc);
-            }
-            started = true;
-            const uint32_t dg = (bits >> b) & 15u;
-            if (dg) {
-                const Xyzz<T> q = xyzz_load_raw<T>(tab + XB * dg);
+    for (int w = 32; w >= 0; w--) {
+        const uint32_t da = (a[w >> 3] >> ((w & 7) * 4)) & 15u, db = w < 32 ? (b[w >> 3] >> ((w & 7) * 4)) & 15u : 0u;
+        if (!started) {
+            if (__ballot((da | db) != 0) == 0) continue;          // wave-uniform leading zero windows
+        } else {
+#pragma unroll 1
+            for (int r = 0; r < 4; r++) acc = xyzz_dbl_impl(acc);
+        }
+        started = true;
+        if (da) {
+            const Xyzz<Fp> q = xyzz_load_raw<Fp>(tab + XB * da);
+            xyzz_add_impl(acc, q);
+        }
+        if (db) {
+            Xyzz<Fp> q = xyzz_load_raw<Fp>(tab + XB * db);
+            endo_apply_g1(q);
+            xyzz_add_impl(acc, q);
+        }
+    }
+    return acc;
+}
+FF_INLINE Xyzz<Fp2H> xyzz_mul_scalar_endo(const Xyzz<Fp2H>& p, const uint32_t* __restrict__ k, uint8_t* __restrict__ tab) {
+    constexpr int XB = RawLayout<Fp2H>::XYZZ;
+    window_table<Fp2H>(p, tab);
+    uint64_t d[4];
+    gls_split_g2(k, d);
+    Xyzz<Fp2H> acc = xyzz_inf<Fp2H>();
+    bool started = false;
+#pragma unroll 1
+    for (int w = 15; w >= 0; w--) {
+        uint32_t dg[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) dg[i] = (uint32_t)(d[i] >> (4 * w)) & 15u;
+        if (!started) {
+            if (__ballot((dg[0] | dg[1] | dg[2] | dg[3]) != 0) == 0) continue;
+        } else {
+#pragma unroll 1
+            for (int r = 0; r < 4; r++) acc = xyzz_dbl_impl(acc);
+        }
+        started = true;
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+            if (dg[i]) {                                          // pair-uniform: both lanes of a pair hold the same scalar
+                Xyzz<Fp2H> q = xyzz_load_raw<Fp2H>(tab + XB * dg[i]);
+                if (i) endo_apply_g2(q, i);
                 xyzz_add_impl(acc, q);
             }
         }
@@ -108,7 +230,7 @@ __global__ __launch_bounds__(128) void k_gntt_stage(uint8_t* __restrict__ pts, c
     Xyzz<T> u = xyzz_load_raw<T>(pts + XB * e), v = xyzz_load_raw<T>(pts + XB * (e + h));
     const uint32_t* w = tw + 8 * (h + j);
     if (INVERSE) {
-        if (log_h) v = xyzz_mul_scalar_w4(v, w, tab);      // span 2: the twiddle is 1 (wave-uniform test)
+        if (log_h) v = xyzz_mul_scalar_endo(v, w, tab);      // span 2: the twiddle is 1 (wave-uniform test)
         Xyzz<T> x = u;
         xyzz_add_impl(x, v);
         v.y = neg_coord(v.y);
@@ -120,7 +242,7 @@ __global__ __launch_bounds__(128) void k_gntt_stage(uint8_t* __restrict__ pts, c
         xyzz_add_impl(x, v);
         v.y = neg_coord(v.y);
         xyzz_add_impl(u, v);                                // u - v
-        if (log_h) u = xyzz_mul_scalar_w4(u, w, tab);
+        if (log_h) u = xyzz_mul_scalar_endo(u, w, tab);
         xyzz_store_raw<T>(pts + XB * e, x);
         xyzz_store_raw<T>(pts + XB * (e + h), u);
     }
@@ -131,7 +253,7 @@ template <class T> __global__ __launch_bounds__(128) void k_g_tabmul(uint8_t* __
     const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, i = i0 + loc;
     if (i >= total) return;
     const Xyzz<T> p = xyzz_load_raw<T>(pts + XB * i);
-    xyzz_store_raw<T>(pts + XB * i, xyzz_mul_scalar_w4(p, tab + 8 * i, scratch + (uint64_t)16 * XB * loc));
+    xyzz_store_raw<T>(pts + XB * i, xyzz_mul_scalar_endo(p, tab + 8 * i, scratch + (uint64_t)16 * XB * loc));
 }
 // scalar multiplications per launch: bounds the scratch of the window tables (16 multiples each) to 1 (G1) / 2 (G2) GiB
 static constexpr uint64_t DERIVE_SLAB = (uint64_t)1 << 18;
