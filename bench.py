@@ -419,13 +419,37 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
         derive_s = time.perf_counter() - t_d
     dt, lat, parity = measure()
     prover.close()
+    # ---- CPU baseline of THIS protocol: the oracle's restatement of ZKCompute.f (pinocchio.ml:427-514: one scalar multiplication per key
+    # element touched, QAP.eval with schoolbook polynomials) on one host core at n = 1024; the GPU proof of the sample must be byte-identical
+    cpu = None
+    if not args.no_cpu_baseline:
+        O = oracle()
+        frs = lambda xs: bytes(RC.fr_bytes(xs))
+        ns = 1024
+        cs2, w2 = RC.iterated_cubic(ns, next(RC.fr_stream(0x5EED0001)))
+        it2 = iter(tox)
+        pk2, _ = PIN.ZK.keygen(lambda: next(it2), cs2)
+        csr2 = [O.CSR(M.ptr, M.col, M.val) for M in (cs2.L, cs2.R, cs2.O)]
+        q = O.QAP(cs2.n, cs2.m, *csr2)
+        dvs = [frs([x]) for x in ds[0]]
+        t_c = time.perf_counter()
+        rc, ref = O.pinocchio_prove(q, bytes(pk2.g1), bytes(pk2.g2), cs2.mid, frs(w2), *dvs)
+        cdt = time.perf_counter() - t_c
+        p2 = PIN.ZK(cs2, pk2)
+        got = p2.prove_with(w2, *ds[0]).to_bytes()
+        p2.close()
+        if rc != 0 or got != ref:
+            raise SystemExit("PARITY FAILURE: GPU Pinocchio proof differs from the oracle on the cpu_baseline sample")
+        cpu = {"value": ns / cdt, "unit": "constraints/s", "cores": 1, "kind": "port",
+               "sample": "oracle restatement of pinocchio.ml:427-514 (ZKCompute.f: single scalar multiplications, schoolbook QAP.eval) on the iterated-cubic "
+                         "R1CS at n=%d; %.2f s; GPU proof of the sample byte-identical" % (ns, cdt)}
     m_mid = cs.n_mid
     alg = 5 * 128 * m_mid + 2 * 128 * cs.m + 2 * 128 * n + 2 * 224 * m_mid + 192 * n       # 1792 n B at m_mid = m = n
     return {"workload": "pinocchio_zk_prove (BASELINE config 5), iterated-cubic R1CS, key+circuit+witness resident in HBM", "log_n": log_n, "constraints": n,
             "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3, "timed_s": dt, "timed_proofs": nproofs,
             "proofs_in_flight": depth, "single_proof_latency_ms": lat * 1e3, "single_proof_note": "one at a time, witness handed over as a host buffer",
             "prove_algorithmic_bytes_per_constraint": alg / n, "prove_hbm_frac": alg / (dt / nproofs) / 1e9 / HBM_PEAK_GBS, "parity": parity,
-            "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "as_uploaded": as_uploaded}
+            "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "as_uploaded": as_uploaded, "cpu_baseline": cpu}
 
 
 def summarize(res, world, peak_products, traffic, lagrange):
