@@ -359,7 +359,7 @@ int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pnt
 }
 
 int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, hipStream_t s) {
-    if (n < 2 || n > (1u << 24)) ZK_FAIL(ZK_ERR_ARG, "constraint count must be in [2, 2^24]");
+    if (n < 1 || n > (1u << 24)) ZK_FAIL(ZK_ERR_ARG, "constraint count must be in [1, 2^24]");
     if (m == 0) ZK_FAIL(ZK_ERR_ARG, "no variables");
     f.n = n; f.m = m;
     f.log_n2 = ceil_log2(n); f.n2 = 1u << f.log_n2;
@@ -367,6 +367,15 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     ZKCHK(upload_csr(f.L, L, n, m, s));
     ZKCHK(upload_csr(f.R, R, n, m, s));
     ZKCHK(upload_csr(f.O, O, n, m, s));
+    if (n == 1) {
+        // ONE gate: v, w, y are the constants (L w)_0, (R w)_0, (O w)_0, Z = X, h = 0 (no coefficient at all: QAP.ml:132-135 divides a
+        // polynomial that must vanish) -- the values ARE the coefficients, no table is needed, only Z for the callers that blind with it
+        ZKCHK(f.z.alloc(64));
+        HIPCHK(hipMemsetAsync(f.z.p, 0, 64, s));
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, s, FRP(f.z) + 8);
+        HIPCHK(hipStreamSynchronize(s));
+        return ZK_OK;
+    }
     ZKCHK(ntt_ensure_twiddles(f.log_S));
     const uint32_t n2 = f.n2, S = f.S;
     ZKCHK(f.invfact.alloc(32 * (size_t)n2));
@@ -469,6 +478,11 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
         hipLaunchKernelGGL(k_check_r1cs, g1d(n), dim3(256), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)cc, n, sc.flag.as<int>());
         HIPCHK(hipGetLastError());
     }
+    if (n == 1) {      // one gate: the values are the (constant) polynomials; h is empty
+        HIPCHK(hipMemcpyAsync(sc.d.p, a, 32, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(FRP(sc.d) + 8 * (uint64_t)n2, b, 32, hipMemcpyDeviceToDevice, s));
+        return ZK_OK;
+    }
     // ---- values -> Newton coefficients (both vectors), into d[0..n2) and d[n2..2 n2)
     {
         ScopedTimer t("fr_newton", s);
@@ -500,6 +514,7 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
 
 int frstage_init_lagrange(FrStage& f, hipStream_t s) {
     const uint32_t n = f.n, S = f.S;
+    if (n == 1) { f.lagrange = true; return ZK_OK; }      // one gate: l_0 = 1, nothing to extrapolate
     ZKCHK(f.g_ntt.alloc(32 * (size_t)S));
     ZKCHK(f.zt.alloc(32 * (size_t)(n > 1 ? n - 1 : 1)));
     hipLaunchKernelGGL(k_inv_range, g1d((S + FCH - 1) / FCH, 64), dim3(64), 0, s, FRP(f.g_ntt), S);
@@ -534,7 +549,7 @@ int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_wit_can
         hipLaunchKernelGGL(k_check_r1cs, g1d(n), dim3(256), 0, s, (const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)cc, n, sc.flag.as<int>());
         HIPCHK(hipGetLastError());
     }
-    {
+    if (n > 1) {
         ScopedTimer t("fr_extrapolate", s);
         const uint32_t* src[3] = {a, b, cc};
         void* dst[3] = {sc.bufA.p, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), sc.tmp.p};

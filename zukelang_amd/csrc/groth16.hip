@@ -193,7 +193,7 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     for (uint32_t i = 0; i < m; i++)
         if (mid[i]) mids.push_back(i);
     k.n_mid = (uint32_t)mids.size();
-    if (n < 2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: need at least 2 constraints");
+    if (n < 1) ZK_FAIL(ZK_ERR_ARG, "pk_upload: need at least 1 constraint");
     k.lagrange = lagrange;
     const uint64_t nt = lagrange ? n : (uint64_t)n + 2;
     k.p1 = 3 + nt + (n - 1) + k.n_mid;
@@ -631,7 +631,7 @@ int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uin
     uint8_t* outs[3] = {v_out, w_out, h_out};
     size_t cnt[3] = {k->n, k->n, (size_t)k->n - 1};
     for (int i = 0; i < 3; i++) {
-        if (!outs[i]) continue;
+        if (!outs[i] || cnt[i] == 0) continue;          // a single gate has no h coefficient
         ZKCHK(fr_from_mont(tmp.p, srcs[i], cnt[i], sl->s0));
         HIPCHK(hipMemcpyAsync(outs[i], tmp.p, 32 * cnt[i], hipMemcpyDeviceToHost, sl->s0));
         HIPCHK(hipStreamSynchronize(sl->s0));

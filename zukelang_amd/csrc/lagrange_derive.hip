@@ -424,6 +424,12 @@ int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_
     HIPCHK(hipMemcpyAsync(out_g1.p, d_g1, 96 * 3, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(out_g1.as<uint8_t>() + 96 * (3 + (uint64_t)n + (n - 1)), d_g1 + 96 * o_lt, 96 * n_mid, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(out_g2.p, d_g2, 192 * 2, hipMemcpyDeviceToDevice, s));
+    if (n == 1) {      // one gate: l_0 = 1, the Lagrange point IS [tau^0]
+        HIPCHK(hipMemcpyAsync(out_g1.as<uint8_t>() + 96 * 3, d_g1 + 96 * o_ti, 96, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(out_g2.as<uint8_t>() + 192 * 2, d_g2 + 192 * 2, 192, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return ZK_OK;
+    }
     {
         ScopedTimer tm("lagrange_derive", s);
         DeriveTables t0;

@@ -136,7 +136,7 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     for (uint32_t i = 0; i < m; i++)
         if (mid[i]) mids.push_back(i);
     const uint64_t nm = k.n_mid = (uint32_t)mids.size();
-    if (n < 2) ZK_FAIL(ZK_ERR_ARG, "pinocchio pk_upload: need at least 2 constraints");      // an EMPTY I_mid is fine: the pools keep their appended single points
+    if (n < 1) ZK_FAIL(ZK_ERR_ARG, "pinocchio pk_upload: need at least 1 constraint");      // an EMPTY I_mid is fine: the pools keep their appended single points
     if (pk_g1_points != 5 * nm + (n + 1) + 2 * (uint64_t)m + 7) ZK_FAIL(ZK_ERR_DOMAIN, "pinocchio pk_upload: G1 key length");
     if (pk_g2_points != 2 * nm + (n + 1) + 2) ZK_FAIL(ZK_ERR_DOMAIN, "pinocchio pk_upload: G2 key length");
     ZKCHK(frstage_init(k.fr, n, m, L, R, O, c.stream));
