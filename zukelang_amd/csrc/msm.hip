@@ -310,13 +310,59 @@ __global__ void k_sort_colscan(SortJobs jobs, uint32_t nb, uint32_t nwg) {
     totals[b] = run;
 }
 
-// single workgroup: offsets[k] = sum_{q<k} counts[q], offsets[nb] = total; cursor = offsets
+// single workgroup: offsets[k] = sum_{q<k} counts[q], offsets[nb] = total; cursor = offsets.
+// The usual geometries (2^12 .. 2^15 counters, a multiple of 4096) run in tiles of 4096: every thread holds one 16-byte vector of each tile
+// (up to eight COALESCED loads issued back to back), a tile is scanned with wave shuffles and sixteen wave totals in LDS, and both outputs
+// leave as coalesced 16-byte stores.  The general path below walks a contiguous chunk per thread with dependent-latency scalar loads (one
+// HBM round trip per counter: 120-150 us per launch on a 2^16 proof's critical path).
 __global__ __launch_bounds__(1024) void k_scan(SortJobs jobs, uint32_t nb) {
     const uint32_t* __restrict__ counts = jobs.counts[blockIdx.x];
     uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.x];
     uint32_t* __restrict__ cursor = jobs.cursor[blockIdx.x];
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
+    if (nb <= 32768 && (nb & 4095) == 0) {
+        const uint32_t tiles = nb >> 12, lane = t & 63u, wv = t >> 6;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(counts);
+        uint4* __restrict__ o1 = reinterpret_cast<uint4*>(offsets);
+        uint4* __restrict__ o2 = reinterpret_cast<uint4*>(cursor);
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (uint32_t)j < tiles ? src[t + 1024u * j] : make_uint4(0, 0, 0, 0);
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if ((uint32_t)j >= tiles) break;                       // block-uniform
+            const uint32_t s4 = v[j].x + v[j].y + v[j].z + v[j].w;
+            uint32_t incl = s4;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= (uint32_t)d) incl += y;
+            }
+            if (lane == 63) part[wv] = incl;
+            __syncthreads();
+            uint32_t before = 0, tot = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 16; w++) {
+                const uint32_t y = part[w];
+                before += w < wv ? y : 0u;
+                tot += y;
+            }
+            __syncthreads();
+            uint32_t run = carry + before + incl - s4;
+            uint4 o;
+            o.x = run; run += v[j].x;
+            o.y = run; run += v[j].y;
+            o.z = run; run += v[j].z;
+            o.w = run;
+            o1[t + 1024u * j] = o;
+            o2[t + 1024u * j] = o;
+            carry += tot;
+        }
+        if (t == 0) offsets[nb] = carry;
+        return;
+    }
     const uint32_t per = (nb + 1023) / 1024;
     const uint32_t lo = t * per, hi = min(lo + per, nb);
     uint32_t s = 0;
