@@ -157,13 +157,16 @@ struct DigitArgs {
     uint32_t K[9];         // the recoding constant, 288 bits
     const uint8_t* ident;  // precomp: 1 = base i is the identity: it never enters a bucket (nullptr: no filter)
     uint32_t coarse_shift;  // two-level sort, level 1: histogram / rank by bucket >> coarse_shift and emit (bucket, reference) records
+    uint32_t scalar_major;  // LDS sorts: a workgroup owns a range of SCALARS and files all their digits (each scalar is read once per pass,
+                            // not once per window: 13-16x less scalar traffic in the two passes); 0: a range of (scalar, window) pairs, window-major
     uint32_t alias_windows; // EXPERIMENT (ZK_EXPERIMENT_TABLE_ALIAS=1, results WRONG): every window reads window 0's table entries --
                             // same additions, same number of gathers, 1/16 of the table footprint: what the 16x table traffic costs
 };
-FF_INLINE bool digit_of(const uint32_t* __restrict__ scalars, uint64_t i, uint32_t j, const DigitArgs& a, uint32_t& key, uint32_t& val) {
+// scalar i plus the recoding constant (9 words); false: the scalar is zero or its base is the identity -- no digit of it enters a bucket
+FF_INLINE bool digits_prepare(const uint32_t* __restrict__ scalars, uint64_t i, const DigitArgs& a, uint32_t s[9]) {
     const uint32_t* sp = scalars + 8 * i;
     uint4 lo = reinterpret_cast<const uint4*>(sp)[0], hi = reinterpret_cast<const uint4*>(sp)[1];
-    uint32_t s[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0};
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w; s[8] = 0;
     if ((s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) == 0) return false;
     if (a.ident && a.ident[i]) return false;
     uint64_t cy = 0;
@@ -173,6 +176,14 @@ FF_INLINE bool digit_of(const uint32_t* __restrict__ scalars, uint64_t i, uint32
         s[k] = (uint32_t)cy;
         cy >>= 32;
     }
+    return true;
+}
+FF_INLINE bool digit_at(const uint32_t s[9], uint64_t i, uint32_t j, const DigitArgs& a, uint32_t& key, uint32_t& val);
+FF_INLINE bool digit_of(const uint32_t* __restrict__ scalars, uint64_t i, uint32_t j, const DigitArgs& a, uint32_t& key, uint32_t& val) {
+    uint32_t s[9];
+    return digits_prepare(scalars, i, a, s) && digit_at(s, i, j, a, key, val);
+}
+FF_INLINE bool digit_at(const uint32_t s[9], uint64_t i, uint32_t j, const DigitArgs& a, uint32_t& key, uint32_t& val) {
     const uint32_t off = j * a.c, w = off >> 5, b = off & 31;
     uint32_t x0 = 0, x1 = 0;
 #pragma unroll
@@ -264,11 +275,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(SortJobs jobs, 
     const uint32_t wg = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) hist[b] = 0;
     __syncthreads();
-    const uint64_t total = a.n * a.nw, lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, total);
-    for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
-        uint32_t key = 0, val = 0;
-        const bool ok = digit_of(scalars, g % a.n, (uint32_t)(g / a.n), a, key, val);
-        (void)wave_aggregated_add(hist, ok, key >> a.coarse_shift);
+    if (a.scalar_major) {
+        const uint64_t lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, a.n);          // per_wg counts scalars here
+        for (uint64_t i0 = lo; i0 < hi; i0 += SORT_THREADS) {                           // whole waves: the aggregated add ballots
+            const uint64_t i = i0 + threadIdx.x;
+            uint32_t sk[9];
+            const bool live = i < hi && digits_prepare(scalars, i, a, sk);
+            for (uint32_t j = 0; j < a.nw; j++) {
+                uint32_t key = 0, val = 0;
+                const bool ok = live && digit_at(sk, i, j, a, key, val);
+                (void)wave_aggregated_add(hist, ok, key >> a.coarse_shift);
+            }
+        }
+    } else {
+        const uint64_t total = a.n * a.nw, lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, total);
+        for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
+            uint32_t key = 0, val = 0;
+            const bool ok = digit_of(scalars, g % a.n, (uint32_t)(g / a.n), a, key, val);
+            (void)wave_aggregated_add(hist, ok, key >> a.coarse_shift);
+        }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) wgcount[(uint64_t)wg * nb + b] = hist[b];   // [workgroup][bucket]: coalesced
@@ -282,6 +307,24 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(SortJobs jobs
     const uint32_t wg = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cur[b] = offsets[b] + base[(uint64_t)wg * nb + b];
     __syncthreads();
+    if (a.scalar_major) {
+        const uint64_t lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, a.n);
+        for (uint64_t i0 = lo; i0 < hi; i0 += SORT_THREADS) {
+            const uint64_t i = i0 + threadIdx.x;
+            uint32_t sk[9];
+            const bool live = i < hi && digits_prepare(scalars, i, a, sk);
+            for (uint32_t j = 0; j < a.nw; j++) {
+                uint32_t key = 0, val = 0;
+                const bool ok = live && digit_at(sk, i, j, a, key, val);
+                const uint32_t pos = wave_aggregated_add(cur, ok, key >> a.coarse_shift);
+                if (ok) {
+                    if (a.coarse_shift) jobs.sorted2[blockIdx.y][pos] = make_uint2(key, val);
+                    else sorted[pos] = val;
+                }
+            }
+        }
+        return;
+    }
     const uint64_t total = a.n * a.nw, lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, total);
     for (uint64_t g = lo + threadIdx.x; g < hi; g += SORT_THREADS) {
         uint32_t key = 0, val = 0;
@@ -993,8 +1036,12 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
     }
     MsmWorkspace& w = *ws[0];
     const uint32_t nbw = 1u << (b.c - 1);
+    // scalar-major LDS sorts need ONE bucket set (resident keys: every window files into the same 2^(c-1) buckets); ZK_SORT_SCALAR_MAJOR=0 restores
+    // the window-major ranges
+    static const bool want_sm = !(getenv("ZK_SORT_SCALAR_MAJOR") && atoi(getenv("ZK_SORT_SCALAR_MAJOR")) == 0);
+    const bool sm = want_sm && b.precomp && w.sort_wgs != 0;
     DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}, b.precomp ? b.ident.as<uint8_t>() : nullptr,
-                 0u, (getenv("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(getenv("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u};
+                 0u, sm ? 1u : 0u, (getenv("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(getenv("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
         uint32_t off = j * b.c, wd = off >> 5, sh = off & 31;
@@ -1020,7 +1067,7 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             }
             DigitArgs d1 = da;
             d1.coarse_shift = w.sort_fine_bits;
-            const uint64_t total = b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
+            const uint64_t total = sm ? b.n : b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
             hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
             dim3 gc = grid_for(bins, 256);
             gc.y = count;
@@ -1031,7 +1078,7 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             for (uint32_t i = 0; i < count; i++) l2.cursor[i] = l1.offsets[i];          // the coarse offsets (k_scan wrote offsets = cursor; the scatter advanced neither: it ranks in LDS)
             hipLaunchKernelGGL(k_sort_fine, dim3(bins, count), dim3(SORT_THREADS), 0, s, l2, w.sort_fine_bits, bins, w.nbuckets);
         } else if (w.sort_wgs) {
-            const uint64_t total = b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
+            const uint64_t total = sm ? b.n : b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
             hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
             dim3 gc = grid_for(w.nbuckets, 256);
             gc.y = count;
