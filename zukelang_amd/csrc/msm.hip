@@ -983,7 +983,10 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
         // every workgroup zeroes and flushes nbuckets counters: give it >= 4 pairs per counter to amortise that
         uint64_t wgs = maxN / (4 * (uint64_t)w.nbuckets);
         if (wgs > 256) wgs = 256;
-        static const uint64_t min_wgs = getenv("ZK_SORT_MIN_WGS") ? (uint64_t)atoll(getenv("ZK_SORT_MIN_WGS")) : 64;      // tuning knob
+        // tuning knob.  With scalar-major passes 8 workgroups already beat the global atomics (2^16: 37.3 -> 38.7-39.4 M constraints/s, the
+        // sort 0.61 -> 0.45 ms per proof; below 8 -- pools of 2^14 constraints -- the global path wins: 23.6 M against 22.3-22.6); it was 64
+        // with window-major passes
+        static const uint64_t min_wgs = getenv("ZK_SORT_MIN_WGS") ? (uint64_t)atoll(getenv("ZK_SORT_MIN_WGS")) : 8;
         if (wgs >= min_wgs) {                               // below that too few workgroups: the global-atomic path is cheaper
             w.sort_wgs = (uint32_t)wgs;
             ZKCHK(w.wgcount.alloc(4 * (size_t)w.nbuckets * wgs));
