@@ -16,7 +16,7 @@ PREFIX = [   # kernel name prefix -> bench.py family, per-proof kernels only (fi
     ("k_msm_fixup", "msm_reduce"), ("k_msm_digit_", "msm_reduce"), ("k_msm_final", "msm_reduce"),
     ("k_proof_to_bytes", "proof_to_bytes"), ("k_groth16_scalars", "groth16_scalars"),
     ("k_ntt_", "ntt"), ("k_tree_levels_fused", "ntt"),
-    ("k_spmv", "fr_pointwise"), ("k_check_r1cs", "fr_pointwise"), ("k_fr_to_mont_flag2", "fr_pointwise"), ("k_scale_pad", "fr_pointwise"), ("k_reverse_pad", "fr_pointwise"),
+    ("k_spmv", "fr_pointwise"), ("k_check_r1cs", "fr_pointwise"), ("k_fr_to_mont_flag2", "fr_pointwise"), ("k_scale_pad", "fr_pointwise"), ("k_reverse_pad", "fr_pointwise"), ("k_lag_", "fr_pointwise"),
 ]
 
 
