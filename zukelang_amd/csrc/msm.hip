@@ -619,7 +619,6 @@ struct DigitPlan {
 // 16 points per digit value: every lane sums cnt/16 buckets serially, then a 4-level tree.  (One value per 64-point
 // workgroup -- 2-4 buckets per lane, 6 levels -- finishes sooner but keeps four times as many waves busy for two thirds
 // of that time; with a dozen proofs in flight SIMD time is what counts.)  NT threads hold NT / lanes points.
-static constexpr uint32_t DS_GROUP = 16;
 // ... G2 (lane pairs: an addition is ~27 us on a lone wave against ~13 us in G1) takes 32 points per digit value: 4-8 serial
 // additions + 5 tree levels instead of 8-16 + 4, so the mixed-curve launch does not wait for the G2 chain twice as long
 // WIDE (windows above 16 bits: a digit value sums 513-2048 buckets): 64 points per value for both curves, i.e. 8-32 serial
