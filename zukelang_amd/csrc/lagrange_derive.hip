@@ -220,35 +220,42 @@ template <class T> __global__ void k_raw_to_aff(uint8_t* __restrict__ dst, const
 
 // ---- one radix-2 stage over the whole array (independent blocks of 2h points): forward = DIF (natural -> bit-reversed),
 // inverse = DIT (bit-reversed -> natural, unscaled) -- the conventions of ntt.hip, so the Fr tables line up.  tw[h + j] = w_2h^(+-j).
+// Two waves per SIMD for G1 (256 registers: 16-122 spilled ones cost less than the second wave brings -- 2^20: 44.4 -> 41.6 s for a key's three
+// sets); the lane-pair G2 form needs 340-400 registers and spills hundreds at 256: one wave per SIMD there.
 template <class T, bool INVERSE>
-__global__ __launch_bounds__(128) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t b0, uint64_t pairs, uint8_t* __restrict__ scratch) {
+__global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : 1)) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t b0, uint64_t pairs, uint8_t* __restrict__ scratch) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, b = b0 + loc;      // a slab of butterflies per launch
     if (b >= pairs) return;
     uint8_t* tab = scratch + (uint64_t)16 * XB * loc;
     const uint64_t h = (uint64_t)1 << log_h, j = b & (h - 1), e = ((b >> log_h) << (log_h + 1)) | j;
-    Xyzz<T> u = xyzz_load_raw<T>(pts + XB * e), v = xyzz_load_raw<T>(pts + XB * (e + h));
     const uint32_t* w = tw + 8 * (h + j);
+    // nothing but the multiplicand stays live across the scalar multiplication (a second point in registers there costs hundreds of spills)
     if (INVERSE) {
+        Xyzz<T> v = xyzz_load_raw<T>(pts + XB * (e + h));
         if (log_h) v = xyzz_mul_scalar_endo(v, w, tab);      // span 2: the twiddle is 1 (wave-uniform test)
+        Xyzz<T> u = xyzz_load_raw<T>(pts + XB * e);
         Xyzz<T> x = u;
         xyzz_add_impl(x, v);
+        xyzz_store_raw<T>(pts + XB * e, x);
         v.y = neg_coord(v.y);
         xyzz_add_impl(u, v);
-        xyzz_store_raw<T>(pts + XB * e, x);
         xyzz_store_raw<T>(pts + XB * (e + h), u);
     } else {
-        Xyzz<T> x = u;
-        xyzz_add_impl(x, v);
+        Xyzz<T> u = xyzz_load_raw<T>(pts + XB * e), v = xyzz_load_raw<T>(pts + XB * (e + h));
+        {
+            Xyzz<T> x = u;
+            xyzz_add_impl(x, v);
+            xyzz_store_raw<T>(pts + XB * e, x);
+        }
         v.y = neg_coord(v.y);
         xyzz_add_impl(u, v);                                // u - v
         if (log_h) u = xyzz_mul_scalar_endo(u, w, tab);
-        xyzz_store_raw<T>(pts + XB * e, x);
         xyzz_store_raw<T>(pts + XB * (e + h), u);
     }
 }
 // pts[i] <- tab[i] * pts[i]
-template <class T> __global__ __launch_bounds__(128) void k_g_tabmul(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tab, uint64_t i0, uint64_t total, uint8_t* __restrict__ scratch) {
+template <class T> __global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : 1)) void k_g_tabmul(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tab, uint64_t i0, uint64_t total, uint8_t* __restrict__ scratch) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, i = i0 + loc;
     if (i >= total) return;
