@@ -544,7 +544,7 @@ template <class T> FF_INLINE void fixup_body(const TailJob& job) {
     }
     xyzz_store_raw<T>(buckets + (uint64_t)XB * kb, acc);
 }
-__global__ __launch_bounds__(128) void k_msm_fixup(TailJobs jobs) {
+__global__ __launch_bounds__(128, 2) void k_msm_fixup(TailJobs jobs) {
     if (blockIdx.z < jobs.n1) fixup_body<Fp>(jobs.j[blockIdx.z]);
     else fixup_body<Fp2H>(jobs.j[blockIdx.z]);
 }
@@ -597,7 +597,7 @@ template <class T> FF_INLINE void fixup_big_body(const TailJob& job, uint32_t (*
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k_msm_fixup_big(TailJobs jobs) {
+__global__ __launch_bounds__(256, 2) void k_msm_fixup_big(TailJobs jobs) {
     __shared__ uint32_t lds[LANE_POINT_WORDS][256];
     if (blockIdx.z < jobs.n1) fixup_big_body<Fp>(jobs.j[blockIdx.z], lds);
     else fixup_big_body<Fp2H>(jobs.j[blockIdx.z], lds);
