@@ -215,6 +215,10 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
  * n .. 2n-2 in the exponent (plus [Z(s)] = <si, Z>, once), so that h enters its multi-scalar product through VALUES; v(s), w(s) never needed
  * coefficient vectors (they come from the per-variable pools).  Once per key; proofs byte-identical. */
 int zk_pinocchio_pk_derive_lagrange(uint64_t handle);
+/* A resident base pool of the key as uncompressed points, in pool order (out == NULL: only *count).  Pools 0..5 are the G1 products
+ * vv|vt, yy|yt, vav|vavt, yay|yayt, bvwy|vbt|wbt|ybt and the h pool (si | v_all | w_all, or after zk_pinocchio_pk_derive_lagrange
+ * [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all); 6..7 the G2 products ww|wt and waw|wawt (pinocchio.ml:37-60). */
+int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t capacity_points, size_t* count);
 int zk_pinocchio_pk_free(uint64_t handle);
 int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32],
                        const uint8_t dy[32], uint8_t proof[960]);

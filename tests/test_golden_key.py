@@ -1,0 +1,103 @@
+"""tests/golden/readme_groth16_key.json -- the README circuit's Groth16 proving key, its Lagrange form and a proof, computed from first
+principles with Python integers (tests/golden/make_readme_keys.py) -- against the three implementations that must reproduce it:
+the C oracle (setup, literal prove, trapdoor prove), the multi-threaded CPU context prover, and on the GPU the keygen, the on-device
+derivation of the Lagrange form (which never sees tau) and the prover on every key form."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import r1cs as RC
+
+FIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_groth16_key.json")))
+cat = lambda xs: b"".join(bytes.fromhex(x) for x in xs)
+PK1, PK2, LG1, LG2 = cat(FIX["pk_g1"]), cat(FIX["pk_g2"]), cat(FIX["lagrange_g1"]), cat(FIX["lagrange_g2"])
+PROOF = tuple(bytes.fromhex(FIX["proof"][k]) for k in "abc")
+TOX = [int(FIX["toxic"][k], 16) for k in ("alpha", "beta", "gamma", "delta", "tau")]
+R_, S_ = int(FIX["r"], 16), int(FIX["s"], 16)
+W = [int(x, 16) for x in FIX["witness"]]
+frb = P.fr_to_bytes
+frs = lambda xs: b"".join(frb(x) for x in xs)
+
+
+def _circuit():
+    cs, w = RC.readme_circuit(3)
+    assert w == W and list(cs.mid) == FIX["mid"]
+    return cs, [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+
+
+def test_oracle_reproduces_the_fixture():
+    cs, csr = _circuit()
+    q = O.QAP(cs.n, cs.m, *csr)
+    pk1, pk2, _, _ = q.groth16_setup(frs(TOX), cs.mid)
+    assert pk1 == PK1 and pk2 == PK2
+    rc, a, b, c = q.groth16_prove(PK1, PK2, cs.mid, frs(W), frb(R_), frb(S_), 1)          # literal groth16.ml:116-161
+    assert rc == 0 and (a, b, c) == PROOF
+    assert O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(W), frs(TOX), frb(R_), frb(S_)) == PROOF
+    fp = O.FastGroth16(cs.n, cs.m, *csr, cs.mid, LG1, LG2, 2)                              # Pippenger + NTT over the Lagrange form
+    rc, a, b, c = fp.prove(frs(W), frb(R_), frb(S_))
+    fp.close()
+    assert rc == 0 and (a, b, c) == PROOF
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_fixture():
+    from zukelang_amd.groth16 import Groth16, PKey
+    cs, _ = _circuit()
+    it = iter(TOX)
+    pk, _vk = Groth16.keygen(lambda: next(it), cs, lagrange=True)
+    assert bytes(pk.g1) == PK1 and bytes(pk.g2) == PK2 and bytes(pk.lag_g1) == LG1 and bytes(pk.lag_g2) == LG2
+    # from the FIXTURE's bytes (not this library's keygen): as uploaded, derived on the device, uploaded in Lagrange form
+    key = PKey(np.frombuffer(PK1, dtype=np.uint8), np.frombuffer(PK2, dtype=np.uint8), np.frombuffer(LG1, dtype=np.uint8), np.frombuffer(LG2, dtype=np.uint8))
+    pr = Groth16(cs, key)
+    p = pr.prove_rs(W, R_, S_)
+    assert (p.a, p.b, p.c) == PROOF
+    pr.derive_lagrange()
+    assert bytes(pr.pool_points(1)) == LG1 and bytes(pr.pool_points(2)) == LG2
+    p = pr.prove_rs(W, R_, S_)
+    assert (p.a, p.b, p.c) == PROOF
+    pr.close()
+    pl = Groth16(cs, key, lagrange=True)
+    p = pl.prove_rs(W, R_, S_)
+    assert (p.a, p.b, p.c) == PROOF
+    pl.close()
+
+
+# ---------------------------------------------------------------- Pinocchio Protocol 2 (tests/golden/make_readme_pinocchio.py)
+PFIX = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "readme_pinocchio_key.json")))
+PPK1, PPK2, PDER = cat(PFIX["pk_g1"]), cat(PFIX["pk_g2"]), cat(PFIX["derived_h_pool_g1"])
+PPROOF = bytes.fromhex(PFIX["proof"])
+PTOX = [int(x, 16) for x in PFIX["toxic"]]
+PDEL = [int(x, 16) for x in PFIX["deltas"]]
+
+
+def test_oracle_reproduces_the_pinocchio_fixture():
+    cs, csr = _circuit()
+    assert [int(x, 16) for x in PFIX["witness"]] == W
+    ex = O.pinocchio_keygen_exponents(None, cs.n, cs.m, *csr, cs.mid, frs(PTOX), False)
+    assert O.points_of_exponents_g1(ex[0]) == PPK1 and O.points_of_exponents_g2(ex[1]) == PPK2
+    q = O.QAP(cs.n, cs.m, *csr)
+    rc, proof = O.pinocchio_prove(q, PPK1, PPK2, cs.mid, frs(W), *(frb(d) for d in PDEL))      # literal ZKCompute.f
+    assert rc == 0 and proof == PPROOF
+    assert O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(W), frs(PTOX), *(frb(d) for d in PDEL)) == PPROOF
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_the_pinocchio_fixture():
+    from zukelang_amd import pinocchio as PIN
+    cs, _ = _circuit()
+    it = iter(PTOX)
+    pk, _vk = PIN.ZK.keygen(lambda: next(it), cs)
+    assert bytes(pk.g1) == PPK1 and bytes(pk.g2) == PPK2
+    key = PIN.PKey(np.frombuffer(PPK1, dtype=np.uint8), np.frombuffer(PPK2, dtype=np.uint8))       # the FIXTURE's bytes
+    pp = PIN.ZK(cs, key)
+    assert pp.prove_with(W, *PDEL).to_bytes() == PPROOF
+    n, m = cs.n, cs.m
+    assert bytes(pp.pool_points(5)) == PPK1[96 * 15:96 * (15 + n + 1 + 2 * m)]                      # si | v_all | w_all as uploaded
+    pp.derive_lagrange()
+    assert bytes(pp.pool_points(5)) == PDER                                                        # [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all, derived without s
+    assert pp.prove_with(W, *PDEL).to_bytes() == PPROOF
+    pp.close()

@@ -18,7 +18,7 @@ EXPORTS = [
     "zk_groth16_pk_upload_sharded", "zk_groth16_prove_partial", "zk_groth16_prove_partial_async", "zk_groth16_prove_partial_wait", "zk_groth16_combine",
     "zk_groth16_pool_layout", "zk_groth16_scalars_async", "zk_groth16_scalars_wait", "zk_groth16_msm_partial_async",
     "zk_device_malloc", "zk_device_free", "zk_device_memcpy",
-    "zk_pinocchio_pk_upload", "zk_pinocchio_pk_derive_lagrange", "zk_pinocchio_pk_free", "zk_pinocchio_prove",
+    "zk_pinocchio_pk_upload", "zk_pinocchio_pk_derive_lagrange", "zk_pinocchio_pool_points", "zk_pinocchio_pk_free", "zk_pinocchio_prove",
     "zk_pinocchio_reserve_slots", "zk_pinocchio_set_witness", "zk_pinocchio_prove_async", "zk_pinocchio_prove_wait",
     "zk_pairing_product", "zk_pairing_check", "zk_groth16_verify", "zk_pinocchio_verify",
     "zk_profile_enable", "zk_profile_reset", "zk_profile_get", "zk_profile_names", "zk_sync",

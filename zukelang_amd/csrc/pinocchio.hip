@@ -220,6 +220,22 @@ int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
     k.lagrange = true;
     return ZK_OK;
 }
+int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t capacity_points, size_t* count) {
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    if (pool < 0 || pool >= PIN_G1 + PIN_G2) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: pool 0..5 (G1) or 6..7 (G2)");
+    const MsmBases& b = pool < PIN_G1 ? kp->g1[pool] : kp->g2[pool - PIN_G1];
+    if (count) *count = b.n;
+    if (!out) return ZK_OK;
+    if (capacity_points < b.n) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: buffer too small");
+    Ctx& c = ctx();
+    DevBuf bytes;
+    ZKCHK(bytes.alloc(aff_bytes(b.curve) * b.n));
+    ZKCHK(points_affine_to_bytes(b.curve, bytes.p, b.table.p, b.n, c.stream));
+    HIPCHK(hipMemcpyAsync(out, bytes.p, aff_bytes(b.curve) * b.n, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return ZK_OK;
+}
 int zk_pinocchio_pk_free(uint64_t handle) {
     auto it = g_pin.find(handle);
     if (it == g_pin.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Pinocchio key handle");

@@ -105,6 +105,14 @@ class _Prover:
         device, once); afterwards every proof skips the basis conversion.  Proof bytes do not change."""
         _lib.check(_lib.lib().zk_pinocchio_pk_derive_lagrange(self.handle))
 
+    def pool_points(self, pool):
+        """A resident base pool as uncompressed bytes, in pool order: 0..5 the G1 products (5 = the h pool), 6..7 the G2 products."""
+        cnt = C.c_size_t()
+        _lib.check(_lib.lib().zk_pinocchio_pool_points(self.handle, C.c_int(pool), None, C.c_size_t(0), C.byref(cnt)))
+        out = np.zeros(cnt.value * (96 if pool < 6 else 192), dtype=np.uint8)
+        _lib.check(_lib.lib().zk_pinocchio_pool_points(self.handle, C.c_int(pool), _p(out), C.c_size_t(cnt.value), C.byref(cnt)))
+        return out
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             _lib.lib().zk_pinocchio_pk_free(self.handle)
