@@ -83,3 +83,24 @@ def test_pinocchio_key_records_round_trip():
     assert list(wire.loads(js)) == ["one", "one2", "av", "aw", "ay", "gm2", "bgm", "bgm2", "yt", "vv_io", "ww_io", "yy_io"]
     vk2, ios2 = wire.pinocchio_vkey_of_json(js)
     assert ios2 == ios and bytes(vk2.g1) == v1 and bytes(vk2.g2) == v2
+
+
+def test_writer_reproduces_the_golden_json_bytes():
+    """tests/golden/readme_groth16_wire.hex: the README circuit's pkey and proof as JSON text from an independent writer
+    (tests/golden/make_readme_wire.py) over the first-principles key of readme_groth16_key.json -- exact bytes, both directions."""
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fix = json.load(open(os.path.join(here, "readme_groth16_key.json")))
+    pkey_js, proof_js = (bytes.fromhex(line) for line in open(os.path.join(here, "readme_groth16_wire.hex")).read().split())
+    from zukelang_amd.groth16 import PKey
+    cat = lambda xs: b"".join(bytes.fromhex(x) for x in xs)
+    pk = PKey(np.frombuffer(cat(fix["pk_g1"]), dtype=np.uint8), np.frombuffer(cat(fix["pk_g2"]), dtype=np.uint8))
+    mids = [("c", 4), ("c", 5), ("input", 3)]
+    assert wire.groth16_pkey_to_json(pk, 3, mids) == pkey_js
+    proof = Proof(*(bytes.fromhex(fix["proof"][k]) for k in "abc"))
+    assert wire.groth16_proof_to_json(proof) == proof_js
+    pk2, mids2 = wire.groth16_pkey_of_json(pkey_js)
+    assert mids2 == mids and bytes(pk2.g1) == bytes(pk.g1) and bytes(pk2.g2) == bytes(pk.g2)
+    back = wire.groth16_proof_of_json(proof_js)
+    assert (back.a, back.b, back.c) == (proof.a, proof.b, proof.c)
