@@ -345,10 +345,15 @@ __global__ void k_sort_colscan(SortJobs jobs, uint32_t nb, uint32_t nwg) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     uint32_t run = 0;
-    for (uint32_t wg = 0; wg < nwg; wg++) {
-        const uint32_t x = cnt[(uint64_t)wg * nb + b];
-        cnt[(uint64_t)wg * nb + b] = run;
-        run += x;
+    for (uint32_t wg0 = 0; wg0 < nwg; wg0 += 8) {          // eight independent loads in flight per lane: the walk is latency, not bandwidth
+        uint32_t x[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) x[j] = wg0 + j < nwg ? cnt[(uint64_t)(wg0 + j) * nb + b] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            if (wg0 + j < nwg) cnt[(uint64_t)(wg0 + j) * nb + b] = run;
+            run += x[j];
+        }
     }
     totals[b] = run;
 }
