@@ -448,11 +448,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint3
     const uint32_t lo = coff[bin], hi = coff[bin + 1];
     for (uint32_t f = t; f < nf; f += SORT_THREADS) cnt[f] = 0;
     __syncthreads();
+    // (both passes fetch the record of the NEXT round before ranking the current one: a round is otherwise one HBM round trip long)
+    uint32_t kn = lo + t < hi ? rec[lo + t].x : 0;
     for (uint32_t base = lo; base < hi; base += SORT_THREADS) {          // whole waves keep the ballots of wave_aggregated_add valid
         const uint32_t i = base + t;
         const bool ok = i < hi;
-        const uint32_t key = ok ? rec[i].x & fm : 0;
-        (void)wave_aggregated_add(cnt, ok, key);
+        const uint32_t key = kn & fm;
+        const uint32_t in = i + SORT_THREADS;
+        kn = in < hi ? rec[in].x : 0;
+        (void)wave_aggregated_add(cnt, ok, ok ? key : 0);
     }
     __syncthreads();
     // exclusive scan of cnt[0..nf): every thread owns nf / SORT_THREADS consecutive counters (1..4)
@@ -479,11 +483,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint3
     }
     if (bin == nbins - 1 && t == 0) offsets[nb] = hi;
     __syncthreads();
+    uint2 rn = lo + t < hi ? rec[lo + t] : make_uint2(0, 0);
     for (uint32_t base = lo; base < hi; base += SORT_THREADS) {
         const uint32_t i = base + t;
         const bool ok = i < hi;
-        uint2 r = make_uint2(0, 0);
-        if (ok) r = rec[i];
+        const uint2 r = rn;
+        const uint32_t in = i + SORT_THREADS;
+        rn = in < hi ? rec[in] : make_uint2(0, 0);
         const uint32_t pos = wave_aggregated_add(cnt, ok, r.x & fm);
         if (ok) sorted[pos] = r.y;
     }
