@@ -677,22 +677,45 @@ template <bool WIDE> __global__ __launch_bounds__(DS_THREADS, WIDE ? 2 : 1) void
 static constexpr uint32_t DW_POINTS = 256;
 FF_INLINE uint32_t* lane_limbs(Fp& a) { return a.v; }
 FF_INLINE uint32_t* lane_limbs(Fp2H& a) { return a.v.v; }
-template <class T, int NT> FF_INLINE void digit_weight_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
+FF_INLINE uint32_t dw_groups(uint32_t cnt) { return (cnt + DW_POINTS - 1) / DW_POINTS; }
+// acc += k * tg, out of line: the one-off group term must not cost the round loop of the kernel its registers
+template <class T> __device__ __noinline__ void dw_group_term(Xyzz<T>* acc, const Xyzz<T>* tg, uint32_t k) {
+    const Xyzz<T> m = xyzz_mul_u32_inl(*tg, k);
+    xyzz_add_impl(*acc, m);
+}
+// More than DW_POINTS digit values per half (windows above 16 bits): the values go in GROUPS of DW_POINTS, one workgroup each.  With
+// d = DW_POINTS g + j:  sum_d d S[d] = sum_g ( sum_j j S[g][j]  +  DW_POINTS g * sum_j S[g][j] ) -- the first term is the scan form on the
+// group, the plain sum T_g is point 0 of the suffix scan (kept aside in LDS before it is dropped), and DW_POINTS g * T_g costs 8-11 doublings
+// on one point after the tree.  k_msm_final adds the groups' contributions.  (The first version of the wide path multiplied every S[d] by d
+// with a 10-bit double-and-add: 265 spilled registers, 2.5 ms of a 2^20 proof's latency.)
+template <class T, int NT, bool GROUPED> FF_INLINE void digit_weight_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT], uint32_t (*keep)[4]) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint8_t* __restrict__ S = job.red;
     uint8_t* __restrict__ V = job.wsum;
     constexpr uint32_t LP = Lanes<T>::N;
-    const uint32_t k = blockIdx.x, win = blockIdx.y, t = threadIdx.x, pt = t / LP;
+    const uint32_t g0 = dw_groups(p.nd0), g1 = dw_groups(p.nd1);
+    const uint32_t k = blockIdx.x < g0 ? 0u : 1u, grp = k ? blockIdx.x - g0 : blockIdx.x;
+    const uint32_t win = blockIdx.y, t = threadIdx.x, pt = t / LP;
     const uint32_t cnt = k == 0 ? p.nd0 : p.nd1;
     const uint8_t* base = S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + (k == 0 ? 0 : p.nd0));
     const bool mine = pt < DW_POINTS;                       // G1 jobs use half of the workgroup's lanes; everyone keeps the barriers
+    const uint32_t d = grp * DW_POINTS + pt;                // this point's digit value
     Xyzz<T> acc = xyzz_inf<T>();
-    if (mine && pt >= 1 && pt < cnt) acc = xyzz_load_raw<T>(base + (uint64_t)XB * pt);
-    // rounds 0..7: suffix scan, partner = pt + 2^r;  round 8: drop point 0 (weight 0);  rounds 8..15: tree, partner = pt + 128 >> (r-8)
+    if (mine && d >= 1 && d < cnt) acc = xyzz_load_raw<T>(base + (uint64_t)XB * d);
+    // rounds 0..7: suffix scan, partner = pt + 2^r;  round 8: drop point 0 (weight 0 inside the group);  rounds 8..15: tree, partner = pt + 128 >> (r-8)
     for (uint32_t r = 0; r < 16; r++) {
         const bool scan = r < 8;
         const uint32_t step = scan ? (1u << r) : (DW_POINTS / 2) >> (r - 8);
-        if (r == 8 && pt == 0) acc = xyzz_inf<T>();
+        if (r == 8 && pt == 0) {
+            if (GROUPED && grp) {                           // T_g = the sum of the whole group: needed with the weight DW_POINTS * grp
+#pragma unroll
+                for (int l = 0; l < FPL; l++) {
+                    keep[l][t] = lane_limbs(acc.x)[l]; keep[FPL + l][t] = lane_limbs(acc.y)[l];
+                    keep[2 * FPL + l][t] = lane_limbs(acc.zz)[l]; keep[3 * FPL + l][t] = lane_limbs(acc.zzz)[l];
+                }
+            }
+            acc = xyzz_inf<T>();
+        }
         __syncthreads();
         if (mine) {
 #pragma unroll
@@ -714,41 +737,29 @@ template <class T, int NT> FF_INLINE void digit_weight_body(const TailJob& job, 
             xyzz_add_impl(acc, q);
         }
     }
-    if (t < LP) xyzz_store_raw<T>(V + (uint64_t)XB * (2 * win + k), acc);
-}
-__global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
-    __shared__ uint32_t lds[LANE_POINT_WORDS][DW_THREADS];
-    if (blockIdx.z < jobs.n1) digit_weight_body<Fp, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
-    else digit_weight_body<Fp2H, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
-}
-// windows above 16 bits (config 3's sweep): more than DW_POINTS digit values per half -- every point multiplies its digit sums by
-// their weights (double-and-add) and sums them before the tree.  Not on the default path (c <= 16).
-template <class T, int NT> FF_INLINE void digit_weight_wide_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
-    constexpr int XB = RawLayout<T>::XYZZ;
-    const uint8_t* __restrict__ S = job.red;
-    uint8_t* __restrict__ V = job.wsum;
-    constexpr uint32_t LP = Lanes<T>::N, NP = NT / LP;
-    const uint32_t k = blockIdx.x, win = blockIdx.y, pt = threadIdx.x / LP;
-    const uint32_t cnt = k == 0 ? p.nd0 : p.nd1;
-    const uint8_t* base = S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + (k == 0 ? 0 : p.nd0));
-    Xyzz<T> acc = xyzz_inf<T>();
-    for (uint32_t d = pt; d < cnt; d += NP) {
-        if (!d) continue;
-        const Xyzz<T> q = xyzz_load_raw<T>(base + (uint64_t)XB * d);
-        const Xyzz<T> m = xyzz_mul_u32_inl(q, d);
-        xyzz_add_impl(acc, m);
+    if (t < LP) {
+        if (GROUPED && grp) {
+            Xyzz<T> tg;
+#pragma unroll
+            for (int l = 0; l < FPL; l++) {
+                lane_limbs(tg.x)[l] = keep[l][t]; lane_limbs(tg.y)[l] = keep[FPL + l][t];
+                lane_limbs(tg.zz)[l] = keep[2 * FPL + l][t]; lane_limbs(tg.zzz)[l] = keep[3 * FPL + l][t];
+            }
+            dw_group_term<T>(&acc, &tg, grp * DW_POINTS);
+        }
+        xyzz_store_raw<T>(V + (uint64_t)XB * ((uint64_t)win * (g0 + g1) + blockIdx.x), acc);
     }
-    block_tree_sum<T, NT>(acc, lds);
-    if (threadIdx.x < LP) xyzz_store_raw<T>(V + (uint64_t)XB * (2 * win + k), acc);
 }
-__global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight_wide(TailJobs jobs, DigitPlan p) {
+// GROUPED = false: at most DW_POINTS digit values per half (windows up to 16 bits, the default path): no group term is compiled in
+template <bool GROUPED> __global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
     __shared__ uint32_t lds[LANE_POINT_WORDS][DW_THREADS];
-    if (blockIdx.z < jobs.n1) digit_weight_wide_body<Fp, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
-    else digit_weight_wide_body<Fp2H, DW_THREADS>(jobs.j[blockIdx.z], p, lds);
+    __shared__ uint32_t keep[LANE_POINT_WORDS][4];          // T_g of the group: the limbs of point 0 (one lane, or a lane pair)
+    if (blockIdx.z < jobs.n1) digit_weight_body<Fp, DW_THREADS, GROUPED>(jobs.j[blockIdx.z], p, lds, keep);
+    else digit_weight_body<Fp2H, DW_THREADS, GROUPED>(jobs.j[blockIdx.z], p, lds, keep);
 }
 // W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one point).
 // The result leaves in the DENSE, fully reduced layout (it is an output of the library).
-template <class T> FF_INLINE void final_body(const TailJob& job, uint32_t nw, uint32_t c, uint32_t lb) {
+template <class T> FF_INLINE void final_body(const TailJob& job, uint32_t nw, uint32_t c, uint32_t lb, uint32_t g0, uint32_t g1) {
     constexpr int XB = RawLayout<T>::XYZZ;
     if (threadIdx.x >= Lanes<T>::N) return;
     const uint8_t* __restrict__ V = job.wsum;
@@ -757,17 +768,24 @@ template <class T> FF_INLINE void final_body(const TailJob& job, uint32_t nw, ui
     for (uint32_t j = nw; j-- > 0;) {
         if (j != nw - 1)
             for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl_impl(acc);
-        Xyzz<T> hi = xyzz_load_raw<T>(V + (uint64_t)XB * (2 * j + 1));
+        const uint8_t* Vw = V + (uint64_t)XB * ((uint64_t)j * (g0 + g1));      // the window's group sums: g0 of the low digit, g1 of the high one
+        Xyzz<T> hi = xyzz_load_raw<T>(Vw + (uint64_t)XB * g0);
+        for (uint32_t g = 1; g < g1; g++) {
+            const Xyzz<T> q = xyzz_load_raw<T>(Vw + (uint64_t)XB * (g0 + g));
+            xyzz_add_impl(hi, q);
+        }
         for (uint32_t k = 0; k < lb; k++) hi = xyzz_dbl_impl(hi);
         xyzz_add_impl(acc, hi);
-        const Xyzz<T> lo = xyzz_load_raw<T>(V + (uint64_t)XB * (2 * j));
-        xyzz_add_impl(acc, lo);
+        for (uint32_t g = 0; g < g0; g++) {
+            const Xyzz<T> lo = xyzz_load_raw<T>(Vw + (uint64_t)XB * g);
+            xyzz_add_impl(acc, lo);
+        }
     }
     xyzz_store<T>(out, acc);
 }
-__global__ __launch_bounds__(64) void k_msm_final(TailJobs jobs, uint32_t nw, uint32_t c, uint32_t lb) {
-    if (blockIdx.z < jobs.n1) final_body<Fp>(jobs.j[blockIdx.z], nw, c, lb);
-    else final_body<Fp2H>(jobs.j[blockIdx.z], nw, c, lb);
+__global__ __launch_bounds__(64) void k_msm_final(TailJobs jobs, uint32_t nw, uint32_t c, uint32_t lb, uint32_t g0, uint32_t g1) {
+    if (blockIdx.z < jobs.n1) final_body<Fp>(jobs.j[blockIdx.z], nw, c, lb, g0, g1);
+    else final_body<Fp2H>(jobs.j[blockIdx.z], nw, c, lb, g0, g1);
 }
 template <class F> __global__ void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
     constexpr int XB = FieldOps<F>::WORDS * 16;
@@ -1026,7 +1044,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     ZKCHK(w.worklist.alloc(4 * (size_t)(w.nbuckets + 1)));
     const DigitPlan dp = digit_plan(b.c);
     ZKCHK(w.red.alloc(XB * (size_t)(dp.nd0 + dp.nd1) * (b.precomp ? 1 : b.nw)));
-    ZKCHK(w.wsum.alloc(XB * 2 * (b.precomp ? 1 : b.nw)));
+    ZKCHK(w.wsum.alloc(XB * (size_t)((dp.nd0 + DW_POINTS - 1) / DW_POINTS + (dp.nd1 + DW_POINTS - 1) / DW_POINTS) * (b.precomp ? 1 : b.nw)));      // one point per group of digit values and window
     return ZK_OK;
 }
 
@@ -1174,6 +1192,7 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
         hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
     }
     const DigitPlan dp = digit_plan(b.c);
+    const uint32_t dwg0 = (dp.nd0 + DW_POINTS - 1) / DW_POINTS, dwg1 = (dp.nd1 + DW_POINTS - 1) / DW_POINTS;      // groups of digit values per half
     // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 2 values; G1: 8)
     const bool wide = dp.nd0 > DW_POINTS;
     const uint32_t per_wg = wide ? (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, true>::N : DS_THREADS / DsGroup<Fp, true>::N)
@@ -1186,12 +1205,12 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     }
     {
         ScopedTimer t3("msm_reduce:digit_weight", s);
-        if (dp.nd0 <= DW_POINTS && dp.nd1 <= DW_POINTS) hipLaunchKernelGGL(k_msm_digit_weight, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
-        else hipLaunchKernelGGL(k_msm_digit_weight_wide, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
+        if (dwg0 + dwg1 == 2) hipLaunchKernelGGL(k_msm_digit_weight<false>, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
+        else hipLaunchKernelGGL(k_msm_digit_weight<true>, dim3(dwg0 + dwg1, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
     }
     {
         ScopedTimer t4("msm_reduce:final", s);
-        hipLaunchKernelGGL(k_msm_final, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb);
+        hipLaunchKernelGGL(k_msm_final, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb, dwg0, dwg1);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
