@@ -106,3 +106,17 @@ def test_shard_range_is_the_rule_the_host_side_mirrors():
                     assert lib.zk_groth16_shard_range(C.c_uint64(size), C.c_uint64(heavy), rank, world, C.byref(lo), C.byref(hi)) == 0
                     assert (lo.value, hi.value) == shard_bounds(size, rank, world, heavy)
     assert lib.zk_groth16_shard_range(C.c_uint64(10), C.c_uint64(0), 2, 2, C.byref(lo), C.byref(hi)) == -1
+
+
+def test_a_plain_c99_host_binds_the_abi(tmp_path):
+    """include/zkmi355x.h is C (no C++-isms, no torch types): examples/c_host.c compiles with gcc -std=c99 -pedantic, links against the
+    library and runs its GPU-free calls."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.join(root, "zukelang_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_host.c"), "-o", exe, "-L" + libdir, "-lzkmi355x", "-Wl,-rpath," + libdir])
+    out = subprocess.check_output([exe])
+    assert out.startswith(b"c-host ok")
