@@ -101,3 +101,17 @@ def test_gpu_reproduces_the_pinocchio_fixture():
     assert bytes(pp.pool_points(5)) == PDER                                                        # [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all, derived without s
     assert pp.prove_with(W, *PDEL).to_bytes() == PPROOF
     pp.close()
+
+
+@pytest.mark.gpu
+def test_a_plain_c_host_proves_the_fixture(tmp_path):
+    """examples/c_prove.c: upload, prove, derive, read back, prove -- all through the C-ABI from C99, bytes against the fixture (no ctypes,
+    no Python in the loop: the process only starts the binary)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_prove")
+    libdir = os.path.join(root, "zukelang_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "examples"),
+                           os.path.join(root, "examples", "c_prove.c"), "-o", exe, "-L" + libdir, "-lzkmi355x", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith(b"c-prove ok"), (out.returncode, out.stdout, out.stderr)
