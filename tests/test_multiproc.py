@@ -27,12 +27,12 @@ def _run(mode, world, n):
     assert "MP-OK %s %d %d" % (mode, world, n) in res.stdout
 
 
-@pytest.mark.parametrize("world,n", [(2, 16), (3, 10)])
+@pytest.mark.parametrize("world,n", [(2, 16), (3, 10), (4, 12), (8, 12)])      # proof bytes independent of the number of ranks, up to a node's eight
 def test_point_sharded_sum_is_exact_gloo_cpu(world, n):
     _run("cpu", world, n)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n", [(2, 256), (3, 1000), (2, 1 << 17)])      # the last: a realistic slice (2^16 per rank, LDS sort path, c = 16)
+@pytest.mark.parametrize("world,n", [(2, 256), (3, 1000), (4, 512), (2, 1 << 17)])      # the last: a realistic slice (2^16 per rank, LDS sort path, c = 16)
 def test_point_sharded_prove_gpu(world, n):
     _run("gpu", world, n)
