@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE config 3: Groth16 at 2^20 constraints, Pippenger window-size sweep on one MI355X.
 Runs bench.py once per window size (ZK_MSM_WINDOW); every row passes bench.py's PARITY GATE (the last timed proof equals the
-oracle's trapdoor evaluation) or the row says FAILED.  Windows above 16 bits leave the LDS-resident counting sort (2^15
-bucket counters) for the global-atomic one.  Prints a table and writes gpurun_out/window_sweep.json.
+oracle's trapdoor evaluation) or the row says FAILED.  Windows above 16 bits (more than 2^15 bucket counters) run the two-level
+counting sort and the grouped digit weights.  Prints a table and writes gpurun_out/window_sweep.json.
 Usage: python scripts/window_sweep.py [log_n] [c ...]"""
 import json
 import os
