@@ -363,7 +363,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     return res
 
 
-def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
+def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight, peak_products=None):
     """BASELINE config 5: Pinocchio Protocol-2 ZK prove (pinocchio.ml:427-514), witness resident, proofs pipelined over slots."""
     from zukelang_amd import r1cs as RC, pinocchio as PIN
     n = 1 << log_n
@@ -388,17 +388,31 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
         for i in range(max(0, count - depth), count):
             last = prover.prove_wait(i % depth)
         return last, (count - 1) % len(ds)
+    fams = {}
+
     def measure():
         run(2 * depth)
         _lib.check(L.zk_sync())
+        # the accumulate launches are bracketed by HIP events on their own streams inside the timed region (level 1), as for Groth16
+        _lib.check(L.zk_profile_reset())
+        _lib.check(L.zk_profile_enable(0 if args.no_live_events else 1))
         t0 = time.perf_counter()
         proof, idx = run(nproofs)
         _lib.check(L.zk_sync())
         dt = time.perf_counter() - t0
+        _lib.check(L.zk_profile_enable(0))
+        fams["timed"] = collect_families(L, _lib, nproofs)
         t1 = time.perf_counter()
         for i in range(2):
             prover.prove_with(wb, *ds[i])      # the witness as 32-byte values: no Python conversion inside the latency
         lat = (time.perf_counter() - t1) / 2
+        _lib.check(L.zk_profile_reset())
+        _lib.check(L.zk_profile_enable(2))     # every kernel family un-overlapped: one proof at a time on one stream
+        for i in range(2):
+            prover.prove_with(wb, *ds[i])
+        fams["alone"] = collect_families(L, _lib, 2)
+        _lib.check(L.zk_profile_enable(0))
+        _lib.check(L.zk_profile_reset())
         parity = None
         if not args.no_parity_gate:
             O = oracle()
@@ -445,11 +459,16 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight):
                          "R1CS at n=%d; %.2f s; GPU proof of the sample byte-identical" % (ns, cdt)}
     m_mid = cs.n_mid
     alg = 5 * 128 * m_mid + 2 * 128 * cs.m + 2 * 128 * n + 2 * 224 * m_mid + 192 * n       # 1792 n B at m_mid = m = n
+    # scalar-point pairs per proof: five pools over I_mid (+ their appended single points), the h pool (n + 1 + 2m), two G2 pools over I_mid
+    pairs = {"g1": 4 * (m_mid + 1) + (m_mid + 3) + (n + 1 + 2 * cs.m), "g2": 2 * (m_mid + 1)}
+    roofs = roofline_objects(fams.get("timed", {}), nproofs, fams.get("alone", {}), 2, pairs, 1, 16, peak_products, None, "")
     return {"workload": "pinocchio_zk_prove (BASELINE config 5), iterated-cubic R1CS, key+circuit+witness resident in HBM", "log_n": log_n, "constraints": n,
             "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3, "timed_s": dt, "timed_proofs": nproofs,
             "proofs_in_flight": depth, "single_proof_latency_ms": lat * 1e3, "single_proof_note": "one at a time, witness handed over as a host buffer",
             "prove_algorithmic_bytes_per_constraint": alg / n, "prove_hbm_frac": alg / (dt / nproofs) / 1e9 / HBM_PEAK_GBS, "parity": parity,
-            "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "as_uploaded": as_uploaded, "cpu_baseline": cpu}
+            "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "as_uploaded": as_uploaded, "cpu_baseline": cpu,
+            "roofline_g1": roofs.get("g1"), "roofline_g2": roofs.get("g2"),      # the six G1 / two G2 accumulate launches of a proof, as for Groth16
+            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fams.get("alone", {}).items())}}
 
 
 def summarize(res, world, peak_products, traffic, lagrange):
@@ -548,7 +567,7 @@ def main():
             pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
             others.append(pub)
         if not args.no_pinocchio:
-            others.append(bench_pinocchio(args, L, _lib, 18, 48, 8))
+            others.append(bench_pinocchio(args, L, _lib, 18, 48, 8, peak.value))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
