@@ -3,15 +3,16 @@
 
 Workload = Groth16 prove of the synthetic iterated-cubic R1CS with the proving key, the circuit and
 the witness already resident in HBM.  A STEP = `--proofs-per-step` (16) consecutive proofs of the pipelined prover
-(`--inflight` proofs in flight, one HIP stream each; the pipeline is NOT drained between steps), so that the default
-20 steps are >= 0.5 s of timed GPU work.  N = 1: n = 2^16 constraints (BASELINE.json configs[1]) is the headline
-`value`; the same run then times the other single-GPU configurations (2^18, 2^20 = config 3's size, 2^22 =
-config 4's size on one GPU, and Pinocchio 2^18 = config 5) and reports them under `other_workloads`, each with its own
-parity check.  N > 1: proofs of n = 2^16 * N constraints (BASELINE config 4 = --log-n 19 at N = 8) whose three
-multi-scalar products are sharded by base points over the ranks (one process per GPU).  Proofs go in rounds: rank j runs
-the Fr stage of the proofs it owns, one all-to-all per scalar vector over RCCL hands every rank its slice of every
-proof's scalars, the 768-byte partial sums of a round travel in one all-gather (EC addition is not an RCCL reduction
-operator) and are added on the GPU; per-GPU work per proof is fixed => "weak" scaling.
+(`--inflight` proofs in flight, one HIP stream each; the pipeline is NOT drained between steps).
+N = 1: n = 2^20 constraints (BASELINE.json configs[2]: the largest configuration the metric names for ONE GPU) is the headline
+`value`; the same run then times the other single-GPU configurations (2^16 = configs[1], 2^18, 2^22 = config 4's size on one
+GPU, and Pinocchio 2^18 = config 5) and reports them under `other_workloads`, each with its own parity check.
+N > 1 (`python bench.py --gpus N` starts its own N ranks; under torch.distributed.run it is one of them): the SAME proof of
+2^log_n constraints, its three multi-scalar products sharded by base points over the ranks (one process per GPU) -- total work
+fixed => "strong" scaling; `--weak` makes it 2^log_n constraints PER GPU instead (BASELINE config 4 = --gpus 8 --log-n 19 --weak).
+Proofs go in rounds: rank j runs the Fr stage of the proofs it owns, one all-to-all per scalar vector over RCCL hands every rank
+its slice of every proof's scalars, the 768-byte partial sums of a round travel in one all-gather (EC addition is not an RCCL
+reduction operator) and are added on the GPU.
 
 PARITY GATE: after every timed region the proof of the LAST timed (r, s) is compared with the oracle's trapdoor
 evaluation (exact at any n; CPU, outside the timed region).  A mismatch aborts the run: no throughput is printed for
@@ -33,7 +34,55 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before torch / HIP initiali
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+
+
+MAX_RANKS_PER_DEVICE = 6      # a GPU box admits at most 6 processes on its card at once
+
+
+def visible_devices():
+    """Number of HIP devices the ranks will see, counted in a CHILD process: the launcher itself must stay free of any GPU state."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 else 0
+    except Exception:
+        return 0
+
+
+def launch_ranks(n, argv):
+    """Starts `n` ranks of this script (one process per GPU, torch.distributed.run on 127.0.0.1), relays rank 0's JSON line and returns the
+    children's exit code.  Fewer visible devices than ranks: the ranks share devices and exchange over gloo (a REHEARSAL of the code path --
+    the line says so in config.rehearsal_ranks_share_gpus); no device at all, or more than 6 ranks per device: refuse.  Never falls through to one rank."""
+    import socket
+    import subprocess
+    ndev = visible_devices()
+    if ndev == 0:
+        print("bench.py: --gpus %d needs at least one MI355X (none visible); refusing to print a line for fewer ranks" % n, file=sys.stderr)
+        return 2
+    if n > ndev * MAX_RANKS_PER_DEVICE:
+        print("bench.py: --gpus %d on %d visible device(s) would put more than %d ranks on one card; refusing" % (n, ndev, MAX_RANKS_PER_DEVICE), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)       # stderr passes through
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 3
+    if line is not None and rc == 0:
+        print(line)
+    return rc
 
 
 def seeded(seed):
@@ -74,34 +123,61 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline():
-    """The oracle's LITERAL restatement of groth16.ml:116-161 + QAP.ml:120-135 (per-variable
-    apply_powers, schoolbook mul / div_rem) on ONE host core, on a bounded sample: n = 128 (~15 s: the
-    literal algorithm is O(m n) scalar multiplications, 4x the work of n = 64).
-    Also used as a checker: the GPU proof of the same sample must be byte-identical."""
+def cpu_baseline(budget_s=45.0):
+    """The oracle's LITERAL restatement of groth16.ml:116-161 + QAP.ml:120-135 (per-variable apply_powers = m*n single double-and-add
+    scalar multiplications, schoolbook mul / div_rem) on ONE host core, at the ladder of sizes BASELINE.md 3.2 names -- n = 16, 64, 256 (and
+    1024 when the fitted model says it fits the budget) -- with the fitted cost model t(n) = a * m * n + b * n^2 and what that model says about
+    the benchmark sizes ("infeasible": it is never extrapolated into a throughput).  `value` is the LARGEST size measured.
+    Also a checker: the GPU proof of every ladder sample must be byte-identical."""
     O = oracle()
     from zukelang_amd import r1cs as RC
     from zukelang_amd.groth16 import Groth16, PKey
-    n = 128
-    cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
-    rng = seeded(0x5EED0002)
-    toxic = [rng() for _ in range(5)]
-    r, s = rng(), rng()
     frs = lambda xs: bytes(RC.fr_bytes(xs))
-    q = O.QAP(cs.n, cs.m, *[O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)])
-    pk1, pk2, _, _ = q.groth16_setup(frs(toxic), cs.mid)
-    t0 = time.perf_counter()
-    rc, a, b, c = q.groth16_prove(pk1, pk2, cs.mid, frs(w), frs([r]), frs([s]), 1)
-    dt = time.perf_counter() - t0
-    assert rc == 0
-    prover = Groth16(cs, PKey(np.frombuffer(pk1, dtype=np.uint8), np.frombuffer(pk2, dtype=np.uint8)))
-    proof = prover.prove_rs(w, r, s)
-    prover.close()
-    if (proof.a, proof.b, proof.c) != (a, b, c):
-        raise SystemExit("PARITY FAILURE: GPU proof differs from the oracle on the cpu_baseline sample")
-    return {"value": n / dt, "unit": "constraints/s", "cores": 1, "kind": "port",
-            "sample": "literal groth16.ml:116-161 + QAP.ml:120-135 (m*n single scalar-muls, schoolbook polynomials) on the "
-                      "iterated-cubic R1CS at n=128, m=130; %.2f s; GPU proof of the sample byte-identical" % dt}
+    ladder, spent = [], 0.0
+    sizes = [16, 64, 256, 1024]
+    for n in sizes:
+        if ladder:          # predicted from the last point with the O(m n) law (m = n + 2): skip what does not fit
+            n0, t0 = ladder[-1]["n"], ladder[-1]["seconds"]
+            pred = t0 * (n * (n + 2.0)) / (n0 * (n0 + 2.0))
+            if spent + pred > budget_s:
+                break
+        cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
+        rng = seeded(0x5EED0002)
+        toxic = [rng() for _ in range(5)]
+        r, s = rng(), rng()
+        q = O.QAP(cs.n, cs.m, *[O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)])
+        pk1, pk2, _, _ = q.groth16_setup(frs(toxic), cs.mid)
+        t0 = time.perf_counter()
+        rc, a, b, c = q.groth16_prove(pk1, pk2, cs.mid, frs(w), frs([r]), frs([s]), 1)
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        prover = Groth16(cs, PKey(np.frombuffer(pk1, dtype=np.uint8), np.frombuffer(pk2, dtype=np.uint8)))
+        proof = prover.prove_rs(w, r, s)
+        prover.close()
+        if (proof.a, proof.b, proof.c) != (a, b, c):
+            raise SystemExit("PARITY FAILURE: GPU proof differs from the oracle on the cpu_baseline sample n = %d" % n)
+        spent += dt
+        ladder.append({"n": n, "m": cs.m, "seconds": round(dt, 4), "constraints_per_s": n / dt, "gpu_proof_identical": True})
+    # least squares for t = a * (m n) + b * n^2 over the ladder (two unknowns; the m n term -- 3 m n scalar multiplications -- dominates)
+    A = np.array([[p["m"] * p["n"], p["n"] ** 2] for p in ladder], dtype=np.float64)
+    y = np.array([p["seconds"] for p in ladder], dtype=np.float64)
+    if len(ladder) >= 2:
+        coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+        a_c, b_c = float(coef[0]), float(coef[1])
+        if b_c < 0 or a_c <= 0:          # degenerate fit on a noisy box: fall back to the pure m n law through the largest point
+            a_c, b_c = float(y[-1] / A[-1, 0]), 0.0
+    else:
+        a_c, b_c = float(y[-1] / A[-1, 0]), 0.0
+    model = lambda n: a_c * (n + 2.0) * n + b_c * n * n
+    year = 365.25 * 86400
+    top = ladder[-1]
+    return {"value": top["constraints_per_s"], "unit": "constraints/s", "cores": 1, "kind": "port",
+            "sample": "literal groth16.ml:116-161 + QAP.ml:120-135 (3 m n single scalar-muls, schoolbook polynomials) on the iterated-cubic R1CS at n = %s "
+                      "(m = n + 2), %.1f s in all; value = the largest size measured (n = %d, %.2f s); GPU proof of every sample byte-identical"
+                      % (", ".join(str(p["n"]) for p in ladder), spent, top["n"], top["seconds"]),
+            "ladder": ladder,
+            "cost_model": {"form": "seconds(n) = a * m * n + b * n^2, m = n + 2 (least squares over the ladder)", "a": a_c, "b": b_c,
+                           "at_benchmark_sizes": {"2^%d" % k: "infeasible (model: %.2g core-years per proof)" % (model(float(1 << k)) / year) for k in (16, 20, 22)}}}
 
 
 def collect_families(L, _lib, nproofs):
@@ -117,20 +193,52 @@ def collect_families(L, _lib, nproofs):
     return out
 
 
+COUNTERS = ("entries", "copies", "second_steps", "full_additions")
+
+
+def collect_counters(L, _lib, nproofs):
+    """Work counters of the accumulate launches (zk_profile_counter; gathered by the library during the one-proof-at-a-time pass), per proof."""
+    out = {}
+    for fam in ("msm_accumulate_g1", "msm_accumulate_g2"):
+        d = {}
+        for c in COUNTERS:
+            v = C.c_uint64()
+            _lib.check(L.zk_profile_counter(("%s:%s" % (fam, c)).encode(), C.byref(v)))
+            d[c] = v.value / nproofs
+        if d["entries"]:
+            out[fam] = d
+    return out
+
+
 # ALGORITHMIC bytes per (scalar, point) pair of a multi-scalar product (SURVEY.md 8d): 32 B scalar + the affine point.
 PAIR_BYTES = {"g1": 128.0, "g2": 224.0}
-# Field products per group addition in the accumulate kernels: the multiplier-bound model.
+# Field products per group addition in the accumulate kernels (DESIGN.md 4): the multiplier-bound model, in units of one 14 x 14-limb Montgomery
+# product (392 multiply-adds).  A full mixed addition XYZZ += affine: G1 6 products + 2 squares (301) + 1 fused double product (588) = 3542 = 9.04;
+# G2 on a lane pair 8 fused double products + 2 squares per lane = 2 x 5488 = 28.0.  The SECOND step of a chunk adds two affine points
+# (mmadd-2008-s): G1 2 + 2 squares + 1 fused = 1974 = 5.04; G2 2 x 3136 = 16.0.  The FIRST entry of a chunk or of a run is a copy: no product.
 MADD_PRODUCTS = {"g1": 9.04, "g2": 28.0}
+MMADD_PRODUCTS = {"g1": 5.04, "g2": 16.0}
 
 
-def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windows, peak_products, traffic, workload_key):
+def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windows, peak_products, traffic, workload_key, counters=None):
     """One roofline object per MSM bucket-accumulation family (`msm_accumulate_g1` covers the two G1 products A and C of
     a proof in ONE launch, `msm_accumulate_g2` the G2 product B).  achieved = algorithmic bytes per launch / average launch
-    duration, both in the timed region (launches stretched by the other proofs in flight) and with one proof in flight."""
+    duration.  `achieved` / `frac` are the UN-OVERLAPPED launch (one proof in flight: the duration rocprofv3 lists for the kernel under
+    profiles/); `timed_region` keeps the same launch as it ran inside the timed region, stretched by the other proofs sharing the SIMDs.
+    `alu`: field products the launch really executed (the library's own counts of full additions / second steps / copies when `counters`
+    has them -- identity bases, zero scalars and zero digits never enter a bucket -- else pairs x windows) against the measured multiplier peak."""
     objs = {}
     for key, fam in (("g1", "msm_accumulate_g1"), ("g2", "msm_accumulate_g2")):
         alg_per_proof = PAIR_BYTES[key] * pairs[key] / world
         o = {"bound": "hbm", "kernel": fam, "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_proof": alg_per_proof}
+        cnt = (counters or {}).get(fam)
+        if cnt:
+            products = cnt["full_additions"] * MADD_PRODUCTS[key] + cnt["second_steps"] * MMADD_PRODUCTS[key]
+            o["additions_per_proof"] = {k: cnt[k] for k in COUNTERS}
+            o["additions_per_proof"]["source"] = "counted by the library (zk_profile_counter), one proof at a time"
+        else:
+            products = alg_per_proof / PAIR_BYTES[key] * windows * MADD_PRODUCTS[key]          # upper bound: one full addition per (point, window) digit
+            o["additions_per_proof"] = {"entries": alg_per_proof / PAIR_BYTES[key] * windows, "source": "pairs x windows (upper bound: no counters in this pass)"}
         for tag, fams, nproofs in (("timed_region", fam_timed, n_timed), ("one_proof_in_flight", fam_alone, n_alone)):
             members = [k for k in fams if k == fam or k.startswith(fam + ":")]          # sub-steps of a family are "family:step"
             if not members or not fams[fam if fam in fams else members[0]]["launches"]:
@@ -140,20 +248,19 @@ def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windo
             avg_ms = ms_per_proof / launches_per_proof
             bytes_per_launch = alg_per_proof / launches_per_proof
             ach = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            madds = alg_per_proof / PAIR_BYTES[key] * windows            # one group addition per (point, window) digit
-            mul_equiv = madds * MADD_PRODUCTS[key] / (ms_per_proof * 1e-3) / 1e9
+            mul_equiv = products / (ms_per_proof * 1e-3) / 1e9
             o[tag] = {"avg_launch_ms": avg_ms, "launches_per_proof": launches_per_proof, "algorithmic_bytes_per_launch": bytes_per_launch,
                       "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                      "alu": {"unit": "G Fp products/s (XYZZ mixed-addition equivalents)", "achieved": mul_equiv, "peak_measured": peak_products,
+                      "alu": {"unit": "G Fp products/s", "achieved": mul_equiv, "peak_measured": peak_products,
                               "frac": mul_equiv / peak_products if peak_products else None}}
         t = None
         if traffic and workload_key in traffic.get("workloads", {}):
             t = traffic["workloads"][workload_key].get(fam, {}).get("hbm_bytes_per_launch")
         o["traffic"] = t
-        if "timed_region" in o:
-            o["achieved"], o["frac"] = o["timed_region"]["achieved"], o["timed_region"]["frac"]
-        elif "one_proof_in_flight" in o:
-            o["achieved"], o["frac"] = o["one_proof_in_flight"]["achieved"], o["one_proof_in_flight"]["frac"]
+        if "one_proof_in_flight" in o:
+            o["achieved"], o["frac"], o["frac_is"] = o["one_proof_in_flight"]["achieved"], o["one_proof_in_flight"]["frac"], "un-overlapped launch (one proof in flight)"
+        elif "timed_region" in o:
+            o["achieved"], o["frac"], o["frac_is"] = o["timed_region"]["achieved"], o["timed_region"]["frac"], "launch inside the timed region (no un-overlapped pass at N > 1)"
         objs[key] = o
     return objs
 
@@ -163,7 +270,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     from zukelang_amd import r1cs as RC
     from zukelang_amd.groth16 import Groth16
     t_setup = time.perf_counter()
-    n = (1 << log_n) * world
+    n = (1 << log_n) * world if args.weak else (1 << log_n)          # strong scaling by default: the same proof on every N
     cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
     rng = seeded(0x5EED0002)
     toxic = [rng() for _ in range(5)]
@@ -173,8 +280,8 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     # parallel) and keeps its shard (cut for equal work, zk_groth16_shard_range).  Otherwise (--derive-lagrange-upto -1, or a total size
     # beyond it) the key is sharded at upload and stays in tau-power form.
     derive_s = None
-    total_log = log_n + max(0, (world - 1).bit_length())
-    sharded_derived = world > 1 and derive_upto is not None and total_log <= derive_upto + 1 and not lagrange and not args.tau_power_key
+    total_log = (n - 1).bit_length()
+    sharded_derived = world > 1 and derive_upto is not None and total_log <= derive_upto and not lagrange and not args.tau_power_key
     if sharded_derived:
         prover = Groth16(cs, pk)
         t_d = time.perf_counter()
@@ -232,6 +339,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
         return last, (first + count - 1) % len(rs)
 
     last_idx = [None]
+    counters = [None]
 
     def measure(with_families):
         """warm-up + settle, the timed region, single-proof latency (and, with_families, the un-overlapped per-family pass), the parity gate"""
@@ -283,6 +391,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
                 for i in range(n_alone):
                     prover.prove_rs(None, *rs[1 + i])
                 fam_alone = collect_families(L, _lib, n_alone)
+                counters[0] = collect_counters(L, _lib, n_alone)
                 _lib.check(L.zk_profile_enable(0))
             _lib.check(L.zk_profile_reset())
 
@@ -314,6 +423,13 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
         derive_s = time.perf_counter() - t_d
         prover.reserve_slots(depth)
     dt, fam_timed, proof, lat, fam_alone, n_alone, parity = measure(True)
+    if power_form is not None:
+        # the derivation is per-key preprocessing OUTSIDE the timed region: say what it costs and when it has paid for itself
+        saved = power_form["ms_per_proof"] - dt / nproofs * 1e3
+        power_form["derive_lagrange_s"] = round(derive_s, 2)
+        power_form["break_even_proofs"] = int(derive_s * 1e3 / saved) + 1 if saved > 0 else None
+        power_form["note"] = ("value = this key exactly as an OCaml keygen emits it (tau powers); the headline proves from the SAME key after a one-time, untimed "
+                              "on-device derivation of its Lagrange form -- amortised after break_even_proofs proofs (derive_lagrange_s / per-proof saving)")
 
     # ---- context: the same job on the HOST cores with the same algorithmic freedom (oracle/fast_cpu.c: Pippenger + NTT
     # convolutions over the Lagrange-form pools this key now holds), all threads of this process's CPU share, one proof, untimed w.r.t. `value`;
@@ -347,7 +463,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
            "ms_per_step": dt / steps * 1e3, "timed_s": dt, "timed_proofs": nproofs, "proofs_in_flight": 2 * group.batch if group is not None else depth,
            "single_proof_latency_ms": None if lat is None else lat * 1e3, "single_proof_value": None if lat is None else n / lat,
            "setup_s": round(setup_s, 1), "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "tau_power_form": power_form, "parity": parity, "cpu_fast_context": cpu_fast, "pairs": pairs, "p1": p1, "p2": p2,
-           "fam_timed": fam_timed, "fam_alone": fam_alone, "n_alone": n_alone, "nproofs": nproofs,
+           "fam_timed": fam_timed, "fam_alone": fam_alone, "n_alone": n_alone, "nproofs": nproofs, "counters": counters[0],
            "kernel_ms_per_proof": {k: round(v["ms_per_proof"], 4) for k, v in sorted(fam_alone.items())},
            "proof_compressed_hex": proof.to_compressed().hex() if proof is not None else None,
            "group_batch": group.batch if group is not None else None}
@@ -411,6 +527,7 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight, peak_products=None)
         for i in range(2):
             prover.prove_with(wb, *ds[i])
         fams["alone"] = collect_families(L, _lib, 2)
+        fams["counters"] = collect_counters(L, _lib, 2)
         _lib.check(L.zk_profile_enable(0))
         _lib.check(L.zk_profile_reset())
         parity = None
@@ -432,6 +549,9 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight, peak_products=None)
         prover.derive_lagrange()
         derive_s = time.perf_counter() - t_d
     dt, lat, parity = measure()
+    if as_uploaded is not None:
+        saved = as_uploaded["ms_per_proof"] - dt / nproofs * 1e3
+        as_uploaded["break_even_proofs"] = int(derive_s * 1e3 / saved) + 1 if saved > 0 else None
     prover.close()
     # ---- CPU baseline of THIS protocol: the oracle's restatement of ZKCompute.f (pinocchio.ml:427-514: one scalar multiplication per key
     # element touched, QAP.eval with schoolbook polynomials) on one host core at n = 1024; the GPU proof of the sample must be byte-identical
@@ -461,7 +581,7 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight, peak_products=None)
     alg = 5 * 128 * m_mid + 2 * 128 * cs.m + 2 * 128 * n + 2 * 224 * m_mid + 192 * n       # 1792 n B at m_mid = m = n
     # scalar-point pairs per proof: five pools over I_mid (+ their appended single points), the h pool (n + 1 + 2m), two G2 pools over I_mid
     pairs = {"g1": 4 * (m_mid + 1) + (m_mid + 3) + (n + 1 + 2 * cs.m), "g2": 2 * (m_mid + 1)}
-    roofs = roofline_objects(fams.get("timed", {}), nproofs, fams.get("alone", {}), 2, pairs, 1, 16, peak_products, None, "")
+    roofs = roofline_objects(fams.get("timed", {}), nproofs, fams.get("alone", {}), 2, pairs, 1, 16, peak_products, None, "", fams.get("counters"))
     return {"workload": "pinocchio_zk_prove (BASELINE config 5), iterated-cubic R1CS, key+circuit+witness resident in HBM", "log_n": log_n, "constraints": n,
             "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3, "timed_s": dt, "timed_proofs": nproofs,
             "proofs_in_flight": depth, "single_proof_latency_ms": lat * 1e3, "single_proof_note": "one at a time, witness handed over as a host buffer",
@@ -476,8 +596,8 @@ def summarize(res, world, peak_products, traffic, lagrange):
     # the key's window width (groth16.hip upload): 20 bits from 2^21 points in the rank's G1 pool, 16 below (from 2^16 constraints up)
     cbits = int(os.environ.get("ZK_MSM_WINDOW", "20" if res["p1"] // world >= 1 << 21 else "16"))
     windows = 255 // cbits + 1
-    key = "groth16_2^%d" % res["log_n"] + ("_lagrange" if lagrange else "")
-    roofs = roofline_objects(res["fam_timed"], res["nproofs"], res["fam_alone"], res["n_alone"], res["pairs"], world, windows, peak_products, traffic, key)
+    key = "groth16_2^%d" % res["log_n"] + ("_derived" if res.get("derive_lagrange_s") is not None else ("_lagrange" if lagrange else ""))
+    roofs = roofline_objects(res["fam_timed"], res["nproofs"], res["fam_alone"], res["n_alone"], res["pairs"], world, windows, peak_products, traffic, key, res.get("counters"))
     out = {k: res[k] for k in ("log_n", "constraints", "variables", "value", "unit", "ms_per_proof", "timed_s", "timed_proofs", "proofs_in_flight",
                                "single_proof_latency_ms", "single_proof_value", "setup_s", "derive_lagrange_s", "tau_power_form", "parity", "cpu_fast_context", "kernel_ms_per_proof")}
     out["prove_algorithmic_bytes_per_constraint"] = 928
@@ -493,13 +613,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = --proofs-per-step consecutive proofs of the pipelined prover")
     ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps")
     ap.add_argument("--proofs-per-step", type=int, default=16)
-    ap.add_argument("--log-n", type=int, default=16, help="log2 constraints per GPU of the headline workload")
-    ap.add_argument("--sizes", default="18,20,22", help="one GPU: further log2 sizes timed in the same run and reported under other_workloads ('' = none; '' = none)")
+    ap.add_argument("--log-n", type=int, default=20, help="log2 constraints of the headline workload (the WHOLE proof, whatever N: strong scaling; with --weak: per GPU)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: 2^log_n constraints PER GPU (n = 2^log_n x N, \"scaling\": \"weak\") instead of the same 2^log_n-constraint proof on every N; "
+                    "BASELINE config 4 is --gpus 8 --log-n 19 --weak")
+    ap.add_argument("--sizes", default="16,18,22", help="one GPU: further log2 sizes timed in the same run and reported under other_workloads ('' = none)")
     ap.add_argument("--no-pinocchio", action="store_true", help="skip the Pinocchio 2^18 workload (config 5) of the default run")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs): same as --sizes '' --no-pinocchio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-fast-upto", type=int, default=18, help="workloads of at most 2^K constraints that hold Lagrange-form pools also run ONE proof on the multi-threaded CPU "
-                    "prover of oracle/fast_cpu.c (context figure `cpu_fast_context`, BASELINE.md 3.3; ~1 s at 2^16, ~4 s at 2^18 on 16 threads); -1 = never")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=45.0, help="seconds of one host core the literal-algorithm ladder of cpu_baseline may take (n = 16, 64, 256, 1024 while the fitted O(m n) law says the next size fits)")
+    ap.add_argument("--cpu-fast-upto", type=int, default=20, help="workloads of at most 2^K constraints that hold Lagrange-form pools also run ONE proof on the multi-threaded CPU "
+                    "prover of oracle/fast_cpu.c (context figure `cpu_fast_context`, BASELINE.md 3.3; ~0.5 s at 2^16, ~3 s at 2^18, ~12 s at 2^20 on 16 threads); -1 = never")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the oracle comparison of the last timed proof (profiling runs only)")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
@@ -514,11 +637,17 @@ def main():
     ap.add_argument("--inflight", type=int, default=14, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls the N = 1 line: this process becomes the LAUNCHER.  It never touches HIP (no
+        # torch.cuda call, no zk_init): the N ranks are fresh child processes under torch.distributed.run, rank 0's JSON line is relayed.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world != args.gpus:
+        raise SystemExit("--gpus (%d) must equal WORLD_SIZE (%d): a line for N GPUs is never measured on another number of ranks" % (args.gpus, world))
 
     dist = None
     rehearsal = False
@@ -547,7 +676,7 @@ def main():
                          lagrange=args.lagrange_key, replicated_fr=args.replicated_fr, events=not args.no_live_events,
                          derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
     peak = C.c_double()
-    _lib.check(L.zk_bench_field_mul(1, 2000, C.byref(peak)))       # the library's dependent-chain product benchmark on this chip, in this process
+    _lib.check(L.zk_bench_field_mul(1 | 8, 2000, C.byref(peak)))   # the library's dependent-chain product benchmark on this chip, in this process: best of 2 / 4 / 6 / 8 waves per SIMD
     traffic = pmc_traffic()
     head_pub, roofs = summarize(head, world, peak.value, traffic, args.lagrange_key)
 
@@ -557,21 +686,21 @@ def main():
             ln = int(tok)
             if ln == args.log_n:
                 continue
-            per = {18: 80, 20: 24, 22: 8}.get(ln, max(8, int(0.6 / (2e-3 * (1 << max(0, ln - 16))))))       # proofs for >= 0.5 s at last round's rates
+            per = {16: 320, 18: 80, 20: 24, 22: 8}.get(ln, max(8, int(0.6 / (2e-3 * (1 << max(0, ln - 16))))))       # proofs for >= 0.5 s at last round's rates
             infl = args.inflight if ln <= 20 else 4
             steps = max(1, (per + args.proofs_per_step - 1) // args.proofs_per_step)
             r = bench_groth16(args, L, _lib, ln, steps, 1 if ln <= 18 else 0, infl, args.settle if ln <= 18 else min(args.settle, 2.0), 0, 1, None,
                               lagrange=args.lagrange_key, events=not args.no_live_events,
                               derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
             pub, _ = summarize(r, 1, peak.value, traffic, args.lagrange_key)
-            pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
+            pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {16: "2", 20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
             others.append(pub)
         if not args.no_pinocchio:
             others.append(bench_pinocchio(args, L, _lib, 18, 48, 8, peak.value))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.cpu_baseline_budget)
 
     if rank == 0:
         # the dominant kernel = the accumulate family with the larger UN-OVERLAPPED time per proof (one proof in flight); N > 1: the
@@ -586,9 +715,10 @@ def main():
             dom = max(cands, key=weight)
             roof = dict(roofs[dom])
             roof["dominant_by"] = "un-overlapped time per proof (one proof in flight)" if roofs[dom].get("one_proof_in_flight") else "timed-region events"
-            roof["note"] = ("algorithmic bytes = 128 B (G1) / 224 B (G2) per scalar-point pair; achieved / frac are those of the TIMED REGION (launches stretched by the "
-                            "other proofs in flight), `one_proof_in_flight` the un-overlapped ones; the kernel is bound by the integer multiplier, not by HBM: see `alu`; "
-                            "traffic (PMC, profiles/%s_pmc_traffic.json) > algorithmic because the resident key stores one precomputed point per (point, window), see DESIGN.md" % PROFILE_ROUND)
+            roof["note"] = ("algorithmic bytes = 128 B (G1) / 224 B (G2) per scalar-point pair; achieved / frac = the UN-OVERLAPPED launch (HIP events, one proof in flight: "
+                            "the duration a reader recomputes from the rocprofv3 kernel stats under profiles/); `timed_region` = the same launch inside the timed region, stretched "
+                            "by the other proofs sharing the SIMDs; the kernel is bound by the integer multiplier, not by HBM: see `alu` (products really executed, counted by the "
+                            "library); traffic (PMC, profiles/%s_pmc_traffic.json) > algorithmic because the resident key stores one precomputed point per (point, window), see DESIGN.md" % PROFILE_ROUND)
         out = {
             "metric": "Groth16 constraints/sec on BLS12-381 at 1/2/4/8 MI355X; proof bit-exact",
             "value": head["value"],
@@ -598,7 +728,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.weak else "strong",      # default: the SAME 2^log_n-constraint proof on every N (total work fixed)
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
@@ -607,7 +737,7 @@ def main():
                                    + (", reference-format key (tau powers) uploaded, its Lagrange form DERIVED on the device once (zk_groth16_pk_derive_lagrange); tau_power_form = the same key before the derivation" if head.get("derive_lagrange_s") is not None else ""),
                        "step": "%d consecutive proofs of the pipelined prover (pipeline not drained between steps)" % args.proofs_per_step,
                        "proofs_per_step": args.proofs_per_step, "timed_proofs": head["timed_proofs"], "timed_s": head["timed_s"],
-                       "constraints": head["constraints"], "variables": head["variables"], "proofs_in_flight": head["proofs_in_flight"], "constraints_per_gpu": 1 << args.log_n,
+                       "constraints": head["constraints"], "variables": head["variables"], "proofs_in_flight": head["proofs_in_flight"], "constraints_per_gpu": head["constraints"] // world,
                        "sharding": ("MSM base points over ranks (slices cut for equal work: the A prefix counts twice); "
                                     + ("every rank derived the key's Lagrange form (derive_lagrange_s) and kept its shard; " if head.get("derive_lagrange_s") is not None else "")
                                     + "Fr stage of a proof on its owner rank + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"

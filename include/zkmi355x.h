@@ -198,6 +198,13 @@ int zk_device_malloc(size_t bytes, void** dptr);
 int zk_device_free(void* dptr);
 int zk_device_memcpy(void* dst, const void* src, size_t bytes);   /* any direction, synchronous */
 int zk_groth16_combine(const uint8_t* partials /* world * 768 */, uint32_t world, uint8_t proof[384]);
+/* Device-resident form of the exchange (the path RCCL takes: slot buffer -> all-gather on a DEVICE tensor -> combine, no PCIe hop in between):
+ * _wait_device waits like zk_groth16_prove_partial_wait and leaves the 768-byte block at the DEVICE address d_partial (same return codes);
+ * _combine_device reads `world` blocks from DEVICE memory, block j at d_partials + j * stride_bytes (stride >= 768: the all-gather of a whole
+ * round of proofs lands as [rank][proof][768]), adds them on the GPU and returns the proof.  Same group elements, same bytes
+ * (groth16.ml:123-161: the proof does not depend on how the sums were cut). */
+int zk_groth16_prove_partial_wait_device(uint64_t handle, uint32_t slot, void* d_partial /* device, 768 B */);
+int zk_groth16_combine_device(const void* d_partials /* device */, size_t stride_bytes, uint32_t world, uint8_t proof[384]);
 
 /* ---- protocol seam: Pinocchio.Make(C).{NonZK,ZK}.prove (src/pinocchio/pinocchio.ml:536-538,559-561) ----
  * Evaluation key of pinocchio.ml:37-60 flattened per group (maps in Var.Map key order over I_mid, resp.
@@ -256,10 +263,13 @@ int zk_profile_enable(int level);   /* 0 off | 1 the MSM accumulate kernels only
 int zk_profile_reset(void);
 int zk_profile_get(const char* family, double* total_ms, uint64_t* launches);
 int zk_profile_names(char* buf, size_t buflen);   /* comma-separated family names */
+/* Work counters gathered at level 2 (one proof at a time) since the last reset, e.g. "msm_accumulate_g1:entries" (sorted (point, window) entries),
+ * ":copies" (first entries of a chunk or run: no field product), ":second_steps" (6-product additions of two affine points), ":full_additions". */
+int zk_profile_counter(const char* name, uint64_t* value);
 int zk_sync(void);                                 /* waits for everything the library has enqueued on this device, the per-slot streams of
                                                       proofs in flight included (hipDeviceSynchronize) */
 /* Throughput of the register-resident Montgomery multiplier (kind 0 = Fr, 1 = Fp): ALU ceiling.
- * kind | 4: one wave on the whole chip (dependent-chain latency). */
+ * kind | 4: one wave on the whole chip (dependent-chain latency).  kind | 8: the best rate over 2 / 4 / 6 / 8 waves per SIMD. */
 int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s);
 /* Field-layer self-test hook (tests/test_gpu_field.py): for each of n (even) operand pairs a_i, b_i < p (48-byte little-endian
  * integers) the device evaluates 18 base-field expressions through the lazy-reduction code paths of the group law and

@@ -1,7 +1,10 @@
 #!/bin/bash
 # What does the 16x window table cost?  A/B of the real tables against ZK_EXPERIMENT_TABLE_ALIAS=1 (every window gathers from
 # window 0's entries: same additions and gathers, 1/16 of the footprint; proofs are WRONG, the parity gate is off).
+# The experiment is NOT in the shipped library: this script rebuilds msm.o with -DZK_EXPERIMENTS first and restores the product build afterwards.
 O=gpurun_out/$1; mkdir -p $O
+( cd zukelang_amd/csrc && rm -f msm.o && make -s CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fvisibility=hidden -fvisibility-inlines-hidden -DZK_EXPERIMENTS" ) || exit 1
+trap '( cd zukelang_amd/csrc && rm -f msm.o && make -s )' EXIT
 for ln in 16 20; do
   for al in 0 1; do
     for infl in 1 12; do

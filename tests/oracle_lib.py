@@ -20,7 +20,7 @@ def build():
 
 
 def _load():
-    so = os.path.join(_ODIR, "libzkoracle.so")
+    so = os.environ.get("ZK_ORACLE_SO") or os.path.join(_ODIR, "libzkoracle.so")      # ZK_ORACLE_SO: the sanitizer build (make -C oracle asan)
     if not os.path.exists(so):
         build()
     return C.CDLL(so)

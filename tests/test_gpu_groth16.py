@@ -212,6 +212,92 @@ def test_lagrange_form_key_gives_the_same_proofs(maker):
     std.close(); lag.close()
 
 
+@pytest.mark.parametrize("log_n", [16, 18, 20])
+def test_derived_key_at_the_config_sizes(log_n):
+    """The path bench.py's headline runs: a key in the REFERENCE's format at BASELINE's sizes (2^16 = config 2, 2^18, 2^20 =
+    config 3's size), its Lagrange form derived on the device (zk_groth16_pk_derive_lagrange, no tau), then proofs -- one at a time and pipelined
+    over slots -- against the oracle's trapdoor evaluation of groth16.ml:123-161 / QAP.ml:120-135.  The derived pools are compared with what a
+    keygen that KNOWS tau emits: every byte of both pools, i.e. all 3 + n + (n-1) + n_mid G1 points and 2 + n G2 points, not a sample."""
+    n = 1 << log_n
+    cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0001)))
+    rng = seeded_rng(0x5EED0D10 + log_n)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, vk = Groth16.keygen(lambda: next(it), cs, lagrange=True)
+    L, R_, Oo = csrs(cs)
+    prover = Groth16(cs, pk)                                    # uploads the tau-power pools only
+    prover.derive_lagrange()
+    g1 = prover.pool_points(1)
+    assert g1.shape == pk.lag_g1.shape and bool((g1 == pk.lag_g1).all())
+    del g1
+    g2 = prover.pool_points(2)
+    assert g2.shape == pk.lag_g2.shape and bool((g2 == pk.lag_g2).all())
+    del g2
+    rs = [(rng(), rng()) for _ in range(4)]
+    exp = [O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s)) for r, s in rs]
+    first = prover.prove_rs(w, *rs[0])
+    assert (first.a, first.b, first.c) == exp[0]
+    prover.set_witness(w)
+    prover.reserve_slots(len(rs))
+    for slot, (r, s) in enumerate(rs):                          # pipelined: four proofs in flight on the derived key
+        prover.prove_async(None, r, s, slot)
+    for slot in range(len(rs)):
+        got = prover.prove_wait(slot)
+        assert (got.a, got.b, got.c) == exp[slot], "slot %d" % slot
+    io_vals = [w[k] for k in range(cs.m) if not cs.mid[k]]
+    assert Groth16.verify(io_vals, vk, first)                   # the reference's own acceptance test (src/lib/test/test.ml:178)
+    w_bad = list(w)
+    w_bad[n // 2] = (w_bad[n // 2] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        prover.prove_rs(w_bad, *rs[0])
+    prover.close()
+
+
+@pytest.mark.parametrize("world,n", [(2, 300), (3, 4096), (8, 1 << 14)])
+def test_device_resident_exchange_of_the_partial_sums(world, n):
+    """The RCCL form of the exchange: every rank's 768-byte block goes slot buffer -> DEVICE buffer (zk_groth16_prove_partial_wait_device),
+    the all-gather lands them as [rank][proof][768] in device memory, zk_groth16_combine_device adds them there.  One process plays all ranks here
+    (`world` sharded handles of one key; RCCL itself needs one GPU per rank); the gathered layout is written the way all_gather_into_tensor leaves it,
+    with a stride of 2 proofs per rank.  Proof bytes = the trapdoor oracle's, i.e. independent of the cut (groth16.ml:123-161)."""
+    import ctypes as C
+    from zukelang_amd import _lib
+    L_ = _lib.lib()
+    cs, w = RC.iterated_cubic(n, 0xD0D0 + n)
+    rng = seeded_rng(0x5EED0E00 + n)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, _ = Groth16.keygen(lambda: next(it), cs)
+    ranks = [Groth16(cs, pk, g, world) for g in range(world)]
+    rs = [(rng(), rng()) for _ in range(2)]
+    gathered = C.c_void_p()
+    _lib.check(L_.zk_device_malloc(C.c_size_t(world * 2 * 768), C.byref(gathered)))
+    p8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    for g, pr in enumerate(ranks):
+        for t, (r, s) in enumerate(rs):
+            rb, sb = RC.fr_bytes([r]), RC.fr_bytes([s])
+            wb = RC.fr_bytes(w)
+            _lib.check(L_.zk_groth16_prove_partial_async(pr.handle, p8(wb), p8(rb), p8(sb), C.c_uint32(t)))
+        for t in range(2):
+            _lib.check(L_.zk_groth16_prove_partial_wait_device(pr.handle, C.c_uint32(t), C.c_void_p(gathered.value + 768 * (2 * g + t))))
+    Lc, R_, Oo = csrs(cs)
+    for t, (r, s) in enumerate(rs):
+        out = np.zeros(384, dtype=np.uint8)
+        _lib.check(L_.zk_groth16_combine_device(C.c_void_p(gathered.value + 768 * t), C.c_size_t(2 * 768), C.c_uint32(world), p8(out)))
+        exp = O.groth16_prove_trapdoor(cs.n, cs.m, Lc, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+        assert bytes(out) == b"".join(exp)
+        # the host form of the same blocks gives the same bytes
+        host = np.zeros(world * 2 * 768, dtype=np.uint8)
+        _lib.check(L_.zk_device_memcpy(p8(host), gathered, C.c_size_t(len(host))))
+        blk = np.ascontiguousarray(host.reshape(world, 2, 768)[:, t, :]).reshape(-1)
+        out2 = np.zeros(384, dtype=np.uint8)
+        _lib.check(L_.zk_groth16_combine(p8(blk), C.c_uint32(world), p8(out2)))
+        assert bytes(out2) == bytes(out)
+    assert L_.zk_groth16_combine_device(gathered, C.c_size_t(100), C.c_uint32(world), p8(out)) != 0          # stride below one block
+    _lib.check(L_.zk_device_free(gathered))
+    for pr in ranks:
+        pr.close()
+
+
 def test_config3_window_sweep_is_parity_checked():
     """BASELINE config 3 (window-size sweep at 2^20 constraints) under parity: the proof must be the
     trapdoor oracle's bytes at every window width the sweep visits, not only at the default c = 16."""

@@ -86,6 +86,18 @@ def test_pinocchio_2_18_trapdoor_and_verify():
     io = [w[k] for k in range(cs.m) if not cs.mid[k]]
     assert O.pinocchio_verify(bytes(G1.of_Fr(v1)), bytes(G2.of_Fr(v2)), io, proof.to_bytes())
     assert len(proof.to_compressed()) == 480
+    # ... and the path bench.py times at this size: the h bases derived on the device (zk_pinocchio_pk_derive_lagrange), proofs one
+    # at a time and pipelined, against the trapdoor oracle of pinocchio.ml:427-514
+    prover.derive_lagrange()
+    ds = [[next(st) for _ in range(3)] for _ in range(3)]
+    exp = [O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), toxic, *(P.fr_to_bytes(x) for x in d)) for d in ds]
+    assert prover.prove_with(w, dv, dw, dy).to_bytes() == proof.to_bytes()
+    assert prover.prove_with(w, *ds[0]).to_bytes() == exp[0]
+    prover.set_witness(w)
+    for slot, d in enumerate(ds):
+        prover.prove_async(*d, slot)
+    for slot in range(len(ds)):
+        assert prover.prove_wait(slot).to_bytes() == exp[slot], "slot %d" % slot
     prover.close()
 
 

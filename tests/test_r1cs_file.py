@@ -76,6 +76,13 @@ def test_malformed_files_are_rejected(tmp_path):
     RF.write_r1cs(p, cs, list(reversed(README_VARS)))
     with pytest.raises(ValueError):
         RF.read_r1cs(p)
+    # a DUPLICATE (name, id): sorted() would accept it, Var.compare order is strict
+    cs, _ = RC.readme_circuit(3)
+    dup = list(README_VARS)
+    dup[1] = dup[0]
+    RF.write_r1cs(p, cs, dup)
+    with pytest.raises(ValueError):
+        RF.read_r1cs(p)
     wit = bytearray(_golden("readme_circuit_x3.wit.hex"))
     with pytest.raises(ValueError):
         RF.read_witness(bytes(wit[:-1]))

@@ -55,6 +55,27 @@ def test_groth16_records_round_trip():
     assert mids2 == mids and bytes(pk2.g1) == g1 and bytes(pk2.g2) == g2
 
 
+def test_names_are_byte_strings_and_malformed_json_raises_valueerror():
+    """A variable name is an OCaml string = raw bytes: a byte >= 0x80 travels as ONE raw byte through every reader and writer (latin-1 on the
+    Python side), never as a UTF-8 pair; malformed input raises ValueError, not an assert / IndexError."""
+    import pytest
+    pt1 = lambda k: P.g1_to_bytes(P.pt_mul(P.G1, k))
+    pt2 = lambda k: P.g2_to_bytes(P.pt_mul(P.G2, k))
+    io_vars = [("ONE", 1), ("caf\xe9", 6)]                       # 0xE9 as a single byte
+    vk = VKey(pt1(1), np.frombuffer(pt1(8) + pt1(9), dtype=np.uint8), pt2(1), pt2(10), pt2(11), bytes(range(64)) * 9)
+    js = wire.groth16_vkey_to_json(vk, io_vars)
+    assert b'"caf\xe9"' in js and b"\xc3\xa9" not in js          # the raw byte, not its UTF-8 encoding
+    vk2, vars2 = wire.groth16_vkey_of_json(js)
+    assert vars2 == io_vars and wire.groth16_vkey_to_json(vk2, vars2) == js
+    assert wire.loads(wire.dumps({"k\xff": 1})) == {"k\xff": 1}
+    for bad in (b"", b"{", b'{"a" 1}', b'{"a":1', b"[1 2]", b'"abc', b'{"a":1} x', b"[,]", b'{"a":"\\q"}'):
+        with pytest.raises(ValueError):
+            wire.loads(bad)
+    for reader in (wire.groth16_vkey_of_json, wire.groth16_pkey_of_json, wire.groth16_proof_of_json, wire.pinocchio_pkey_of_json, wire.pinocchio_vkey_of_json):
+        with pytest.raises(ValueError):
+            reader(b'{"one1":1}')                               # valid JSON, not the record
+
+
 def test_pinocchio_key_records_round_trip():
     """pinocchio.ml:37-60 (pkey) and :62-75 (vkey): field order of the derivers, the I_mid / [m] / io maps as Var.Map
     bindings, flat pools of include/zkmi355x.h on the other side."""

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkmi355x.so")
+# ZK_LIBZKMI355X_PATH: load another build of the SAME library (the host-only sanitizer build of `make asan-host`, tests/test_sanitizers.py).
+# Not a fallback: a missing file or a missing entry point still fails loudly.
+LIB_PATH = os.environ.get("ZK_LIBZKMI355X_PATH") or os.path.join(_HERE, "libzkmi355x.so")
 
 # every symbol include/zkmi355x.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [
@@ -15,13 +17,13 @@ EXPORTS = [
     "zk_fr_ntt", "zk_fr_poly_mul", "zk_msm_g1", "zk_msm_g2", "zk_g1_of_fr", "zk_g2_of_fr",
     "zk_g1_powers", "zk_g2_powers", "zk_g1_compress", "zk_g2_compress", "zk_g1_decompress", "zk_g2_decompress",
     "zk_groth16_pk_upload", "zk_groth16_pk_upload_lagrange", "zk_groth16_pk_derive_lagrange", "zk_groth16_pk_shard", "zk_groth16_shard_range", "zk_groth16_pool_points", "zk_groth16_pk_free", "zk_groth16_prove", "zk_groth16_reserve_slots", "zk_groth16_prove_async", "zk_groth16_prove_wait", "zk_groth16_set_witness", "zk_groth16_qap_eval",
-    "zk_groth16_pk_upload_sharded", "zk_groth16_prove_partial", "zk_groth16_prove_partial_async", "zk_groth16_prove_partial_wait", "zk_groth16_combine",
+    "zk_groth16_pk_upload_sharded", "zk_groth16_prove_partial", "zk_groth16_prove_partial_async", "zk_groth16_prove_partial_wait", "zk_groth16_combine", "zk_groth16_prove_partial_wait_device", "zk_groth16_combine_device",
     "zk_groth16_pool_layout", "zk_groth16_scalars_async", "zk_groth16_scalars_wait", "zk_groth16_msm_partial_async",
     "zk_device_malloc", "zk_device_free", "zk_device_memcpy",
     "zk_pinocchio_pk_upload", "zk_pinocchio_pk_derive_lagrange", "zk_pinocchio_pool_points", "zk_pinocchio_pk_free", "zk_pinocchio_prove",
     "zk_pinocchio_reserve_slots", "zk_pinocchio_set_witness", "zk_pinocchio_prove_async", "zk_pinocchio_prove_wait",
     "zk_pairing_product", "zk_pairing_check", "zk_groth16_verify", "zk_pinocchio_verify",
-    "zk_profile_enable", "zk_profile_reset", "zk_profile_get", "zk_profile_names", "zk_sync",
+    "zk_profile_enable", "zk_profile_reset", "zk_profile_get", "zk_profile_names", "zk_profile_counter", "zk_sync",
     "zk_bench_field_mul", "zk_selftest_fp",
 ]
 

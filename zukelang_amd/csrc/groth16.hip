@@ -153,9 +153,9 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
         // Slot 0 -- the slot of the synchronous zk_groth16_prove -- keeps two more streams and forks onto them while it is the ONLY
         // proof in flight: the G2 product's latency-bound reduction chain then runs beside the G1 products instead of in front of
         // them (single-proof latency; with other proofs in flight it stays on one stream like every other slot).
-        const char* ss = getenv("ZK_SLOT_STREAMS");
+        const char* ss = ZK_ENV("ZK_SLOT_STREAMS");
         const bool want3 = ss ? atoi(ss) >= 3 : idx == 0;
-        if (getenv("ZK_SERIAL_STREAMS") || !want3) {
+        if (ZK_ENV("ZK_SERIAL_STREAMS") || !want3) {
             sl->s1 = sl->s2 = sl->s0;
             sl->serial = true;
         } else {
@@ -262,7 +262,7 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
     // fork onto the slot's extra streams only while no other proof is in flight on this key (and never when ZK_SLOT_STREAMS forces it)
     bool serial = sl.serial;
     if (ctx().profiling >= 2) serial = true;      // the per-family event timers want un-overlapped launches (bench.py's one-proof-in-flight pass)
-    if (!serial && !getenv("ZK_SLOT_STREAMS"))
+    if (!serial && !ZK_ENV("ZK_SLOT_STREAMS"))
         for (uint32_t i = 0; i < MAX_SLOTS; i++)
             if (k.slots[i] && k.slots[i].get() != &sl && k.slots[i]->busy) serial = true;
     char* res = sl.results.as<char>();
@@ -355,22 +355,30 @@ int zk_groth16_pk_derive_lagrange(uint64_t handle) {
         if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_derive_lagrange: a proof is in flight on this key");
     HIPCHK(hipDeviceSynchronize());
     Ctx& c = ctx();
-    DevBuf n1, n2;
-    // window 0 of the resident tables IS the key as uploaded (dense affine, pool order)
-    ZKCHK(groth16_derive_lagrange_pools(k.fr, k.g1.table.as<uint8_t>(), k.n_mid, k.g2.table.as<uint8_t>(), n1, n2, c.stream));
-    for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();          // workspaces are sized for the old pools
+    // Everything is built into TEMPORARIES first; the handle changes only after every allocation and launch has succeeded (an OOM while the new
+    // window tables are built -- they are 13-16x the pools -- leaves the key exactly as it was: tau-power pools, tau-power Fr stage, lagrange = false).
+    MsmBases g1, g2;
     const uint64_t p1n = 3 + (uint64_t)k.n + (k.n - 1) + k.n_mid, p2n = 2 + (uint64_t)k.n;
-    k.g1 = MsmBases();
-    k.g2 = MsmBases();
-    const uint32_t cw = key_window(p1n);
-    ZKCHK(msm_bases_from_device_affine(k.g1, CURVE_G1, n1.p, p1n, cw, true, c.stream));
-    ZKCHK(msm_bases_from_device_affine(k.g2, CURVE_G2, n2.p, p2n, cw, true, c.stream));
-    ZKCHK(frstage_init_lagrange(k.fr, c.stream));
+    {
+        DevBuf n1, n2;
+        // window 0 of the resident tables IS the key as uploaded (dense affine, pool order)
+        ZKCHK(groth16_derive_lagrange_pools(k.fr, k.g1.table.as<uint8_t>(), k.n_mid, k.g2.table.as<uint8_t>(), n1, n2, c.stream));
+        const uint32_t cw = key_window(p1n);
+        ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, n1.p, p1n, cw, true, c.stream));
+        ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, n2.p, p2n, cw, true, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));          // n1 / n2 are released here: the table builds have read them
+    }
+    ZKCHK(frstage_init_lagrange(k.fr, c.stream));        // ADDS the Lagrange tables to the Fr stage; the tau-power path keeps working until `lagrange` flips
+    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(hipGetLastError());
+    // ---- commit (nothing below can fail before the key is consistent again)
+    for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();          // workspaces are sized for the old pools
+    k.g1 = std::move(g1);
+    k.g2 = std::move(g2);
     k.lagrange = true;
     k.p1 = p1n; k.p2 = p2n; k.lo1 = 0; k.hi1 = p1n; k.lo2 = 0; k.hi2 = p2n;
-    HIPCHK(hipStreamSynchronize(c.stream));
     Slot* sl;
-    ZKCHK(slot_get(k, 0, &sl));
+    ZKCHK(slot_get(k, 0, &sl));          // on failure the key is valid in Lagrange form; the slot is created at the next use
     return ZK_OK;
 }
 int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
@@ -492,6 +500,18 @@ int zk_groth16_prove_partial_wait(uint64_t handle, uint32_t slot, uint8_t partia
     memcpy(partial, sl.host_partial, ZK_GROTH16_PARTIAL_BYTES);
     return ZK_OK;
 }
+int zk_groth16_prove_partial_wait_device(uint64_t handle, uint32_t slot, void* d_partial) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (!d_partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait_device: null");
+    if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait_device: slot never used");
+    Slot& sl = *k->slots[slot];
+    const int rc = prove_finish(sl);                     // the slot is free again whatever the Fr stage's flags say
+    // results = A | C | B raw XYZZ partial sums, device to device: the block never visits the host
+    HIPCHK(hipMemcpyAsync(d_partial, sl.results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToDevice, sl.s0));
+    HIPCHK(hipStreamSynchronize(sl.s0));
+    return rc;
+}
 int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32],
                              uint8_t partial[ZK_GROTH16_PARTIAL_BYTES]) {
     ZKCHK(zk_groth16_prove_partial_async(handle, sol, r, s, 0));
@@ -575,8 +595,9 @@ static void combine_release() {
     g_combine.world = 0;
 }
 static CleanupRegistrar g_combine_cleanup(combine_release);
-int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[384]) {
-    if (!partials || !proof || world == 0) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_combine: bad argument");
+// partials: `world` blocks of 768 B, block j at partials + j * stride, in HOST memory (from_device = false) or DEVICE memory
+static int combine_impl(const uint8_t* partials, size_t stride, uint32_t world, uint8_t proof[384], bool from_device) {
+    if (!partials || !proof || world == 0 || stride < ZK_GROTH16_PARTIAL_BYTES) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_combine: bad argument");
     ZKCHK(ensure_init());
     Ctx& c = ctx();
     const size_t g1b = xyzz_bytes(CURVE_G1), g2b = xyzz_bytes(CURVE_G2), blk = 2 * g1b + g2b;
@@ -590,22 +611,33 @@ int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[38
         if (!B.host) HIPCHK(hipHostMalloc((void**)&B.host, 384, hipHostMallocDefault));
         B.world = world;
     }
-    HIPCHK(hipMemcpyAsync(B.parts.p, partials, blk * world, hipMemcpyHostToDevice, c.stream));
+    const char* src = (const char*)partials;
+    if (!from_device) {
+        if (stride == blk) HIPCHK(hipMemcpyAsync(B.parts.p, partials, blk * world, hipMemcpyHostToDevice, c.stream));
+        else
+            for (uint32_t j = 0; j < world; j++) HIPCHK(hipMemcpyAsync(B.parts.as<char>() + blk * j, partials + stride * j, blk, hipMemcpyHostToDevice, c.stream));
+        src = B.parts.as<char>();
+        stride = blk;
+    }
     for (uint32_t j = 0; j < world; j++) {     // rank-major blocks -> [rank][A, C] and [rank][B]
-        HIPCHK(hipMemcpyAsync(B.g1p.as<char>() + 2 * g1b * j, B.parts.as<char>() + blk * j, 2 * g1b, hipMemcpyDeviceToDevice, c.stream));
-        HIPCHK(hipMemcpyAsync(B.g2p.as<char>() + g2b * j, B.parts.as<char>() + blk * j + 2 * g1b, g2b, hipMemcpyDeviceToDevice, c.stream));
+        HIPCHK(hipMemcpyAsync(B.g1p.as<char>() + 2 * g1b * j, src + stride * j, 2 * g1b, hipMemcpyDeviceToDevice, c.stream));
+        HIPCHK(hipMemcpyAsync(B.g2p.as<char>() + g2b * j, src + stride * j + 2 * g1b, g2b, hipMemcpyDeviceToDevice, c.stream));
     }
     ZKCHK(xyzz_sum_columns(CURVE_G1, B.sum.p, B.g1p.p, world, 2, c.stream));
     ZKCHK(xyzz_sum_columns(CURVE_G2, B.sum.as<char>() + 2 * g1b, B.g2p.p, world, 1, c.stream));
-    // A, C (G1) -> proof[0..96), proof[288..384); B (G2) -> proof[96..288)
-    char* out = B.out.as<char>();
-    ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, B.sum.p, 1, out, c.stream));
-    ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, B.sum.as<char>() + g1b, 1, out + 288, c.stream));
-    ZKCHK(points_xyzz_to_bytes_dev(CURVE_G2, B.sum.as<char>() + 2 * g1b, 1, out + 96, c.stream));
+    // A, C (G1) -> proof[0..96), proof[288..384); B (G2) -> proof[96..288): one launch, the three inversions side by side
+    const uint32_t o1[2] = {0, 288}, o2[1] = {96};
+    ZKCHK(proof_points_to_bytes_dev(B.sum.p, 2, o1, B.sum.as<char>() + 2 * g1b, 1, o2, B.out.p, c.stream));
     HIPCHK(hipMemcpyAsync(B.host, B.out.p, 384, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     memcpy(proof, B.host, 384);
     return ZK_OK;
+}
+int zk_groth16_combine(const uint8_t* partials, uint32_t world, uint8_t proof[384]) {
+    return combine_impl(partials, ZK_GROTH16_PARTIAL_BYTES, world, proof, false);
+}
+int zk_groth16_combine_device(const void* d_partials, size_t stride_bytes, uint32_t world, uint8_t proof[384]) {
+    return combine_impl((const uint8_t*)d_partials, stride_bytes, world, proof, true);
 }
 int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out) {
     Groth16Key* k;

@@ -23,6 +23,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <type_traits>
 
 namespace zk {
@@ -159,8 +160,8 @@ struct DigitArgs {
     uint32_t coarse_shift;  // two-level sort, level 1: histogram / rank by bucket >> coarse_shift and emit (bucket, reference) records
     uint32_t scalar_major;  // LDS sorts: a workgroup owns a range of SCALARS and files all their digits (each scalar is read once per pass,
                             // not once per window: 13-16x less scalar traffic in the two passes); 0: a range of (scalar, window) pairs, window-major
-    uint32_t alias_windows; // EXPERIMENT (ZK_EXPERIMENT_TABLE_ALIAS=1, results WRONG): every window reads window 0's table entries --
-                            // same additions, same number of gathers, 1/16 of the table footprint: what the 16x table traffic costs
+    uint32_t alias_windows; // EXPERIMENT, compiled in only with -DZK_EXPERIMENTS (scripts/table_alias_ab.sh; results WRONG by design): every window
+                            // reads window 0's table entries -- same additions and gathers, 1/16 of the table footprint.  Always 0 in the shipped library.
 };
 // scalar i plus the recoding constant (9 words); false: the scalar is zero or its base is the identity -- no digit of it enters a bucket
 FF_INLINE bool digits_prepare(const uint32_t* __restrict__ scalars, uint64_t i, const DigitArgs& a, uint32_t s[9]) {
@@ -198,7 +199,11 @@ FF_INLINE bool digit_at(const uint32_t s[9], uint64_t i, uint32_t j, const Digit
     const uint32_t neg = e < bias ? 1u : 0u;
     const uint32_t d = neg ? bias - e : e - bias;
     key = (a.precomp ? 0u : j * a.nb_per_window) + (d - 1);
+#ifdef ZK_EXPERIMENTS
     val = (uint32_t)(a.precomp && !a.alias_windows ? (uint64_t)j * a.n + i : i) | (neg << 31);
+#else
+    val = (uint32_t)(a.precomp ? (uint64_t)j * a.n + i : i) | (neg << 31);
+#endif
     return true;
 }
 // Wave-aggregated atomic increment.  Boolean-heavy witnesses put a large share of the digits into ONE bucket
@@ -849,6 +854,19 @@ __global__ __launch_bounds__(128) void k_fixed_base_mul(uint8_t* __restrict__ ou
     aff_store<F>(out + AB * i, xyzz_to_aff(acc));
 }
 
+// Work counters of one product's accumulate launch (profiling level 2 only: bench.py's ALU model counts the additions that really run).
+// out[0] = sorted entries, out[1] = non-empty buckets, out[2] = runs that start on a chunk border, out[3] = runs that start on step 1 of a chunk.
+__global__ void k_acc_stats(const uint32_t* __restrict__ offsets, uint32_t nb, uint32_t chunk, unsigned long long* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) atomicAdd(&out[0], (unsigned long long)offsets[nb]);
+    if (k >= nb) return;
+    const uint32_t s = offsets[k], e = offsets[k + 1];
+    if (e == s) return;
+    atomicAdd(&out[1], 1ull);
+    if (s % chunk == 0) atomicAdd(&out[2], 1ull);
+    if (s % chunk == 1) atomicAdd(&out[3], 1ull);
+}
+
 // ================================================================== host side
 static inline dim3 grid_for(uint64_t n, unsigned threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
 static inline DigitPlan digit_plan(uint32_t c) {
@@ -891,7 +909,7 @@ template <class F> static int bases_finish(MsmBases& b, hipStream_t s) {
 static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool precomp) {
     if (n == 0) ZK_FAIL(ZK_ERR_ARG, "msm: empty base set");
     if (c == 0) {
-        const char* e = getenv("ZK_MSM_WINDOW");         // window-size sweeps (BASELINE config 3)
+        const char* e = getenv("ZK_MSM_WINDOW");         // window-size sweeps (BASELINE config 3); key set-up, not a per-proof path
         c = e ? (uint32_t)atoi(e) : msm_auto_window(n, precomp);
     }
     if (c < 2 || c > 22) ZK_FAIL(ZK_ERR_ARG, "msm: window_bits must be in [2, 22]");
@@ -1071,8 +1089,13 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
     // the window-major ranges
     static const bool want_sm = !(getenv("ZK_SORT_SCALAR_MAJOR") && atoi(getenv("ZK_SORT_SCALAR_MAJOR")) == 0);
     const bool sm = want_sm && b.precomp && w.sort_wgs != 0;
+#ifdef ZK_EXPERIMENTS
+    static const uint32_t alias = (getenv("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(getenv("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u;
+#else
+    const uint32_t alias = 0u;
+#endif
     DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}, b.precomp ? b.ident.as<uint8_t>() : nullptr,
-                 0u, sm ? 1u : 0u, (getenv("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(getenv("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u};
+                 0u, sm ? 1u : 0u, alias};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
         uint32_t off = j * b.c, wd = off >> 5, sh = off & 31;
@@ -1148,6 +1171,27 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             for (uint32_t i = 0; i < count; i++) { ws[i]->red_offsets = ws[i]->offsets.as<uint32_t>(); ws[i]->red_chunk = ws[i]->chunk; }
             ZKCHK(msm_accumulate_launch(b.curve, w.nthreads, b.table.p, aj, count, w.nbuckets, w.chunk, s));
         }
+    }
+    if (ctx().profiling >= 2 && !rounds) {
+        // what the launch really did (un-overlapped measurement pass only: this synchronises): chunks = lanes that ran, copies = first entries of a
+        // chunk or of a run (no product), second steps = the 6-product addition of two affine points, everything else a full mixed addition
+        DevBuf st;
+        ZKCHK(st.alloc(32));
+        unsigned long long h[4], tot[4] = {0, 0, 0, 0}, chunks = 0;
+        for (uint32_t i = 0; i < count; i++) {
+            HIPCHK(hipMemsetAsync(st.p, 0, 32, s));
+            hipLaunchKernelGGL(k_acc_stats, grid_for(w.nbuckets, 256), dim3(256), 0, s, (const uint32_t*)ws[i]->offsets.as<uint32_t>(), w.nbuckets, w.chunk, st.as<unsigned long long>());
+            HIPCHK(hipMemcpyAsync(h, st.p, 32, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (int q = 0; q < 4; q++) tot[q] += h[q];
+            chunks += (h[0] + w.chunk - 1) / w.chunk;
+        }
+        const char* f = b.curve == CURVE_G1 ? "msm_accumulate_g1" : "msm_accumulate_g2";
+        const unsigned long long copies = chunks + tot[1] - tot[2], second = chunks > tot[3] ? chunks - tot[3] : 0;
+        profile_count((std::string(f) + ":entries").c_str(), tot[0]);
+        profile_count((std::string(f) + ":copies").c_str(), copies);
+        profile_count((std::string(f) + ":second_steps").c_str(), second);
+        profile_count((std::string(f) + ":full_additions").c_str(), tot[0] > copies + second ? tot[0] - copies - second : 0);
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;

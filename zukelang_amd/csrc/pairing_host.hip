@@ -12,7 +12,7 @@
 // c0.c0.a, c0.c0.b, c0.c1.a, ... c1.c2.b as 48-byte big-endian integers = 576 B.
 #include "../../include/zkmi355x.h"
 #include "pairing_consts.h"
-#include "zk_common.h"
+#include "zk_err.h"
 
 #include <string.h>
 #include <vector>

@@ -3,10 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
 #include "../../include/zkmi355x.h"
+#include "zk_err.h"
 
 namespace zk {
 
@@ -29,24 +31,18 @@ struct Ctx {
     int profiling = 0;                 // 0 off, 1 = the dominant (accumulate) kernels only, 2 = every family
     std::vector<hipEvent_t> event_pool; // recycled events: hipEventCreate costs tens of microseconds
     std::vector<KernelTimer> timers;
+    std::vector<std::pair<std::string, uint64_t>> counters;   // work counters collected with profiling level 2 (zk_profile_counter)
     std::string last_error;
 };
 Ctx& ctx();
-int set_error(int code, const char* what, const char* file, int line);
 int ensure_init();
 std::vector<void (*)()>& cleanup_hooks();   // run by zk_shutdown before the streams die
 struct CleanupRegistrar { explicit CleanupRegistrar(void (*f)()) { cleanup_hooks().push_back(f); } };
 
-#define ZK_FAIL(code, what) return ::zk::set_error((code), (what), __FILE__, __LINE__)
 #define HIPCHK(expr)                                                                      \
     do {                                                                                  \
         hipError_t _e = (expr);                                                           \
         if (_e != hipSuccess) return ::zk::set_error(ZK_ERR_HIP, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-#define ZKCHK(expr)                 \
-    do {                            \
-        int _rc = (expr);           \
-        if (_rc != ZK_OK) return _rc; \
     } while (0)
 
 // RAII device buffer
@@ -82,6 +78,15 @@ struct ScopedTimer {
     ScopedTimer(const char* name, hipStream_t stream, int level = 2);
     ~ScopedTimer();
 };
+
+void profile_count(const char* name, uint64_t add);      // no-op unless profiling level 2 is on
+
+// Environment knobs are read ONCE per process (tuning / test switches; a getenv per launch is a libc lock + string scan on the proof's hot path).
+static inline const char* env_once(const char* name, const char** cache, bool* done) {
+    if (!*done) { *cache = getenv(name); *done = true; }
+    return *cache;
+}
+#define ZK_ENV(name) ([]() -> const char* { static const char* v = nullptr; static bool d = false; return ::zk::env_once(name, &v, &d); }())
 
 static inline uint32_t ceil_log2(uint64_t x) {
     uint32_t l = 0;

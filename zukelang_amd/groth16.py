@@ -331,9 +331,7 @@ class Groth16:
         else:
             part = np.zeros(768, dtype=np.uint8)
             rc = _lib.lib().zk_groth16_prove_partial(self.handle, _p(w) if w is not None else None, _p(rb), _p(sb), _p(part))
-            if rc == 0:          # the Fr stage is replicated on this path: a bad witness fails on every rank at once
-                gathered = all_gather_bytes(part, self.world)
-                rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
+            rc = self._exchange_and_combine(rc, part, out)
         if rc == ZK_ERR_REMAINDER:
             raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
         _lib.check(rc)
@@ -371,14 +369,26 @@ class Groth16:
             part = np.zeros(768, dtype=np.uint8)
             rc = _lib.lib().zk_groth16_prove_partial_wait(self.handle, C.c_uint32(slot), _p(part))
             getattr(self, "_inflight", {}).pop(slot, None)
-            if rc == 0:
-                gathered = all_gather_bytes(part, self.world)
-                rc = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
+            rc = self._exchange_and_combine(rc, part, out)
         if rc == ZK_ERR_REMAINDER:
             raise AssertionError("Polynomial.is_zero rem")      # QAP.ml:134
         _lib.check(rc)
         b = bytes(out)
         return Proof(b[:96], b[96:288], b[288:])
+
+    def _exchange_and_combine(self, rc, part, out):
+        """The collective half of a sharded proof with the Fr stage replicated: all ranks agree on the local return codes BEFORE the all-gather
+        (a failure only one rank sees -- a HIP error in its MSM slice -- must not leave its peers waiting in the collective) and again after
+        the combine; every rank gets the same code back and raises the same exception, or none does."""
+        local = rc
+        rc = agree_on_status(rc)
+        if rc == 0:
+            gathered = all_gather_bytes(part, self.world)
+            local = _lib.lib().zk_groth16_combine(_p(gathered), C.c_uint32(self.world), _p(out))
+            rc = agree_on_status(local)
+        if rc != 0 and rc != ZK_ERR_REMAINDER and local != rc:
+            raise _lib.ZkError(rc, "a peer rank failed in this proof's products or combine")
+        return rc
 
     def prove_partial(self, w, rb, sb):
         part = np.zeros(768, dtype=np.uint8)
@@ -479,10 +489,22 @@ class GroupProver:
         self.full = [[torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p1, **u8), torch.zeros(32 * self.p2, **u8)] for _ in range(self.K)]
         self.recv = [[[torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len1, **u8), torch.zeros(W * self.len2, **u8)] for _ in range(self.K)] for _ in range(2)]
         self.recvA = [torch.zeros(W * self.lenA if self.clipA else 0, **u8) for _ in range(self.K)]      # compact landing buffer of the clipped A slices
+        # the partial sums of a round: [proof][768] on this rank, [rank][proof][768] after the all-gather (RCCL path: device resident)
+        self.parts_dev = torch.zeros(self.batch * 768, **u8)
+        self.gathered_dev = torch.zeros(W * self.batch * 768, **u8)
         self.count = 0                              # proofs handled so far: proof i of the job belongs to rank i % world
         self.rounds_done = 0                        # parity of the slot set / landing buffers the next round uses
         prover.reserve_slots(self.fr0 + self.K)
         torch.cuda.current_stream().synchronize()
+
+    def _raise_together(self, local, what):
+        """All ranks exchange their worst local return code; every rank raises (its own error, or a note that a peer failed) or none does."""
+        worst = agree_on_status(local)
+        if worst == 0:
+            return
+        if local == worst:
+            _lib.check(worst)
+        raise _lib.ZkError(worst, "a peer rank failed in %s" % what)
 
     def _launch_fr(self, rnd, base):
         """rnd: list of (r, s), at most `batch`; proof t of the round belongs to rank (base + t) % world.
@@ -537,50 +559,85 @@ class GroupProver:
         proofs = []
 
         def collect(cnt, base, slot0):
-            """wait for the products of one round, all-gather its partial sums, combine"""
-            parts = np.zeros((self.batch, 768), dtype=np.uint8)
-            for t in range(cnt):
-                _lib.check(L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(slot0 + t), _p(parts[t])))
-            gathered = all_gather_bytes(parts.reshape(-1), W).reshape(W, self.batch, 768)        # [rank][proof]
+            """wait for the products of one round, all-gather its partial sums, combine.  Over RCCL the 768-byte blocks never leave the GPUs:
+            slot buffer -> device tensor -> all_gather_into_tensor -> zk_groth16_combine_device; over gloo (CPU tests, rehearsal on a shared
+            GPU) they travel as host bytes.  The ranks agree on the worst return code before the all-gather and after the combines."""
+            import torch.distributed as dist
+            torch = self.torch
+            on_device = dist.get_backend() == "nccl"
+            worst = 0
+            if on_device:
+                parts = self.parts_dev
+                for t in range(cnt):
+                    worst = min(worst, L.zk_groth16_prove_partial_wait_device(self.p.handle, C.c_uint32(slot0 + t), C.c_void_p(parts.data_ptr() + 768 * t)))
+            else:
+                parts = np.zeros((self.batch, 768), dtype=np.uint8)
+                for t in range(cnt):
+                    worst = min(worst, L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(slot0 + t), _p(parts[t])))
+            self._raise_together(worst, "the products of this round")
+            if on_device:
+                dist.all_gather_into_tensor(self.gathered_dev, parts)            # [rank][proof][768], device to device over xGMI
+                torch.cuda.current_stream().synchronize()
+            else:
+                gathered = all_gather_bytes(parts.reshape(-1), W).reshape(W, self.batch, 768)        # [rank][proof]
+            worst = 0
             for t in range(cnt):
                 if not combine_all and (base + t) % W != self.rank:
                     proofs.append(None)
                     continue
                 out = np.zeros(384, dtype=np.uint8)
-                blk = np.ascontiguousarray(gathered[:, t, :]).reshape(-1)
-                _lib.check(L.zk_groth16_combine(_p(blk), C.c_uint32(W), _p(out)))
+                if on_device:
+                    rc = L.zk_groth16_combine_device(C.c_void_p(self.gathered_dev.data_ptr() + 768 * t), C.c_size_t(768 * self.batch), C.c_uint32(W), _p(out))
+                else:
+                    blk = np.ascontiguousarray(gathered[:, t, :]).reshape(-1)
+                    rc = L.zk_groth16_combine(_p(blk), C.c_uint32(W), _p(out))
+                worst = min(worst, rc)
                 b = bytes(out)
                 proofs.append(Proof(b[:96], b[96:288], b[288:]))
+            self._raise_together(worst, "the combine of this round")
 
-        launched = self._launch_fr(rounds[0], bases[0]) if rounds else []
-        pending = None                          # the round whose products are in flight: (count, base, first slot)
-        for ri, rnd in enumerate(rounds):
-            cnt, base = len(rnd), bases[ri]
-            half = self.rounds_done & 1
-            rv_set = self.recv[half]
-            try:
+        # what is enqueued and not yet waited for -- on ANY exception below (all of them are raised on every rank together, _raise_together /
+        # agree_on_status) these slots are drained so that none stays busy and the prover remains usable; their results are dropped everywhere
+        state = {"fr": [], "msm": []}           # Fr slots launched (indices k); MSM rounds in flight: (count, first slot)
+
+        def drain():
+            scratch = np.zeros(768, dtype=np.uint8)
+            for k in state["fr"]:
+                L.zk_groth16_scalars_wait(self.p.handle, C.c_uint32(self.fr0 + k))
+            for cnt_, slot0_ in state["msm"]:
+                for t in range(cnt_):
+                    L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(slot0_ + t), _p(scratch))
+            state["fr"], state["msm"] = [], []
+
+        try:
+            state["fr"] = self._launch_fr(rounds[0], bases[0]) if rounds else []
+            pending = None                          # the round whose products are in flight: (count, base, first slot)
+            for ri, rnd in enumerate(rounds):
+                cnt, base = len(rnd), bases[ri]
+                half = self.rounds_done & 1
+                rv_set = self.recv[half]
+                launched, state["fr"] = state["fr"], []          # _finish_fr_and_exchange waits for every slot it is given, whatever the codes
                 self._finish_fr_and_exchange(launched, cnt, rv_set)
-            except BaseException:
-                # every rank raises here together (agree_on_status); the previous round's products are still in flight: drain them, the
-                # slots must not stay busy (the prover remains usable), their partial sums are dropped on every rank alike
+                if ri + 1 < len(rounds):
+                    state["fr"] = self._launch_fr(rounds[ri + 1], bases[ri + 1])      # overlaps with this round's and the previous round's products
+                slot0 = half * self.batch
+                state["msm"].append((0, slot0))
+                for t in range(cnt):
+                    k, owner = t // W, (base + t) % W
+                    rv = rv_set[k]
+                    _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(slot0 + t), C.c_void_p(rv[0].data_ptr() + owner * self.len1),
+                                                              C.c_void_p(rv[1].data_ptr() + owner * self.len1), C.c_void_p(rv[2].data_ptr() + owner * self.len2)))
+                    state["msm"][-1] = (t + 1, slot0)
+                self.rounds_done += 1
                 if pending is not None:
-                    scratch = np.zeros(768, dtype=np.uint8)
-                    for t in range(pending[0]):
-                        L.zk_groth16_prove_partial_wait(self.p.handle, C.c_uint32(pending[2] + t), _p(scratch))
-                raise
-            if ri + 1 < len(rounds):
-                launched = self._launch_fr(rounds[ri + 1], bases[ri + 1])      # overlaps with this round's and the previous round's products
-            slot0 = half * self.batch
-            for t in range(cnt):
-                k, owner = t // W, (base + t) % W
-                rv = rv_set[k]
-                _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(slot0 + t), C.c_void_p(rv[0].data_ptr() + owner * self.len1),
-                                                          C.c_void_p(rv[1].data_ptr() + owner * self.len1), C.c_void_p(rv[2].data_ptr() + owner * self.len2)))
-            self.rounds_done += 1
+                    state["msm"].pop(0)             # collect waits for every slot of that round itself
+                    collect(*pending)               # the previous round: its products ran while this round's Fr stages and exchange did
+                pending = (cnt, base, slot0)
             if pending is not None:
-                collect(*pending)               # the previous round: its products ran while this round's Fr stages and exchange did
-            pending = (cnt, base, slot0)
-        if pending is not None:
-            collect(*pending)
+                state["msm"].pop(0)
+                collect(*pending)
+        except BaseException:
+            drain()
+            raise
         self.count = c
         return proofs

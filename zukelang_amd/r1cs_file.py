@@ -108,8 +108,8 @@ def read_r1cs(path):
             raise ValueError(".r1cs: truncated variable name")
         names.append((data[pos:pos + ln].decode("latin-1"), vid))      # byte order = code-point order: String.compare
         pos += ln
-    if names != sorted(names):
-        raise ValueError(".r1cs: variables are not in Var.compare order")       # polymorphic compare on (string * int)
+    if any(a >= b for a, b in zip(names, names[1:])):
+        raise ValueError(".r1cs: variables are not in STRICT Var.compare order (duplicate or misordered (name, id))")       # polymorphic compare on (string * int)
     pos += -pos % 8
     if pos + m > len(data):
         raise ValueError(".r1cs: truncated mid flags")

@@ -39,7 +39,7 @@ def json_bytes_string(b):
 def dumps(v):
     """Python value -> JSON bytes: dict (insertion order) / list / tuple / int / bytes (raw string) / str."""
     if isinstance(v, dict):
-        return b"{" + b",".join(json_bytes_string(k.encode()) + b":" + dumps(x) for k, x in v.items()) + b"}"
+        return b"{" + b",".join(json_bytes_string(k.encode("latin-1")) + b":" + dumps(x) for k, x in v.items()) + b"}"
     if isinstance(v, (list, tuple)):
         return b"[" + b",".join(dumps(x) for x in v) + b"]"
     if isinstance(v, bool):
@@ -47,14 +47,43 @@ def dumps(v):
     if isinstance(v, int):
         return str(v).encode()
     if isinstance(v, str):
-        return json_bytes_string(v.encode())
+        return json_bytes_string(v.encode("latin-1"))       # names are BYTE strings (OCaml string): one code point per byte, as Yojson writes them
     return json_bytes_string(bytes(v))
 
 
 def loads(data):
-    """JSON bytes -> dict / list / int / bytes (every string comes back as bytes)."""
-    data = bytes(data)
+    """JSON bytes -> dict / list / int / bytes (every string comes back as bytes; record field names as latin-1 str).
+    Malformed input raises ValueError (never an assert: `python -O` must not turn the parser permissive)."""
+    try:
+        return _loads_body(bytes(data))
+    except (IndexError, KeyError) as e:
+        raise ValueError("JSON: truncated or malformed input (%s)" % type(e).__name__) from None
+
+
+def _reader(fn):
+    """A record reader fed something that is not the record (missing field, wrong nesting) raises ValueError like the parser itself."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(data):
+        try:
+            return fn(data)
+        except (KeyError, IndexError, TypeError, AttributeError) as e:
+            raise ValueError("wire: not a %s record (%s: %s)" % (fn.__name__.replace("_of_json", ""), type(e).__name__, e)) from None
+    return wrapped
+
+
+def _need(cond, what):
+    if not cond:
+        raise ValueError("wire: " + what)
+
+
+def _loads_body(data):
     pos = 0
+
+    def need(cond, what):
+        if not cond:
+            raise ValueError("JSON: %s at byte %d" % (what, pos))
 
     def ws():
         nonlocal pos
@@ -74,16 +103,16 @@ def loads(data):
                 return out
             while True:
                 ws()
-                k = string().decode()
+                k = string().decode("latin-1")
                 ws()
-                assert data[pos] == 0x3A
+                need(data[pos] == 0x3A, "':' expected")
                 pos += 1
                 out[k] = value()
                 ws()
                 pos += 1
                 if data[pos - 1] == 0x7D:
                     return out
-                assert data[pos - 1] == 0x2C
+                need(data[pos - 1] == 0x2C, "',' expected")
         if c == 0x5B:       # [
             pos += 1
             out = []
@@ -97,17 +126,18 @@ def loads(data):
                 pos += 1
                 if data[pos - 1] == 0x5D:
                     return out
-                assert data[pos - 1] == 0x2C
+                need(data[pos - 1] == 0x2C, "',' expected")
         if c == 0x22:
             return string()
         start = pos
         while pos < len(data) and data[pos] in b"+-0123456789":
             pos += 1
+        need(pos > start, "value expected")
         return int(data[start:pos])
 
     def string():
         nonlocal pos
-        assert data[pos] == 0x22
+        need(data[pos] == 0x22, "string expected")
         pos += 1
         out = bytearray()
         while data[pos] != 0x22:
@@ -128,7 +158,7 @@ def loads(data):
 
     v = value()
     ws()
-    assert pos == len(data), "trailing bytes after the JSON value"
+    need(pos == len(data), "trailing bytes after the JSON value")
     return v
 
 
@@ -151,6 +181,7 @@ def groth16_proof_to_json(proof):
     return dumps({"a": G1.to_compressed_bytes(proof.a), "b": G2.to_compressed_bytes(proof.b), "c": G1.to_compressed_bytes(proof.c)})
 
 
+@_reader
 def groth16_proof_of_json(data):
     from .groth16 import Proof
     d = loads(data)
@@ -160,18 +191,19 @@ def groth16_proof_of_json(data):
 def groth16_vkey_to_json(vk, io_vars):
     """io_vars: the (name, id) of the public variables in key order (Var.Map order = the order of vk.ltgm_io)."""
     lt = bytes(vk.ltgm_io)
-    assert len(lt) == 96 * len(io_vars)
+    _need(len(lt) == 96 * len(io_vars), "key / record lengths or variable domains do not match")
     return dumps({"one1": G1.to_compressed_bytes(vk.one1),
                   "ltgm_io": [[[name, vid], G1.to_compressed_bytes(lt[96 * i:96 * i + 96])] for i, (name, vid) in enumerate(io_vars)],
                   "one2": G2.to_compressed_bytes(vk.one2), "gm": G2.to_compressed_bytes(vk.gm), "d": G2.to_compressed_bytes(vk.d),
                   "ab": bytes(vk.ab)})
 
 
+@_reader
 def groth16_vkey_of_json(data):
     from .groth16 import VKey
     import numpy as np
     d = loads(data)
-    io_vars = [(b[0][0].decode(), b[0][1]) for b in d["ltgm_io"]]
+    io_vars = [(b[0][0].decode("latin-1"), b[0][1]) for b in d["ltgm_io"]]
     lt = b"".join(g1_of_json(b[1]) for b in d["ltgm_io"])
     vk = VKey(g1_of_json(d["one1"]), np.frombuffer(lt, dtype=np.uint8), g2_of_json(d["one2"]), g2_of_json(d["gm"]), g2_of_json(d["d"]), d["ab"])
     return vk, io_vars
@@ -184,13 +216,14 @@ def groth16_pkey_to_json(pk, n, mid_vars):
     p2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
     o_ti, o_tz = 3, 3 + (n + 2)
     o_lt = o_tz + (n - 1)
-    assert len(g1) == 96 * (o_lt + len(mid_vars)) and len(g2) == 192 * (2 + n + 2)
+    _need(len(g1) == 96 * (o_lt + len(mid_vars)) and len(g2) == 192 * (2 + n + 2), "key / record lengths or variable domains do not match")
     return dumps({"a": p1(0), "d1": p1(1), "ti1": [p1(o_ti + i) for i in range(n + 2)],
                   "ltd_mid": [[[name, vid], p1(o_lt + i)] for i, (name, vid) in enumerate(mid_vars)],
                   "tiztd": [p1(o_tz + i) for i in range(n - 1)], "b1": p1(2), "b2": p2(0), "d2": p2(1),
                   "ti2": [p2(2 + i) for i in range(n + 2)]})
 
 
+@_reader
 def groth16_pkey_of_json(data):
     from .groth16 import PKey
     import numpy as np
@@ -198,7 +231,7 @@ def groth16_pkey_of_json(data):
     g1 = [g1_of_json(d["a"]), g1_of_json(d["d1"]), g1_of_json(d["b1"])] + [g1_of_json(x) for x in d["ti1"]] + \
          [g1_of_json(x) for x in d["tiztd"]] + [g1_of_json(b[1]) for b in d["ltd_mid"]]
     g2 = [g2_of_json(d["b2"]), g2_of_json(d["d2"])] + [g2_of_json(x) for x in d["ti2"]]
-    mid_vars = [(b[0][0].decode(), b[0][1]) for b in d["ltd_mid"]]
+    mid_vars = [(b[0][0].decode("latin-1"), b[0][1]) for b in d["ltd_mid"]]
     return PKey(np.frombuffer(b"".join(g1), dtype=np.uint8), np.frombuffer(b"".join(g2), dtype=np.uint8)), mid_vars
 
 
@@ -210,6 +243,7 @@ def pinocchio_proof_to_json(proof):
     return dumps({f: (G1 if g == 1 else G2).to_compressed_bytes(getattr(proof, f)) for f, g in _PIN_FIELDS})
 
 
+@_reader
 def pinocchio_proof_of_json(data):
     from .pinocchio import Proof
     d = loads(data)
@@ -220,6 +254,7 @@ def fr_to_json(x):
     return dumps(str(int(x)))        # Z.yojson_of_t: the decimal string
 
 
+@_reader
 def fr_of_json(data):
     return int(loads(data).decode())
 
@@ -236,7 +271,7 @@ def pinocchio_pkey_to_json(pk, n, mid_vars, all_vars):
     """mid_vars: (name, id) of circuit.mids in Var.Map order; all_vars: every variable (the domain of v_all / w_all)."""
     g1, g2 = bytes(pk.g1), bytes(pk.g2)
     k, m = len(mid_vars), len(all_vars)
-    assert len(g1) == 96 * (5 * k + (n + 1) + 2 * m + 7) and len(g2) == 192 * (2 * k + (n + 1) + 2)
+    _need(len(g1) == 96 * (5 * k + (n + 1) + 2 * m + 7) and len(g2) == 192 * (2 * k + (n + 1) + 2), "key / record lengths or variable domains do not match")
     c1 = lambda i: G1.to_compressed_bytes(g1[96 * i:96 * i + 96])
     c2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
     r1 = lambda o, cnt: [c1(o + i) for i in range(cnt)]
@@ -255,6 +290,7 @@ def pinocchio_pkey_to_json(pk, n, mid_vars, all_vars):
                   "v_all": _vmap(all_vars, r1(o_va, m), ident), "w_all": _vmap(all_vars, r1(o_wa, m), ident)})
 
 
+@_reader
 def pinocchio_pkey_of_json(data):
     """-> (pinocchio.PKey, n, mid_vars, all_vars)"""
     from .pinocchio import PKey
@@ -265,8 +301,8 @@ def pinocchio_pkey_of_json(data):
     m2 = lambda f: [g2_of_json(b[1]) for b in d[f]]
     mid_vars, all_vars = vars_of("vv"), vars_of("v_all")
     for f in ("ww", "yy", "vav", "waw", "yay", "bvwy"):
-        assert vars_of(f) == mid_vars, "Pinocchio pkey: the I_mid maps must share one domain"
-    assert vars_of("w_all") == all_vars
+        _need(vars_of(f) == mid_vars, "Pinocchio pkey: the I_mid maps must share one domain")
+    _need(vars_of("w_all") == all_vars, "key / record lengths or variable domains do not match")
     g1 = (m1("vv") + m1("yy") + m1("vav") + m1("yay") + m1("bvwy") + [g1_of_json(x) for x in d["si"]] + m1("v_all") + m1("w_all")
           + [g1_of_json(d[f]) for f in ("vt", "yt", "vavt", "yayt", "vbt", "wbt", "ybt")])
     g2 = m2("ww") + m2("waw") + [g2_of_json(x) for x in d["si2"]] + [g2_of_json(d["wt"]), g2_of_json(d["wawt"])]
@@ -276,7 +312,7 @@ def pinocchio_pkey_of_json(data):
 def pinocchio_vkey_to_json(vk, io_vars):
     g1, g2 = bytes(vk.g1), bytes(vk.g2)
     k = len(io_vars)
-    assert len(g1) == 96 * (3 + 2 * k) and len(g2) == 192 * (6 + k)
+    _need(len(g1) == 96 * (3 + 2 * k) and len(g2) == 192 * (6 + k), "key / record lengths or variable domains do not match")
     c1 = lambda i: G1.to_compressed_bytes(g1[96 * i:96 * i + 96])
     c2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
     ident = lambda x: x
@@ -285,12 +321,13 @@ def pinocchio_vkey_to_json(vk, io_vars):
                   "yy_io": _vmap(io_vars, [c1(3 + k + i) for i in range(k)], ident)})
 
 
+@_reader
 def pinocchio_vkey_of_json(data):
     from .pinocchio import VKey
     import numpy as np
     d = loads(data)
     io_vars = [(b[0][0].decode("latin-1"), b[0][1]) for b in d["vv_io"]]
-    assert [(b[0][0].decode("latin-1"), b[0][1]) for b in d["ww_io"]] == io_vars and [(b[0][0].decode("latin-1"), b[0][1]) for b in d["yy_io"]] == io_vars
+    _need([(b[0][0].decode("latin-1"), b[0][1]) for b in d["ww_io"]] == io_vars and [(b[0][0].decode("latin-1"), b[0][1]) for b in d["yy_io"]] == io_vars, "key / record lengths or variable domains do not match")
     g1 = [g1_of_json(d["one"]), g1_of_json(d["aw"]), g1_of_json(d["bgm"])] + [g1_of_json(b[1]) for b in d["vv_io"]] + [g1_of_json(b[1]) for b in d["yy_io"]]
     g2 = [g2_of_json(d[f]) for f in ("one2", "av", "ay", "gm2", "bgm2", "yt")] + [g2_of_json(b[1]) for b in d["ww_io"]]
     return VKey(np.frombuffer(b"".join(g1), dtype=np.uint8), np.frombuffer(b"".join(g2), dtype=np.uint8)), io_vars
