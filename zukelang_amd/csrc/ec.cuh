@@ -321,6 +321,67 @@ template <class F> FF_INLINE void xyzz_store_raw(void* p, const Xyzz<F>& a) {
     store_raw_f(c + 2 * B, a.zz);
     store_raw_f(c + 3 * B, a.zzz);
 }
+// ---- layout of the RESIDENT BASE TABLES (MsmBases::table): one 128-byte record per lane that reads the entry --
+//      x as its 14 register limbs | y as its 14 register limbs | 16 B of padding, canonical (< p, exact 29-bit limbs).
+//      G1: one record per point (128 B); G2: two records per point (256 B), record c = the c-th Fp2 component of x and of y, i.e. what
+//      lane c of a lane pair keeps.  A gather touches exactly ONE 128-byte cache line per lane (the dense 96-byte entries straddled two
+//      lines at every other index: 1.25-1.5 lines per gather) and the limbs go from memory to the product without repacking.
+//      The identity is all-zero limbs, as everywhere.
+static constexpr int TAB_REC = 128, TAB_REC_WORDS = 2 * FPL;
+template <class F> struct TableLayout;
+template <> struct TableLayout<Fp> { static constexpr int ENTRY = TAB_REC; };
+template <> struct TableLayout<Fp2> { static constexpr int ENTRY = 2 * TAB_REC; };
+template <> struct TableLayout<Fp2H> { static constexpr int ENTRY = 2 * TAB_REC; };
+struct TabRec {          // one record in registers, still untyped: what the accumulate loop keeps in flight for the NEXT step
+    uint32_t w[TAB_REC_WORDS];
+};
+FF_INLINE TabRec tab_rec_load(const uint8_t* rec) {
+    TabRec r;
+    const uint4* q = reinterpret_cast<const uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < TAB_REC_WORDS / 4; i++) {
+        const uint4 x = q[i];
+        r.w[4 * i] = x.x; r.w[4 * i + 1] = x.y; r.w[4 * i + 2] = x.z; r.w[4 * i + 3] = x.w;
+    }
+    return r;
+}
+FF_INLINE void tab_rec_store(uint8_t* rec, const FpB<1>& x, const FpB<1>& y) {
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < FPL; i++) { w[i] = x.v[i]; w[FPL + i] = y.v[i]; }
+#pragma unroll
+    for (int i = TAB_REC_WORDS; i < 32; i++) w[i] = 0;
+    uint4* q = reinterpret_cast<uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+FF_INLINE FpB<1> tab_rec_x(const TabRec& r) {
+    FpB<1> x;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) x.v[i] = r.w[i];
+    return x;
+}
+FF_INLINE FpB<1> tab_rec_y(const TabRec& r) {
+    FpB<1> y;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) y.v[i] = r.w[FPL + i];
+    return y;
+}
+// whole entries (key set-up kernels: one lane per point)
+FF_INLINE void tab_store(uint8_t* entry, const Aff<Fp>& a) { tab_rec_store(entry, fp_canon(a.x), fp_canon(a.y)); }
+FF_INLINE void tab_store(uint8_t* entry, const Aff<Fp2>& a) {
+    tab_rec_store(entry, fp_canon(a.x.c0), fp_canon(a.y.c0));
+    tab_rec_store(entry + TAB_REC, fp_canon(a.x.c1), fp_canon(a.y.c1));
+}
+FF_INLINE Aff<Fp> tab_load(const Fp*, const uint8_t* entry) {
+    const TabRec r = tab_rec_load(entry);
+    return {tab_rec_x(r), tab_rec_y(r)};
+}
+FF_INLINE Aff<Fp2> tab_load(const Fp2*, const uint8_t* entry) {
+    const TabRec r0 = tab_rec_load(entry), r1 = tab_rec_load(entry + TAB_REC);
+    return {{tab_rec_x(r0), tab_rec_x(r1)}, {tab_rec_y(r0), tab_rec_y(r1)}};
+}
+
 // the 4 x 14 limbs one lane holds of a point (a whole G1 point, or one Fp2 component of a G2 point)
 static constexpr int LANE_POINT_WORDS = 4 * FPL;
 FF_INLINE void xyzz_to_words(uint32_t* w, const Xyzz<Fp>& a) {

@@ -360,9 +360,15 @@ int zk_groth16_pk_derive_lagrange(uint64_t handle) {
     MsmBases g1, g2;
     const uint64_t p1n = 3 + (uint64_t)k.n + (k.n - 1) + k.n_mid, p2n = 2 + (uint64_t)k.n;
     {
-        DevBuf n1, n2;
-        // window 0 of the resident tables IS the key as uploaded (dense affine, pool order)
-        ZKCHK(groth16_derive_lagrange_pools(k.fr, k.g1.table.as<uint8_t>(), k.n_mid, k.g2.table.as<uint8_t>(), n1, n2, c.stream));
+        DevBuf n1, n2, d1, d2;
+        // window 0 of the resident tables IS the key as uploaded (pool order): back into the dense affine format the derivation reads
+        ZKCHK(d1.alloc(96 * k.g1.n));
+        ZKCHK(d2.alloc(192 * k.g2.n));
+        ZKCHK(msm_bases_dense(k.g1, 0, k.g1.n, d1.p, c.stream));
+        ZKCHK(msm_bases_dense(k.g2, 0, k.g2.n, d2.p, c.stream));
+        ZKCHK(groth16_derive_lagrange_pools(k.fr, d1.as<uint8_t>(), k.n_mid, d2.as<uint8_t>(), n1, n2, c.stream));
+        d1.release();
+        d2.release();
         const uint32_t cw = key_window(p1n);
         ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, n1.p, p1n, cw, true, c.stream));
         ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, n2.p, p2n, cw, true, c.stream));
@@ -400,8 +406,13 @@ int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
     // window 0 of the resident tables is the pool in order: the rank keeps its contiguous slice and builds its own window tables
     MsmBases g1, g2;
     const uint32_t cw = key_window(hi1 - lo1);
-    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, k.g1.table.as<uint8_t>() + 96 * lo1, hi1 - lo1, cw, true, c.stream));
-    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, k.g2.table.as<uint8_t>() + 192 * lo2, hi2 - lo2, cw, true, c.stream));
+    DevBuf d1, d2;
+    ZKCHK(d1.alloc(96 * (hi1 - lo1)));
+    ZKCHK(d2.alloc(192 * (hi2 - lo2)));
+    ZKCHK(msm_bases_dense(k.g1, lo1, hi1 - lo1, d1.p, c.stream));
+    ZKCHK(msm_bases_dense(k.g2, lo2, hi2 - lo2, d2.p, c.stream));
+    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, d1.p, hi1 - lo1, cw, true, c.stream));
+    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, d2.p, hi2 - lo2, cw, true, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     k.g1 = std::move(g1);
     k.g2 = std::move(g2);
@@ -420,9 +431,11 @@ int zk_groth16_pool_points(uint64_t handle, int group, uint8_t* out, size_t capa
     if (!out) return ZK_OK;
     if (capacity_points < b.n) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pool_points: buffer too small");
     Ctx& c = ctx();
-    DevBuf bytes;
+    DevBuf bytes, dense;
     ZKCHK(bytes.alloc(aff_bytes(b.curve) * b.n));
-    ZKCHK(points_affine_to_bytes(b.curve, bytes.p, b.table.p, b.n, c.stream));
+    ZKCHK(dense.alloc(aff_bytes(b.curve) * b.n));
+    ZKCHK(msm_bases_dense(b, 0, b.n, dense.p, c.stream));
+    ZKCHK(points_affine_to_bytes(b.curve, bytes.p, dense.p, b.n, c.stream));
     HIPCHK(hipMemcpyAsync(out, bytes.p, aff_bytes(b.curve) * b.n, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     return ZK_OK;

@@ -19,7 +19,7 @@ struct MsmBases {
     uint32_t c = 0;          // window bits
     uint32_t nw = 0;         // windows
     bool precomp = false;    // table holds 2^(c*j) * P_i for j < nw at [j*n + i]; one bucket set
-    DevBuf table;            // affine Montgomery points
+    DevBuf table;            // affine Montgomery points in the 128-byte record layout of ec.cuh (TableLayout): canonical limbs, one cache line per lane and gather
     DevBuf ident;            // precomp: one byte per point, 1 = the base is the identity (the sort never files it into a bucket)
 };
 
@@ -53,7 +53,10 @@ struct MsmWorkspace {
 
 uint32_t msm_auto_window(uint64_t n, bool precomp);
 int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
+// d_affine: n DENSE affine points (96 / 192 B each); it must stay valid until the stream has run the table build
 int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
+// base points [lo, lo + count) of the set (window 0 of the table) back in the dense affine format, exact
+int msm_bases_dense(const MsmBases& b, uint64_t lo, uint64_t count, void* d_dense, hipStream_t s);
 // max_nonzero: upper bound of the non-zero scalars this workspace's products ever carry (0 = all of b.n): sizes the batch-affine buffers
 int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero = 0);
 // d_scalars: n canonical (non-Montgomery) Fr, 32 B each, on device.  d_result: one XYZZ point.

@@ -121,27 +121,37 @@ __global__ __launch_bounds__(64) void k_proof_to_bytes(const uint8_t* g1, uint32
     else aff_encode(out + off.g2[b - n1], xyzz_to_aff(xyzz_load<Fp2>(g2 + 384 * (size_t)(b - n1))));
 }
 
-// ------------------------------------------------------------------ precomputation: table[j*n + i] = 2^(c*j) * P_i
-template <class F> __global__ void k_precompute(uint8_t* table, uint64_t n, uint32_t c, uint32_t nw) {
+// ------------------------------------------------------------------ base tables: table[j*n + i] = 2^(c*j) * P_i, j < nw
+// `dense` holds the n base points in the dense affine format (what the key arrived as); the table takes them -- and with nw > 1 their
+// multiples by 2^(c j) -- in the 128-byte record layout of ec.cuh (TableLayout).
+template <class F> __global__ void k_precompute(uint8_t* table, const uint8_t* __restrict__ dense, uint64_t n, uint32_t c, uint32_t nw) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    constexpr int B = FieldOps<F>::WORDS * 8;
-    Aff<F> p = aff_load<F>(table + B * i);
+    constexpr int B = FieldOps<F>::WORDS * 8, TB = TableLayout<F>::ENTRY;
+    Aff<F> p = aff_load<F>(dense + B * i);
+    tab_store(table + TB * i, p);
     for (uint32_t j = 1; j < nw; j++) {
         Xyzz<F> q = xyzz_dbl_aff(p);
         for (uint32_t k = 1; k < c; k++) q = xyzz_dbl(q);
         p = xyzz_to_aff(q);
-        aff_store<F>(table + B * ((uint64_t)j * n + i), p);
+        tab_store(table + TB * ((uint64_t)j * n + i), p);
     }
+}
+// window 0 of a table back in the dense affine format (key derivation, re-sharding, zk_*_pool_points): exact -- the records hold canonical limbs
+template <class F> __global__ void k_table_to_dense(uint8_t* __restrict__ dense, const uint8_t* __restrict__ table, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int B = FieldOps<F>::WORDS * 8, TB = TableLayout<F>::ENTRY;
+    aff_store<F>(dense + B * i, tab_load((const F*)nullptr, table + TB * i));
 }
 
 // flags[i] = 1 iff base i is the identity (its table entries 2^(cj) P are the identity for every window, and only those:
 // neither curve has points of even order)
-template <class F> __global__ void k_ident_flags(uint8_t* flags, const uint8_t* table, uint64_t n) {
+template <class F> __global__ void k_ident_flags(uint8_t* flags, const uint8_t* dense, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     constexpr int B = FieldOps<F>::WORDS * 8;
-    const uint4* q = reinterpret_cast<const uint4*>(table + B * i);
+    const uint4* q = reinterpret_cast<const uint4*>(dense + B * i);
     uint32_t o = 0;
     for (int k = 0; k < B / 16; k++) { const uint4 x = q[k]; o |= x.x | x.y | x.z | x.w; }
     flags[i] = o == 0 ? 1 : 0;
@@ -894,16 +904,24 @@ uint32_t msm_auto_window(uint64_t n, bool precomp) {
     return bc;
 }
 
-template <class F> static int bases_finish(MsmBases& b, hipStream_t s) {
+template <class F> static int bases_finish(MsmBases& b, const void* d_dense, hipStream_t s) {
     if (b.precomp) {
         ZKCHK(b.ident.alloc(b.n));
-        hipLaunchKernelGGL(k_ident_flags<F>, grid_for(b.n, 256), dim3(256), 0, s, b.ident.as<uint8_t>(), (const uint8_t*)b.table.as<uint8_t>(), b.n);
+        hipLaunchKernelGGL(k_ident_flags<F>, grid_for(b.n, 256), dim3(256), 0, s, b.ident.as<uint8_t>(), (const uint8_t*)d_dense, b.n);
     }
-    if (b.precomp && b.nw > 1) {
-        ScopedTimer t("msm_precompute", s);
-        hipLaunchKernelGGL(k_precompute<F>, grid_for(b.n, 64), dim3(64), 0, s, b.table.as<uint8_t>(), b.n, b.c, b.nw);
-        HIPCHK(hipGetLastError());
-    }
+    ScopedTimer t("msm_precompute", s);
+    hipLaunchKernelGGL(k_precompute<F>, grid_for(b.n, 64), dim3(64), 0, s, b.table.as<uint8_t>(), (const uint8_t*)d_dense, b.n, b.c, b.precomp ? b.nw : 1u);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+size_t table_entry_bytes(Curve c) { return c == CURVE_G1 ? TableLayout<Fp>::ENTRY : TableLayout<Fp2>::ENTRY; }
+int msm_bases_dense(const MsmBases& b, uint64_t lo, uint64_t count, void* d_dense, hipStream_t s) {
+    if (lo + count > b.n) ZK_FAIL(ZK_ERR_ARG, "msm_bases_dense: range outside the base set");
+    if (!count) return ZK_OK;
+    const uint8_t* src = b.table.as<uint8_t>() + table_entry_bytes(b.curve) * lo;
+    if (b.curve == CURVE_G1) hipLaunchKernelGGL(k_table_to_dense<Fp>, grid_for(count, 128), dim3(128), 0, s, (uint8_t*)d_dense, src, count);
+    else hipLaunchKernelGGL(k_table_to_dense<Fp2>, grid_for(count, 128), dim3(128), 0, s, (uint8_t*)d_dense, src, count);
+    HIPCHK(hipGetLastError());
     return ZK_OK;
 }
 static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool precomp) {
@@ -915,7 +933,7 @@ static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool pr
     if (c < 2 || c > 22) ZK_FAIL(ZK_ERR_ARG, "msm: window_bits must be in [2, 22]");
     b.curve = curve; b.n = n; b.c = c; b.nw = msm_windows(c); b.precomp = precomp;
     if ((precomp ? (uint64_t)b.nw : 1) * n >= ((uint64_t)1 << 31)) ZK_FAIL(ZK_ERR_ARG, "msm: too many points for 31-bit references");
-    return b.table.alloc(aff_bytes(curve) * n * (precomp ? b.nw : 1));
+    return b.table.alloc(table_entry_bytes(curve) * n * (precomp ? b.nw : 1));
 }
 int points_bytes_to_affine(Curve curve, void* d_aff, const void* d_bytes, uint64_t n, int* d_flag, hipStream_t s) {
     if (!n) return ZK_OK;
@@ -957,23 +975,25 @@ int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_
 }
 int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s) {
     ZKCHK(bases_setup(b, curve, n, c, precomp));
-    HIPCHK(hipMemcpyAsync(b.table.p, d_affine, aff_bytes(curve) * n, hipMemcpyDeviceToDevice, s));
-    return curve == CURVE_G1 ? bases_finish<Fp>(b, s) : bases_finish<Fp2>(b, s);
+    return curve == CURVE_G1 ? bases_finish<Fp>(b, d_affine, s) : bases_finish<Fp2>(b, d_affine, s);
 }
 int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s) {
     ZKCHK(bases_setup(b, curve, n, c, precomp));
-    DevBuf raw, flag;
+    DevBuf raw, dense, flag;
     ZKCHK(raw.alloc(aff_bytes(curve) * n));
+    ZKCHK(dense.alloc(aff_bytes(curve) * n));
     ZKCHK(flag.alloc(4));
     HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
     HIPCHK(hipMemcpyAsync(raw.p, host_bytes, aff_bytes(curve) * n, hipMemcpyHostToDevice, s));
-    ZKCHK(points_bytes_to_affine(curve, b.table.p, raw.p, n, flag.as<int>(), s));
+    ZKCHK(points_bytes_to_affine(curve, dense.p, raw.p, n, flag.as<int>(), s));
     int h = 0;
     HIPCHK(hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (h & 2) ZK_FAIL(ZK_ERR_ARG, "point encoding: compressed flag set or coordinate >= p");
     if (h & 1) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "a base point is not on the curve");
-    return curve == CURVE_G1 ? bases_finish<Fp>(b, s) : bases_finish<Fp2>(b, s);
+    ZKCHK((curve == CURVE_G1 ? bases_finish<Fp>(b, dense.p, s) : bases_finish<Fp2>(b, dense.p, s)));
+    HIPCHK(hipStreamSynchronize(s));          // `dense` is released on return: the table build has read it
+    return ZK_OK;
 }
 
 // Batch-affine rounds before the XYZZ accumulate: halve the runs until ~2-3 entries per bucket are left (uniform digits; the

@@ -8,27 +8,21 @@
 
 namespace zk {
 
-// one table entry in the dense memory format, still packed: what the loop keeps in flight for the NEXT step
-template <class F> struct PackedAff {
-    FpWords x, y;
-};
-template <class F> FF_INLINE PackedAff<F> packed_aff_load(const uint8_t* p) {
-    if constexpr (std::is_same<F, Fp2H>::value) {
-        const uint32_t c = 48 * pair_comp();
-        return {fpw_load(p + c), fpw_load(p + 96 + c)};
-    } else {
-        return {fpw_load(p), fpw_load(p + 48)};
-    }
+// one table record (ec.cuh: TabRec, the lane's 128-byte line of the entry) -> the affine operand of the mixed addition; no repacking, the
+// conditional negation of y is the only arithmetic (table entries are canonical: -y = 2p - y)
+template <class F> FF_INLINE TabRec table_rec_load(const uint8_t* table, uint32_t ref) {
+    if constexpr (std::is_same<F, Fp2H>::value) return tab_rec_load(table + (uint64_t)TableLayout<F>::ENTRY * (ref & 0x7fffffffu) + TAB_REC * pair_comp());
+    else return tab_rec_load(table + (uint64_t)TableLayout<F>::ENTRY * (ref & 0x7fffffffu));
 }
-template <class F> FF_INLINE Aff<F> packed_aff_unpack(const PackedAff<F>& a, bool negate) {
-    const FpB<1> x = fp_unpack(a.x), y = fp_unpack(a.y);
+template <class F> FF_INLINE Aff<F> table_rec_point(const TabRec& a, bool negate) {
+    const FpB<1> x = tab_rec_x(a), y = tab_rec_y(a);
     Aff<F> r;
     if constexpr (std::is_same<F, Fp2H>::value) {
         r.x = Fp2H(x);
         r.y = negate ? Fp2H(fe_neg(y)) : Fp2H(y);
     } else {
         r.x = x;
-        if (negate) r.y = fe_neg(y);      // table entries are fully reduced: -y = 2p - y
+        if (negate) r.y = fe_neg(y);
         else r.y = y;
     }
     return r;
@@ -36,14 +30,19 @@ template <class F> FF_INLINE Aff<F> packed_aff_unpack(const PackedAff<F>& a, boo
 
 // RAW = false: the sorted entries are table references (index | sign).  RAW = true (the finisher of the batch-affine rounds,
 // msm_ba.cuh): entry `pos` is the affine point at pts + pos * 2 * RawLayout<F>::ELEM in the raw limb layout, identity = (0, 0).
-template <class F, bool RAW>
+// GLDS = true (G1, table references): the record of step i+1 travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, per-lane source address, no
+// VGPR destination) while step i computes, and is read from LDS when its turn comes: the look-ahead costs 7 KiB of LDS per wave instead of 28
+// registers per lane in a kernel that sits at the register limit.
+template <class F, bool RAW, bool GLDS = false>
 __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __restrict__ table, AccJobs jobs, uint32_t nb, uint32_t chunk) {
+    static_assert(!GLDS || (!RAW && !std::is_same<F, Fp2H>::value), "the LDS-DMA look-ahead is the G1 table-reference path");
+    __shared__ uint4 la_buf[GLDS ? 2 : 1][GLDS ? TAB_REC_WORDS / 4 : 1][GLDS ? 64 : 1];      // [wave][16-byte piece][lane]
     const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
     const uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
     uint8_t* __restrict__ buckets = jobs.buckets[blockIdx.y];
     uint8_t* __restrict__ head = jobs.head[blockIdx.y];
     uint8_t* __restrict__ tail = jobs.tail[blockIdx.y];
-    constexpr int AB = FieldOps<F>::WORDS * 8, XB = RawLayout<F>::XYZZ;       // table: dense; sums: raw layout
+    constexpr int XB = RawLayout<F>::XYZZ;       // sums: raw layout
     constexpr bool PAIR = std::is_same<F, Fp2H>::value;      // G2: two lanes per chunk, one Fp2 component each
     const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> (PAIR ? 1 : 0);
     const uint32_t N = offsets[nb];
@@ -63,7 +62,7 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
     // nest over runs would make the wave pay the longest run of every lane in turn).  A lane
     // crossing into the next bucket stores its running sum first -- a short divergent epilogue.
     // The reference and the table entry of step i+1 are requested before the mixed addition of step i
-    // (24 registers of look-ahead): the gather latency hides behind ~5k ALU instructions.
+    // (28 registers of look-ahead): the gather latency hides behind ~5k ALU instructions.
     uint32_t bstart = offsets[kb], bend = offsets[kb + 1];
     uint32_t seg_start = pos;
     bool first = true;
@@ -72,21 +71,48 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
     // the 24 look-ahead registers would be spilled)
     constexpr int RB = RawLayout<F>::ELEM;
     const uint8_t* __restrict__ pts = jobs.pts[blockIdx.y];
-    uint32_t v_next = 0;
-    PackedAff<F> p_next;
+    uint32_t v_next = 0, v_next2 = 0;
+    TabRec p_next;
+    const uint32_t la_wave = (threadIdx.x >> 6) & 1u, la_lane = threadIdx.x & 63u;
+    auto la_issue = [&](uint32_t ref) {             // the 112 bytes of one record: seven 16-byte pieces, piece j of lane l at la_buf[wave][j][l]
+        const uint8_t* src = table + (uint64_t)TableLayout<F>::ENTRY * (ref & 0x7fffffffu);
+#pragma unroll
+        for (int j = 0; j < TAB_REC_WORDS / 4; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * j),
+                                             (__attribute__((address_space(3))) void*)&la_buf[la_wave][j][0], 16, 0, 0);
+    };
+    auto la_take = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the DMA of this record was issued one whole group addition ago
+        TabRec r;
+#pragma unroll
+        for (int j = 0; j < TAB_REC_WORDS / 4; j++) {
+            const uint4 x = la_buf[la_wave][j][la_lane];
+            r.w[4 * j] = x.x; r.w[4 * j + 1] = x.y; r.w[4 * j + 2] = x.z; r.w[4 * j + 3] = x.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next DMA may overwrite the slot
+        return r;
+    };
     if constexpr (!RAW) {
         v_next = sorted[pos];
-        if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+        if constexpr (GLDS) {
+            v_next2 = pos + 1 < end ? sorted[pos + 1] : 0u;
+            la_issue(v_next);
+        } else if constexpr (!PAIR) p_next = table_rec_load<F>(table, v_next);
     }
     for (; pos < end; pos++) {
         const uint32_t v = v_next;
-        PackedAff<F> pk;
-        if constexpr (!RAW) {
-            if constexpr (PAIR) pk = packed_aff_load<F>(table + (uint64_t)AB * (v & 0x7fffffffu));
+        TabRec pk;
+        if constexpr (GLDS) {
+            pk = la_take();
+            if (pos + 1 < end) la_issue(v_next2);                  // its reference was loaded one step ago: no dependent-load stall here
+            v_next = v_next2;
+            v_next2 = pos + 2 < end ? sorted[pos + 2] : 0u;
+        } else if constexpr (!RAW) {
+            if constexpr (PAIR) pk = table_rec_load<F>(table, v);
             else pk = p_next;
             if (pos + 1 < end) {
                 v_next = sorted[pos + 1];
-                if constexpr (!PAIR) p_next = packed_aff_load<F>(table + (uint64_t)AB * (v_next & 0x7fffffffu));
+                if constexpr (!PAIR) p_next = table_rec_load<F>(table, v_next);
             }
         }
         if (pos == bend) {                              // run finished inside the chunk
@@ -100,7 +126,7 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
         }
         Aff<F> p;
         if constexpr (RAW) p = {load_raw_f((const F*)nullptr, pts + (uint64_t)2 * RB * pos), load_raw_f((const F*)nullptr, pts + (uint64_t)2 * RB * pos + RB)};
-        else p = packed_aff_unpack<F>(pk, (v >> 31) != 0);
+        else p = table_rec_point<F>(pk, (v >> 31) != 0);
         // The mixed addition is inlined so the accumulator lives in VGPRs for the whole chunk.  G2 runs
         // as F = Fp2H, one Fp2 component per lane of a pair, which gives it the register footprint of G1.
         // Second step of the chunk (a wave-uniform test): every lane holds the identity (run border just crossed) or

@@ -5,9 +5,14 @@
 #define ZK_FP_INLINE_MUL 1
 #include "msm_acc.cuh"
 
+#include <stdlib.h>
+
 namespace zk {
 int msm_accumulate_launch_g1(uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s) {
-    hipLaunchKernelGGL((k_msm_accumulate<Fp, false>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
+    // ZK_ACC_G1_GLDS=0: the register look-ahead (A/B of the LDS-DMA look-ahead; read once)
+    static const bool glds = !(getenv("ZK_ACC_G1_GLDS") && atoi(getenv("ZK_ACC_G1_GLDS")) == 0);
+    if (glds) hipLaunchKernelGGL((k_msm_accumulate<Fp, false, true>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
+    else hipLaunchKernelGGL((k_msm_accumulate<Fp, false, false>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }

@@ -108,14 +108,33 @@ template <int A> FF_INLINE void ba_store_coord(void* p, const FpB<A>& a) { fp_st
 template <int A> FF_INLINE void ba_store_coord(void* p, const Fp2HB<A>& a) { fp_store_raw((char*)p + 64 * pair_comp(), Fp(a.v)); }
 template <class F> struct BaLayout { static constexpr int COORD = RawLayout<F>::ELEM, POINT = 2 * RawLayout<F>::ELEM; };
 
-// one dense table coordinate (48 B, canonical) -> tight register form; G2 lanes take their own component
+// one coordinate of a table entry (ec.cuh: 128-byte records of canonical limbs; 56 B per coordinate) -> tight register form; G2 lanes
+// take their own record
+FF_INLINE FpB<1> ba_table_limbs(const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);          // 56 B = 3 x 16 + 8, 8-byte aligned
+    const uint2* q2 = reinterpret_cast<const uint2*>(p);
+    FpB<1> r;
+    if (((uintptr_t)p & 15) == 0) {
+        const uint4 a = q[0], b = q[1], c = q[2];
+        const uint2 d = q2[6];
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+        r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w; r.v[12] = d.x; r.v[13] = d.y;
+    } else {
+        const uint2 d = q2[0];
+        const uint4* q1 = reinterpret_cast<const uint4*>(p + 8);
+        const uint4 a = q1[0], b = q1[1], c = q1[2];
+        r.v[0] = d.x; r.v[1] = d.y; r.v[2] = a.x; r.v[3] = a.y; r.v[4] = a.z; r.v[5] = a.w; r.v[6] = b.x; r.v[7] = b.y;
+        r.v[8] = b.z; r.v[9] = b.w; r.v[10] = c.x; r.v[11] = c.y; r.v[12] = c.z; r.v[13] = c.w;
+    }
+    return r;
+}
 FF_INLINE FpB<4> ba_table_coord(const Fp*, const uint8_t* entry, int which, bool negate) {
-    const FpB<1> c = fp_load(entry + 48 * which);
+    const FpB<1> c = ba_table_limbs(entry + 4 * FPL * which);
     if (negate) return FpB<4>(fe_neg(c));
     return FpB<4>(c);
 }
 FF_INLINE Fp2HB<4> ba_table_coord(const Fp2H*, const uint8_t* entry, int which, bool negate) {
-    const FpB<1> c = fp_load(entry + 96 * which + 48 * pair_comp());
+    const FpB<1> c = ba_table_limbs(entry + TAB_REC * pair_comp() + 4 * FPL * which);
     if (negate) return {FpB<4>(fe_neg(c))};
     return {FpB<4>(c)};
 }
@@ -178,7 +197,7 @@ FF_INLINE BaItem<F, FIRST> ba_item(const uint8_t* table, const uint32_t* refs, c
     BaItem<F, FIRST> it;
     it.pair = pair;
     if constexpr (FIRST) {
-        constexpr int AB = FieldOps<F>::WORDS * 8;
+        constexpr int AB = TableLayout<F>::ENTRY;
         const uint32_t v1 = refs[s0], v2 = pair ? refs[s0 + 1] : 0u;
         it.p1 = table + (uint64_t)AB * (v1 & 0x7fffffffu);
         it.p2 = table + (uint64_t)AB * (v2 & 0x7fffffffu);

@@ -187,9 +187,11 @@ int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
     const uint64_t ph = (uint64_t)n + 1 + 2 * (uint64_t)k.m;
     MsmBases& old = k.g1[5];
     if (old.n != ph) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: unexpected pool length");
-    DevBuf pool;
+    DevBuf pool, old_dense;
     ZKCHK(pool.alloc(96 * ph));
-    const uint8_t* si = old.table.as<uint8_t>();                         // window 0 = the pool as uploaded
+    ZKCHK(old_dense.alloc(96 * ph));
+    ZKCHK(msm_bases_dense(old, 0, ph, old_dense.p, c.stream));            // window 0 = the pool as uploaded, back in the dense affine format
+    const uint8_t* si = old_dense.as<uint8_t>();
     // [lambda_t(s)], t < n - 1
     ZKCHK(derive_shifted_bases_g1(k.fr, si, pool.as<uint8_t>(), c.stream));
     // [Z(s)] = sum_i Z_i [s^i]: one MSM over the n + 1 powers with the canonical coefficients of Z
@@ -229,9 +231,11 @@ int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t cap
     if (!out) return ZK_OK;
     if (capacity_points < b.n) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: buffer too small");
     Ctx& c = ctx();
-    DevBuf bytes;
+    DevBuf bytes, dense;
     ZKCHK(bytes.alloc(aff_bytes(b.curve) * b.n));
-    ZKCHK(points_affine_to_bytes(b.curve, bytes.p, b.table.p, b.n, c.stream));
+    ZKCHK(dense.alloc(aff_bytes(b.curve) * b.n));
+    ZKCHK(msm_bases_dense(b, 0, b.n, dense.p, c.stream));
+    ZKCHK(points_affine_to_bytes(b.curve, bytes.p, dense.p, b.n, c.stream));
     HIPCHK(hipMemcpyAsync(out, bytes.p, aff_bytes(b.curve) * b.n, hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     return ZK_OK;
