@@ -104,19 +104,20 @@ template <class F> __device__ __noinline__ void xyzz_madd_equal_x_fn(Xyzz<F>* ou
     else *out = xyzz_inf<F>();
 }
 template <class F> FF_INLINE void xyzz_madd_equal_x(Xyzz<F>& acc, const Aff<F>& q, bool same_y) {
-    if constexpr (std::is_same<F, Fp2H>::value) {      // the lane-pair G2 loop runs at the register limit: keep the cold path out of it
-        Xyzz<F> t;
-        const Aff<F> qc = q;
-        xyzz_madd_equal_x_fn<F>(&t, &qc, same_y ? 1 : 0);
-        acc = t;
-    } else {
-        if (same_y) acc = xyzz_dbl_aff(q);
-        else acc = xyzz_inf<F>();
-    }
+    // always out of line: the doubling is ~17 KB of straight-line code with the field products expanded in place (G1 accumulate), sitting in the
+    // middle of a loop body that has to live in a 64 KB instruction cache; the lane-pair G2 loop runs at the register limit as well
+    Xyzz<F> t;
+    const Aff<F> qc = q;
+    xyzz_madd_equal_x_fn<F>(&t, &qc, same_y ? 1 : 0);
+    acc = t;
 }
-// madd-2008-s: acc += q (q affine)
-template <class F> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) {
-    if (aff_is_inf(q)) return;
+// madd-2008-s: acc += q (q affine).  Q_MAY_BE_INF = false: the caller knows q is a genuine point (entries of the resident base tables: the
+// counting sort never files an identity base into a bucket), so the identity test -- 28 limbs OR-ed, a zero test of the lazily reduced y with
+// its out-of-line slow path, and the registers that path pins -- stays out of the bucket loop
+template <class F, bool Q_MAY_BE_INF = true> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) {
+    if constexpr (Q_MAY_BE_INF) {
+        if (aff_is_inf(q)) return;
+    }
     if (xyzz_is_inf(acc)) {
         acc = {q.x, q.y, FieldOps<F>::one(), FieldOps<F>::one()};
         return;
@@ -141,8 +142,10 @@ template <class F> FF_INLINE void xyzz_madd_impl(Xyzz<F>& acc, const Aff<F>& q) 
 }
 // mmadd-2008-s: the same when acc is known to hold an AFFINE point (zz = zzz = 1) or the identity -- the second entry
 // of a bucket run.  6 products instead of 10: U2 = x2, S2 = y2, ZZ3 = PP, ZZZ3 = PPP.
-template <class F> FF_INLINE void xyzz_mmadd_impl(Xyzz<F>& acc, const Aff<F>& q) {
-    if (aff_is_inf(q)) return;
+template <class F, bool Q_MAY_BE_INF = true> FF_INLINE void xyzz_mmadd_impl(Xyzz<F>& acc, const Aff<F>& q) {
+    if constexpr (Q_MAY_BE_INF) {
+        if (aff_is_inf(q)) return;
+    }
     if (xyzz_is_inf(acc)) {
         acc = {q.x, q.y, FieldOps<F>::one(), FieldOps<F>::one()};
         return;

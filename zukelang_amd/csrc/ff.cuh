@@ -547,6 +547,29 @@ __device__ __noinline__ static FpRaw fp_canon_call(FP_ARGS(a)) {
     return r;
 }
 template <int A> FF_INLINE FpB<1> fp_canon(const FpB<A>& a) { return fp_from_raw<1>(fp_canon_call(FP_PASS(a.v))); }
+// The same reduction expanded in place, for the slow path of the zero test inside loops that must not contain a call (a call pins every live value
+// to the callee-saved half of the register file and drains the loads in flight; the slow path itself runs once in ~2^23 tests)
+FF_INLINE bool fp_is_zero_mod_p_inline(const uint32_t* __restrict__ a) {
+    uint32_t t[FPL];
+#pragma unroll
+    for (int i = 0; i < FPL; i++) t[i] = a[i];
+#pragma unroll
+    for (int i = 0; i < FPL - 1; i++) {
+        t[i + 1] += t[i] >> FP29_W;
+        t[i] &= FP29_MASK;
+    }
+    // value = k p exactly  <=>  every limb of value - k p is zero, k = limb0 / p mod 2^29 (the only candidate)
+    const uint32_t k = (t[0] * FP29_PINV) & FP29_MASK;
+    int64_t cy = 0;
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) {
+        const int64_t cur = (int64_t)t[i] - (int64_t)((uint64_t)k * FP29_MOD[i]) + cy;
+        o |= i < FPL - 1 ? ((uint32_t)cur & FP29_MASK) : (uint32_t)cur;
+        cy = cur >> FP29_W;
+    }
+    return o == 0 && cy == 0;
+}
 
 // value == 0 mod p ?  Exact zeros (how the identity is encoded) are caught first; otherwise a multiple
 // k p, k < B, must have k = limb0 * p^-1 mod 2^29 < B: everything else (all but B in 2^29 values) is
@@ -560,11 +583,15 @@ template <int B> FF_INLINE bool fe_is_zero(const FpB<B>& a) {
     else {
         const uint32_t k = (a.v[0] * FP29_PINV) & FP29_MASK;
         if (k >= (uint32_t)B) return false;
+#ifdef ZK_FP_INLINE_MUL
+        return fp_is_zero_mod_p_inline(a.v);
+#else
         const FpB<1> c = fp_canon(a);
         uint32_t z = 0;
 #pragma unroll
         for (int i = 0; i < FPL; i++) z |= c.v[i];
         return z == 0;
+#endif
     }
 }
 template <int A, int B> FF_INLINE bool fe_eq(const FpB<A>& a, const FpB<B>& b) { return fe_is_zero(fe_sub(a, b)); }

@@ -142,9 +142,13 @@ static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
         ZKCHK(sl->rs.alloc(64));
         ZKCHK(sl->results.alloc(2 * xyzz_bytes(CURVE_G1) + xyzz_bytes(CURVE_G2)));
         ZKCHK(sl->out_dev.alloc(384));
-        ZKCHK(msm_workspace_alloc(sl->wsA, k.g1));
-        ZKCHK(msm_workspace_alloc(sl->wsC, k.g1));
-        ZKCHK(msm_workspace_alloc(sl->wsB, k.g2));
+        // A and C go out as ONE accumulate launch over the G1 pool: A carries the non-zero prefix a | d1 | b1 | tau basis only (this rank's part of it),
+        // C the whole slice; every scalar has a digit in (nearly) every window
+        const uint64_t pre = k.p2 + 1, a_pts = k.lo1 >= pre ? 0 : (k.hi1 < pre ? k.hi1 : pre) - k.lo1;
+        const uint64_t e1 = (a_pts + k.g1.n) * k.g1.nw;
+        ZKCHK(msm_workspace_alloc(sl->wsA, k.g1, 0, e1));
+        ZKCHK(msm_workspace_alloc(sl->wsC, k.g1, 0, e1));
+        ZKCHK(msm_workspace_alloc(sl->wsB, k.g2, 0, k.g2.n * k.g2.nw));
         HIPCHK(hipStreamCreateWithFlags(&sl->s0, hipStreamNonBlocking));
         // One stream per proof by default: the chip runs at most 16 hardware queues side by side and
         // falls off a cliff beyond (24 streams x 1 ms of 1-workgroup kernels: 72 ms, scripts/proto/concurrency.hip),

@@ -58,7 +58,9 @@ int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine,
 // base points [lo, lo + count) of the set (window 0 of the table) back in the dense affine format, exact
 int msm_bases_dense(const MsmBases& b, uint64_t lo, uint64_t count, void* d_dense, hipStream_t s);
 // max_nonzero: upper bound of the non-zero scalars this workspace's products ever carry (0 = all of b.n): sizes the batch-affine buffers
-int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero = 0);
+// launch_entries: sorted entries of one whole accumulate launch these workspaces take part in (0 = unknown): picks the chunk length that fills a whole
+// number of rounds of the chip's resident lanes
+int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero = 0, uint64_t launch_entries = 0);
 // d_scalars: n canonical (non-Montgomery) Fr, 32 B each, on device.  d_result: one XYZZ point.
 int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_result_xyzz, hipStream_t s);
 // the same in two halves: sort + bucket accumulation per MSM, then ONE chain of reduction launches for up to 8 MSMs

@@ -1014,7 +1014,7 @@ static uint32_t ba_rounds_for(const MsmBases& b, uint32_t nbuckets) {
     while (((uint64_t)8 << r) <= mean) r++;                 // mean in [8, 16) -> 1 round ... [2^(k+2), 2^(k+3)) -> k rounds
     return r > 24 ? 24 : r;
 }
-int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero) {
+int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero, uint64_t launch_entries) {
     w.curve = b.curve; w.c = b.c; w.nw = b.nw; w.precomp = b.precomp; w.cap_points = b.n;
     const uint32_t nbw = 1u << (b.c - 1);
     w.nbuckets = (b.precomp ? 1 : b.nw) * nbw;
@@ -1025,6 +1025,17 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     static const uint64_t target_threads = getenv("ZK_MSM_TARGET_THREADS") ? (uint64_t)atoll(getenv("ZK_MSM_TARGET_THREADS")) : 256 * 1024;   // tuning knob
     uint32_t chunk = (uint32_t)((maxN + target_threads - 1) / target_threads);
     static const uint32_t chunk_min = getenv("ZK_MSM_CHUNK_MIN") ? (uint32_t)atoi(getenv("ZK_MSM_CHUNK_MIN")) : 16;   // tuning knob
+    if (launch_entries) {
+        // The caller knows how many sorted entries ONE accumulate launch carries (several products over these bases, e.g. Groth16's A and C):
+        // cut it into a WHOLE number of rounds of the chip's resident lanes (256 CUs x 4 SIMDs x 2 waves x 64 lanes, half as many chunks for the
+        // lane pairs of G2).  Every lane does the same number of additions, so a launch whose chunks fill 2.65 rounds costs three (2^20
+        // constraints: 157 entries per chunk by the rule above; 208 makes it two rounds).
+        const uint64_t round = (uint64_t)256 * 4 * 2 * 64 / (b.curve == CURVE_G1 ? 1 : 2);
+        const uint64_t k = (launch_entries + round * 208 - 1) / (round * 208);          // rounds, chunks of at most ~208 entries
+        const uint64_t c2 = (launch_entries + k * round - 1) / (k * round);
+        if (c2 > chunk_min) chunk = (uint32_t)c2;
+        else chunk = chunk_min;
+    }
     if (chunk < chunk_min) chunk = chunk_min;
     w.chunk = chunk;
     w.nthreads = (maxN + chunk - 1) / chunk;

@@ -33,9 +33,11 @@ template <class F> FF_INLINE Aff<F> table_rec_point(const TabRec& a, bool negate
 // GLDS = true (G1, table references): the record of step i+1 travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, per-lane source address, no
 // VGPR destination) while step i computes, and is read from LDS when its turn comes: the look-ahead costs 7 KiB of LDS per wave instead of 28
 // registers per lane in a kernel that sits at the register limit.
-template <class F, bool RAW, bool GLDS = false>
+// MMADD = true: the second step of a chunk uses the 6-product addition of two affine points (a second, 25 KB copy of the group law beside the
+// hot loop); false: every step is the general mixed addition -- less code in the instruction cache for 4 more products once per chunk.
+template <class F, bool RAW, bool GLDS = false, bool MMADD = true>
 __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __restrict__ table, AccJobs jobs, uint32_t nb, uint32_t chunk) {
-    static_assert(!GLDS || (!RAW && !std::is_same<F, Fp2H>::value), "the LDS-DMA look-ahead is the G1 table-reference path");
+    static_assert(!GLDS || !RAW, "the LDS-DMA look-ahead serves table references");
     __shared__ uint4 la_buf[GLDS ? 2 : 1][GLDS ? TAB_REC_WORDS / 4 : 1][GLDS ? 64 : 1];      // [wave][16-byte piece][lane]
     const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
     const uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
@@ -61,21 +63,25 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
     // Flat loop: one mixed addition per lane per iteration whatever the run boundaries are (a loop
     // nest over runs would make the wave pay the longest run of every lane in turn).  A lane
     // crossing into the next bucket stores its running sum first -- a short divergent epilogue.
-    // The reference and the table entry of step i+1 are requested before the mixed addition of step i
-    // (28 registers of look-ahead): the gather latency hides behind ~5k ALU instructions.
+    // The reference and the table entry of step i+1 are requested before the mixed addition of step i: the gather latency hides behind ~5k ALU instructions.
+    // Order inside an iteration: take the record of this step (its transfer was issued one whole group addition ago) -> run border, if this
+    // lane crossed one (stores of the finished sum; the end of the NEXT run is already in a register, prefetched at the previous border:
+    // no dependent load on the path) -> request the record of the next step -> the group addition.  With the border after the request every
+    // wave stalled for a full HBM round trip whenever ANY of its lanes crossed a run border (the dependent offsets load waits for
+    // everything older, the gather just issued included): at 2^20 that is 47 % of the iterations (PMC: 13 % of the wave cycles in s_waitcnt).
     uint32_t bstart = offsets[kb], bend = offsets[kb + 1];
+    uint32_t bend2 = kb + 2 <= nb ? offsets[kb + 2] : bend;          // end of the run after this one
     uint32_t seg_start = pos;
     bool first = true;
     Xyzz<F> acc = xyzz_inf<F>();
-    // (G2: the products are calls, which drain outstanding loads anyway -- only the reference is fetched ahead there,
-    // the 24 look-ahead registers would be spilled)
+    // (G2: the products are calls, which drain outstanding loads anyway -- only the reference is fetched ahead there)
     constexpr int RB = RawLayout<F>::ELEM;
     const uint8_t* __restrict__ pts = jobs.pts[blockIdx.y];
     uint32_t v_next = 0, v_next2 = 0;
     TabRec p_next;
     const uint32_t la_wave = (threadIdx.x >> 6) & 1u, la_lane = threadIdx.x & 63u;
     auto la_issue = [&](uint32_t ref) {             // the 112 bytes of one record: seven 16-byte pieces, piece j of lane l at la_buf[wave][j][l]
-        const uint8_t* src = table + (uint64_t)TableLayout<F>::ENTRY * (ref & 0x7fffffffu);
+        const uint8_t* src = table + (uint64_t)TableLayout<F>::ENTRY * (ref & 0x7fffffffu) + (PAIR ? TAB_REC * pair_comp() : 0u);
 #pragma unroll
         for (int j = 0; j < TAB_REC_WORDS / 4; j++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * j),
@@ -102,27 +108,29 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
     for (; pos < end; pos++) {
         const uint32_t v = v_next;
         TabRec pk;
-        if constexpr (GLDS) {
-            pk = la_take();
-            if (pos + 1 < end) la_issue(v_next2);                  // its reference was loaded one step ago: no dependent-load stall here
-            v_next = v_next2;
-            v_next2 = pos + 2 < end ? sorted[pos + 2] : 0u;
-        } else if constexpr (!RAW) {
-            if constexpr (PAIR) pk = table_rec_load<F>(table, v);
-            else pk = p_next;
-            if (pos + 1 < end) {
-                v_next = sorted[pos + 1];
-                if constexpr (!PAIR) p_next = table_rec_load<F>(table, v_next);
-            }
-        }
+        if constexpr (GLDS) pk = la_take();
+        else if constexpr (!RAW && !PAIR) pk = p_next;
         if (pos == bend) {                              // run finished inside the chunk
             const bool complete = seg_start == bstart;
             uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
             xyzz_store_raw<F>(dst, acc);
             first = false;
             acc = xyzz_inf<F>();
-            do { kb++; bstart = bend; bend = offsets[kb + 1]; } while (bend == bstart);   // skip empty buckets
+            kb++; bstart = bend; bend = bend2;
+            while (bend == bstart) { kb++; bend = offsets[kb + 1]; }        // empty buckets: rare, the only dependent load left
+            bend2 = kb + 2 <= nb ? offsets[kb + 2] : bend;                    // consumed at the next border
             seg_start = pos;
+        }
+        if constexpr (GLDS) {
+            if (pos + 1 < end) la_issue(v_next2);                  // its reference was loaded one step ago: no dependent-load stall here
+            v_next = v_next2;
+            v_next2 = pos + 2 < end ? sorted[pos + 2] : 0u;
+        } else if constexpr (!RAW) {
+            if constexpr (PAIR) pk = table_rec_load<F>(table, v);
+            if (pos + 1 < end) {
+                v_next = sorted[pos + 1];
+                if constexpr (!PAIR) p_next = table_rec_load<F>(table, v_next);
+            }
         }
         Aff<F> p;
         if constexpr (RAW) p = {load_raw_f((const F*)nullptr, pts + (uint64_t)2 * RB * pos), load_raw_f((const F*)nullptr, pts + (uint64_t)2 * RB * pos + RB)};
@@ -131,8 +139,11 @@ __global__ __launch_bounds__(128, 2) void k_msm_accumulate(const uint8_t* __rest
         // as F = Fp2H, one Fp2 component per lane of a pair, which gives it the register footprint of G1.
         // Second step of the chunk (a wave-uniform test): every lane holds the identity (run border just crossed) or
         // the single affine point of step one, so the 6-product addition of two affine points does.
-        if (pos == pos0 + 1) xyzz_mmadd_impl(acc, p);
-        else xyzz_madd_impl(acc, p);
+        // Table entries are never the identity (the sort filters identity bases): only the raw-point path tests for it.
+        if constexpr (MMADD) {
+            if (pos == pos0 + 1) xyzz_mmadd_impl<F, RAW>(acc, p);
+            else xyzz_madd_impl<F, RAW>(acc, p);
+        } else xyzz_madd_impl<F, RAW>(acc, p);
     }
     {
         const bool complete = (seg_start == bstart) && (end == bend);
