@@ -122,6 +122,33 @@ template <int V> __global__ void k_bench(uint32_t* out, uint32_t iters) {
     for (int i = 0; i < L; i++) acc ^= x[i] ^ y[i];
     if (acc == 0x12345678u) out[0] = acc;
 }
+// the same dependent chain with the loop body UNROLLED to 2 * U products (U = 10: ~40 KB of straight-line code, the size of an inlined group addition):
+// does a long loop body alone slow a wave down (instruction fetch)?
+template <int V, int U> __global__ void k_bench_long(uint32_t* out, uint32_t iters) {
+    uint32_t x[L], y[L], t[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        x[i] = (0x1234567u * (i + 1) ^ (threadIdx.x * 2654435761u >> (i & 7))) & MASK;
+        y[i] = (0x7654321u * (i + 3) + blockIdx.x) & MASK;
+    }
+    x[L - 1] &= 0xffff;
+    y[L - 1] &= 0xffff;
+    for (uint32_t it = 0; it < iters; it += U) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            mul<V>(t, x, y);
+#pragma unroll
+            for (int i = 0; i < L; i++) x[i] = t[i];
+            mul<V>(t, y, x);
+#pragma unroll
+            for (int i = 0; i < L; i++) y[i] = t[i];
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) acc ^= x[i] ^ y[i];
+    if (acc == 0x12345678u) out[0] = acc;
+}
 // two INDEPENDENT chains per lane (what an inlined group addition offers the scheduler: U2 | S2, PPP | Q, ZZ3 | ZZZ3)
 template <int V> __global__ void k_bench2(uint32_t* out, uint32_t iters) {
     uint32_t x[L], y[L], u[L], v[L], t[L], s[L];
@@ -178,6 +205,19 @@ template <int V> static void run(uint32_t* d, const char* name) {
         hipEventElapsedTime(&ms2, e0, e1);
         printf("  %d waves/SIMD: one chain %.2f G mul/s | two independent chains per lane %.2f G mul/s\n", wps, 2.0 * iters * blocks * threads / ms / 1e6,
                4.0 * iters * blocks * threads / ms2 / 1e6);
+    }
+    for (int wps : {1, 2}) {
+        const int blocks = 256 * wps, threads = 256;
+        hipEvent_t a0, a1;
+        hipEventCreate(&a0); hipEventCreate(&a1);
+        k_bench_long<V, 10><<<blocks, threads>>>(d, 10);
+        hipEventRecord(a0);
+        k_bench_long<V, 10><<<blocks, threads>>>(d, iters);
+        hipEventRecord(a1);
+        hipEventSynchronize(a1);
+        float msl;
+        hipEventElapsedTime(&msl, a0, a1);
+        printf("  %d waves/SIMD, loop body unrolled to 20 products (~40 KB): %.2f G mul/s\n", wps, 2.0 * iters * blocks * threads / msl / 1e6);
     }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

@@ -20,7 +20,7 @@ struct MsmBases {
     uint32_t nw = 0;         // windows
     bool precomp = false;    // table holds 2^(c*j) * P_i for j < nw at [j*n + i]; one bucket set
     DevBuf table;            // affine Montgomery points in the 128-byte record layout of ec.cuh (TableLayout): canonical limbs, one cache line per lane and gather
-    DevBuf ident;            // precomp: one byte per point, 1 = the base is the identity (the sort never files it into a bucket)
+    DevBuf ident;            // one byte per point, 1 = the base is the identity (the sort never files it into a bucket: table entries the accumulate loop meets are genuine points)
 };
 
 struct MsmWorkspace {
@@ -74,6 +74,8 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
                      const MsmBases* b2, MsmWorkspace* const* ws2, void* const* outs2, uint32_t n2, hipStream_t s);
 // step 4 of msm_run (msm_acc_g1.hip / msm_acc_g2.hip) for up to 4 MSMs over the same table in one launch (blockIdx.y = job)
 static constexpr uint32_t MAX_ACC_JOBS = 4;
+// waves per SIMD of the accumulate kernels (msm_acc.cuh compiles to them, msm_workspace_alloc sizes the chunks for whole rounds of them)
+static constexpr uint32_t ACC_WAVES_G1 = 3, ACC_WAVES_G2 = 2;
 struct AccJobs {
     const uint32_t* offsets[MAX_ACC_JOBS];
     const uint32_t* sorted[MAX_ACC_JOBS];

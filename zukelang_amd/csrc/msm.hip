@@ -905,10 +905,10 @@ uint32_t msm_auto_window(uint64_t n, bool precomp) {
 }
 
 template <class F> static int bases_finish(MsmBases& b, const void* d_dense, hipStream_t s) {
-    if (b.precomp) {
-        ZKCHK(b.ident.alloc(b.n));
-        hipLaunchKernelGGL(k_ident_flags<F>, grid_for(b.n, 256), dim3(256), 0, s, b.ident.as<uint8_t>(), (const uint8_t*)d_dense, b.n);
-    }
+    // every base set carries its identity flags: the sort never files an identity base into a bucket, so the accumulate loop can take table
+    // entries for genuine points (no identity test per addition) in BOTH table modes
+    ZKCHK(b.ident.alloc(b.n));
+    hipLaunchKernelGGL(k_ident_flags<F>, grid_for(b.n, 256), dim3(256), 0, s, b.ident.as<uint8_t>(), (const uint8_t*)d_dense, b.n);
     ScopedTimer t("msm_precompute", s);
     hipLaunchKernelGGL(k_precompute<F>, grid_for(b.n, 64), dim3(64), 0, s, b.table.as<uint8_t>(), (const uint8_t*)d_dense, b.n, b.c, b.precomp ? b.nw : 1u);
     HIPCHK(hipGetLastError());
@@ -1025,12 +1025,12 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     static const uint64_t target_threads = getenv("ZK_MSM_TARGET_THREADS") ? (uint64_t)atoll(getenv("ZK_MSM_TARGET_THREADS")) : 256 * 1024;   // tuning knob
     uint32_t chunk = (uint32_t)((maxN + target_threads - 1) / target_threads);
     static const uint32_t chunk_min = getenv("ZK_MSM_CHUNK_MIN") ? (uint32_t)atoi(getenv("ZK_MSM_CHUNK_MIN")) : 16;   // tuning knob
-    if (launch_entries) {
+    if (launch_entries && chunk >= 64) {            // short chunks (small keys) already fill whole rounds: at 2^16, 2 rounds of 16-entry chunks beat 1 round of 32
         // The caller knows how many sorted entries ONE accumulate launch carries (several products over these bases, e.g. Groth16's A and C):
-        // cut it into a WHOLE number of rounds of the chip's resident lanes (256 CUs x 4 SIMDs x 2 waves x 64 lanes, half as many chunks for the
-        // lane pairs of G2).  Every lane does the same number of additions, so a launch whose chunks fill 2.65 rounds costs three (2^20
+        // cut it into a WHOLE number of rounds of the chip's resident lanes (256 CUs x 4 SIMDs x 3 (G1) or 2 (G2) waves x 64 lanes, half as many
+        // chunks for the lane pairs of G2).  Every lane does the same number of additions, so a launch whose chunks fill 2.65 rounds costs three (2^20
         // constraints: 157 entries per chunk by the rule above; 208 makes it two rounds).
-        const uint64_t round = (uint64_t)256 * 4 * 2 * 64 / (b.curve == CURVE_G1 ? 1 : 2);
+        const uint64_t round = b.curve == CURVE_G1 ? (uint64_t)256 * 4 * ACC_WAVES_G1 * 64 : (uint64_t)256 * 4 * ACC_WAVES_G2 * 64 / 2;
         const uint64_t k = (launch_entries + round * 208 - 1) / (round * 208);          // rounds, chunks of at most ~208 entries
         const uint64_t c2 = (launch_entries + k * round - 1) / (k * round);
         if (c2 > chunk_min) chunk = (uint32_t)c2;
@@ -1125,7 +1125,7 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
 #else
     const uint32_t alias = 0u;
 #endif
-    DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}, b.precomp ? b.ident.as<uint8_t>() : nullptr,
+    DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}, b.ident.as<uint8_t>(),
                  0u, sm ? 1u : 0u, alias};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
