@@ -276,8 +276,8 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     toxic = [rng() for _ in range(5)]
     it = iter(toxic)
     pk, _vk = Groth16.keygen(lambda: next(it), cs, lagrange=lagrange)
-    # N > 1 with the derivation enabled for this total size: every rank uploads the key WHOLE, derives its Lagrange form (redundantly, in
-    # parallel) and keeps its shard (cut for equal work, zk_groth16_shard_range).  Otherwise (--derive-lagrange-upto -1, or a total size
+    # N > 1 with the derivation enabled for this total size: every rank uploads the key WHOLE, the ranks SHARE the derivation of its Lagrange form
+    # (one of the three independent sets per rank, broadcast) and each keeps its shard (cut for equal work, zk_groth16_shard_range).  Otherwise (--derive-lagrange-upto -1, or a total size
     # beyond it) the key is sharded at upload and stays in tau-power form.
     derive_s = None
     total_log = (n - 1).bit_length()
@@ -285,9 +285,8 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     if sharded_derived:
         prover = Groth16(cs, pk)
         t_d = time.perf_counter()
-        prover.derive_lagrange()
+        prover.derive_lagrange_shared(rank, world)      # one derived set per rank, broadcast over RCCL, this rank's shard installed
         derive_s = time.perf_counter() - t_d
-        prover.shard(rank, world)
         # default: the Fr stage of a proof runs on ONE rank (its owner) and the scalar slices travel (GroupProver: one all-to-all per
         # vector) -- replicated, every rank would run a (2^log_n x world)-constraint Fr stage per proof beside an MSM slice that does
         # not grow with the world size; --replicated-fr keeps the simpler scheme
@@ -747,7 +746,7 @@ def main():
                        "proofs_per_step": args.proofs_per_step, "timed_proofs": head["timed_proofs"], "timed_s": head["timed_s"],
                        "constraints": head["constraints"], "variables": head["variables"], "proofs_in_flight": head["proofs_in_flight"], "constraints_per_gpu": head["constraints"] // world,
                        "sharding": ("MSM base points over ranks (slices cut for equal work: the A prefix counts twice); "
-                                    + ("every rank derived the key's Lagrange form (derive_lagrange_s) and kept its shard; " if head.get("derive_lagrange_s") is not None else "")
+                                    + ("the ranks shared the derivation of the key's Lagrange form (one set per rank, broadcast: derive_lagrange_s) and kept their shards; " if head.get("derive_lagrange_s") is not None else "")
                                     + "Fr stage of a proof on its owner rank + all-to-all of scalar slices; all-gather of 768 B partial sums + local EC reduce"
                                     if head["group_batch"] is not None else
                                     ("MSM base points over ranks; every rank derived the key's Lagrange form (derive_lagrange_s) and runs the three-convolution Fr stage replicated; "

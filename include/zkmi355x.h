@@ -121,6 +121,17 @@ int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const
  * (seconds at 2^16 constraints, minutes at 2^20); afterwards every prove entry point runs the three-convolution Fr stage.  Proof bytes do
  * not change.  Single-GPU keys only; no proof may be in flight. */
 int zk_groth16_pk_derive_lagrange(uint64_t handle);
+/* The same in two halves, so that the N ranks of a node share ONE derivation instead of running it N times: the three derived sets -- bit 0:
+ * [l_i(tau)]_1, bit 1: [l_i(tau)]_2, bit 2: the h bases [lambda_t(tau) Z(tau)/delta]_1 -- are independent of one another.  Every rank uploads the key
+ * whole (zk_groth16_pk_upload), derives the sets of its `sets` mask into caller-owned DEVICE buffers holding the Lagrange-form pools
+ * (zk_groth16_lagrange_pool_sizes points of 96 / 192 B; the copied parts a | d1 | b1, ltd_mid, b2 | d2 are always written, a set that is not
+ * selected leaves its region untouched), the host framework broadcasts each set from its owner (RCCL broadcast on device memory: set 0 is
+ * g1[3, 3+n), set 1 is g2[2, 2+n), set 2 is g1[3+n, 3+n+n-1)), and zk_groth16_pk_install_lagrange builds this rank's slice of the window tables
+ * from the complete pools (world = 1: the whole key; same slicing rule as zk_groth16_pk_shard) and flips the key to the three-convolution
+ * Fr stage.  zk_groth16_pk_derive_lagrange == _sets(handle, 7, ...) + _install(..., 0, 1).  The key is unchanged until _install has succeeded. */
+int zk_groth16_lagrange_pool_sizes(uint64_t handle, uint64_t* g1_points, uint64_t* g2_points);
+int zk_groth16_pk_derive_lagrange_sets(uint64_t handle, uint32_t sets, void* d_g1_out, void* d_g2_out);
+int zk_groth16_pk_install_lagrange(uint64_t handle, const void* d_g1, const void* d_g2, uint32_t rank, uint32_t world);
 /* Turns a key uploaded WHOLE (zk_groth16_pk_upload[_lagrange], possibly after zk_groth16_pk_derive_lagrange) into rank `rank`'s shard of a
  * point-sharded multi-GPU prover: the rank keeps its contiguous slice of both pools (same slicing rule as zk_groth16_pk_upload_sharded) and
  * from then on answers zk_groth16_prove_partial*.  How a derived Lagrange-form key reaches N GPUs: every rank uploads, derives, shards. */

@@ -183,6 +183,14 @@ def main():
         for (rr, ss), pr in zip(rs[:2 * world + 1], gdp):
             e4 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
             assert (pr.a, pr.b, pr.c) == e4, "rank %d: a group proof from the derived + sharded key differs" % rank
+        # round 3: the derivation SHARED by the ranks (one set per rank, broadcast, install of the rank's shard): the pools a rank ends up with
+        # must be the ones the redundant derivation + zk_groth16_pk_shard left it with, byte for byte, and so must the proofs
+        ds = Groth16(cs, pk)
+        ds.derive_lagrange_shared(rank, world)
+        assert bytes(ds.pool_points(1)) == bytes(dp.pool_points(1)) and bytes(ds.pool_points(2)) == bytes(dp.pool_points(2)), "rank %d: shared derivation gives other pools" % rank
+        ps = ds.prove_rs(w, r, s)
+        assert (ps.a, ps.b, ps.c) == expect, "rank %d: proof from the shared derivation differs" % rank
+        ds.close()
         dp.close()
         # an unsatisfied witness: only the OWNER of a proof sees ZK_ERR_REMAINDER (QAP.ml:134); every rank must raise
         # before the round's all-to-all instead of hanging in it, and the prover must stay usable afterwards

@@ -96,19 +96,18 @@ template <class F> FF_INLINE Xyzz<F> xyzz_dbl_aff(const Aff<F>& p) {
     const auto Y3 = fe_mul_sub(M, fe_sub(S, X3), W, p.y);
     return {X3, Y3, V, W};
 }
-// The equal-x case of a mixed addition (P + P or P + (-P)): a doubling's worth of code that a bucket loop meets once in 2^381
-// additions unless the bases repeat.  Out of line, operands through private memory (copies: the caller's accumulator stays in
-// registers), so the hot loop does not pay its register pressure.
-template <class F> __device__ __noinline__ void xyzz_madd_equal_x_fn(Xyzz<F>* out, const Aff<F>* q, int same_y) {
-    if (same_y) *out = xyzz_dbl_aff(*q);
-    else *out = xyzz_inf<F>();
+// The equal-x case of a mixed addition (P + P or P + (-P)): a doubling's worth of code that a bucket loop meets once in 2^381 additions unless
+// the bases repeat.  Out of line -- ~17 KB of straight-line code with the products expanded in place, in the middle of a loop body that has to
+// live in the instruction cache -- and on the ACCUMULATOR, which holds the same point as q here (equal x, equal y) and is live anyway: doubling
+// q instead kept the 28 words of the table entry alive across the whole addition, and the compiler parked them in scratch memory in EVERY
+// iteration (PMC: 112 B of scratch writes per addition, 5.9 GB per 2^20 proof, for a path that never runs).
+template <class F> __device__ __noinline__ void xyzz_madd_equal_x_fn(Xyzz<F>* acc, int same_y) {
+    if (same_y) *acc = xyzz_dbl_impl(*acc);
+    else *acc = xyzz_inf<F>();
 }
-template <class F> FF_INLINE void xyzz_madd_equal_x(Xyzz<F>& acc, const Aff<F>& q, bool same_y) {
-    // always out of line: the doubling is ~17 KB of straight-line code with the field products expanded in place (G1 accumulate), sitting in the
-    // middle of a loop body that has to live in a 64 KB instruction cache; the lane-pair G2 loop runs at the register limit as well
-    Xyzz<F> t;
-    const Aff<F> qc = q;
-    xyzz_madd_equal_x_fn<F>(&t, &qc, same_y ? 1 : 0);
+template <class F> FF_INLINE void xyzz_madd_equal_x(Xyzz<F>& acc, bool same_y) {
+    Xyzz<F> t = acc;
+    xyzz_madd_equal_x_fn<F>(&t, same_y ? 1 : 0);
     acc = t;
 }
 // madd-2008-s: acc += q (q affine).  Q_MAY_BE_INF = false: the caller knows q is a genuine point (entries of the resident base tables: the
@@ -127,7 +126,7 @@ template <class F, bool Q_MAY_BE_INF = true> FF_INLINE void xyzz_madd_impl(Xyzz<
     const auto P = fe_sub(U2, acc.x);
     const auto R = fe_sub(S2, acc.y);
     if (fe_is_zero(P)) {
-        xyzz_madd_equal_x(acc, q, fe_is_zero(R));
+        xyzz_madd_equal_x(acc, fe_is_zero(R));
         return;
     }
     const auto PP = fe_sqr(P);
@@ -153,7 +152,7 @@ template <class F, bool Q_MAY_BE_INF = true> FF_INLINE void xyzz_mmadd_impl(Xyzz
     const auto P = fe_sub(q.x, acc.x);
     const auto R = fe_sub(q.y, acc.y);
     if (fe_is_zero(P)) {
-        xyzz_madd_equal_x(acc, q, fe_is_zero(R));
+        xyzz_madd_equal_x(acc, fe_is_zero(R));
         return;
     }
     const auto PP = fe_sqr(P);

@@ -106,7 +106,7 @@ __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __rest
     }
 }
 
-int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, DevBuf& out_g1, DevBuf& out_g2, hipStream_t s);   // lagrange_derive.hip
+int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, uint8_t* out_g1, uint8_t* out_g2, uint32_t sets, hipStream_t s);   // lagrange_derive.hip
 
 // Contiguous slice [lo, hi) of a pool of `points` base points for `rank` of `world`, cut for equal WORK: the first `heavy` points of the G1
 // pool (a | d1 | b1 | the tau basis) carry two products of a proof, A and C (groth16.ml:128-134 vs :147-160), every other point one, so
@@ -349,47 +349,83 @@ int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const
                                   const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
     return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, handle, true);
 }
-int zk_groth16_pk_derive_lagrange(uint64_t handle) {
+// ---- derivation in two halves, so that the ranks of a node can share it (one set per rank, broadcast, install) -- and the single-call form on top
+static int derive_precheck(Groth16Key& k, const char* who) {
+    if (k.world != 1) ZK_FAIL(ZK_ERR_ARG, "derive: sharded keys hold only a slice of the powers");
+    for (uint32_t i = 0; i < MAX_SLOTS; i++)
+        if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, who);
+    HIPCHK(hipDeviceSynchronize());
+    return ZK_OK;
+}
+// the Lagrange-form pool sizes of a key with n constraints: g1' = 3 + n + (n - 1) + n_mid points, g2' = 2 + n points
+int zk_groth16_lagrange_pool_sizes(uint64_t handle, uint64_t* g1_points, uint64_t* g2_points) {
+    Groth16Key* k;
+    ZKCHK(key_lookup(handle, &k));
+    if (g1_points) *g1_points = 3 + (uint64_t)k->n + (k->n - 1) + k->n_mid;
+    if (g2_points) *g2_points = 2 + (uint64_t)k->n;
+    return ZK_OK;
+}
+int zk_groth16_pk_derive_lagrange_sets(uint64_t handle, uint32_t sets, void* d_g1_out, void* d_g2_out) {
     Groth16Key* kp;
     ZKCHK(key_lookup(handle, &kp));
     Groth16Key& k = *kp;
-    if (k.lagrange) return ZK_OK;
-    if (k.world != 1) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_derive_lagrange: sharded keys hold only a slice of the powers");
-    for (uint32_t i = 0; i < MAX_SLOTS; i++)
-        if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_derive_lagrange: a proof is in flight on this key");
-    HIPCHK(hipDeviceSynchronize());
+    if (!d_g1_out || !d_g2_out || (sets & ~7u)) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_derive_lagrange_sets: bad argument");
+    if (k.lagrange) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_derive_lagrange_sets: the key already holds Lagrange-form pools");
+    ZKCHK(derive_precheck(k, "zk_groth16_pk_derive_lagrange_sets: a proof is in flight on this key"));
+    Ctx& c = ctx();
+    DevBuf d1, d2;
+    // window 0 of the resident tables IS the key as uploaded (pool order): back into the dense affine format the derivation reads
+    ZKCHK(d1.alloc(96 * k.g1.n));
+    ZKCHK(d2.alloc(192 * k.g2.n));
+    ZKCHK(msm_bases_dense(k.g1, 0, k.g1.n, d1.p, c.stream));
+    ZKCHK(msm_bases_dense(k.g2, 0, k.g2.n, d2.p, c.stream));
+    ZKCHK(groth16_derive_lagrange_pools(k.fr, d1.as<uint8_t>(), k.n_mid, d2.as<uint8_t>(), (uint8_t*)d_g1_out, (uint8_t*)d_g2_out, sets, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    return ZK_OK;
+}
+int zk_groth16_pk_install_lagrange(uint64_t handle, const void* d_g1, const void* d_g2, uint32_t rank, uint32_t world) {
+    Groth16Key* kp;
+    ZKCHK(key_lookup(handle, &kp));
+    Groth16Key& k = *kp;
+    if (!d_g1 || !d_g2 || world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_install_lagrange: bad argument");
+    if (k.lagrange) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_install_lagrange: the key already holds Lagrange-form pools");
+    ZKCHK(derive_precheck(k, "zk_groth16_pk_install_lagrange: a proof is in flight on this key"));
     Ctx& c = ctx();
     // Everything is built into TEMPORARIES first; the handle changes only after every allocation and launch has succeeded (an OOM while the new
     // window tables are built -- they are 13-16x the pools -- leaves the key exactly as it was: tau-power pools, tau-power Fr stage, lagrange = false).
     MsmBases g1, g2;
     const uint64_t p1n = 3 + (uint64_t)k.n + (k.n - 1) + k.n_mid, p2n = 2 + (uint64_t)k.n;
-    {
-        DevBuf n1, n2, d1, d2;
-        // window 0 of the resident tables IS the key as uploaded (pool order): back into the dense affine format the derivation reads
-        ZKCHK(d1.alloc(96 * k.g1.n));
-        ZKCHK(d2.alloc(192 * k.g2.n));
-        ZKCHK(msm_bases_dense(k.g1, 0, k.g1.n, d1.p, c.stream));
-        ZKCHK(msm_bases_dense(k.g2, 0, k.g2.n, d2.p, c.stream));
-        ZKCHK(groth16_derive_lagrange_pools(k.fr, d1.as<uint8_t>(), k.n_mid, d2.as<uint8_t>(), n1, n2, c.stream));
-        d1.release();
-        d2.release();
-        const uint32_t cw = key_window(p1n);
-        ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, n1.p, p1n, cw, true, c.stream));
-        ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, n2.p, p2n, cw, true, c.stream));
-        HIPCHK(hipStreamSynchronize(c.stream));          // n1 / n2 are released here: the table builds have read them
-    }
+    uint64_t lo1, hi1, lo2, hi2;
+    shard_range(p1n, p2n + 1, rank, world, &lo1, &hi1);        // p2n + 1 = 3 + the n Lagrange points: the A prefix counts twice
+    shard_range(p2n, 0, rank, world, &lo2, &hi2);
+    if (hi1 == lo1 || hi2 == lo2) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_install_lagrange: more ranks than key points");
+    const uint32_t cw = key_window(hi1 - lo1);
+    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, (const uint8_t*)d_g1 + 96 * lo1, hi1 - lo1, cw, true, c.stream));
+    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, (const uint8_t*)d_g2 + 192 * lo2, hi2 - lo2, cw, true, c.stream));
     ZKCHK(frstage_init_lagrange(k.fr, c.stream));        // ADDS the Lagrange tables to the Fr stage; the tau-power path keeps working until `lagrange` flips
-    HIPCHK(hipStreamSynchronize(c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));              // the caller's pools have been read
     HIPCHK(hipGetLastError());
     // ---- commit (nothing below can fail before the key is consistent again)
     for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();          // workspaces are sized for the old pools
     k.g1 = std::move(g1);
     k.g2 = std::move(g2);
     k.lagrange = true;
-    k.p1 = p1n; k.p2 = p2n; k.lo1 = 0; k.hi1 = p1n; k.lo2 = 0; k.hi2 = p2n;
+    k.rank = rank; k.world = world;
+    k.p1 = p1n; k.p2 = p2n; k.lo1 = lo1; k.hi1 = hi1; k.lo2 = lo2; k.hi2 = hi2;
     Slot* sl;
     ZKCHK(slot_get(k, 0, &sl));          // on failure the key is valid in Lagrange form; the slot is created at the next use
     return ZK_OK;
+}
+int zk_groth16_pk_derive_lagrange(uint64_t handle) {
+    Groth16Key* kp;
+    ZKCHK(key_lookup(handle, &kp));
+    Groth16Key& k = *kp;
+    if (k.lagrange) return ZK_OK;
+    DevBuf n1, n2;
+    ZKCHK(n1.alloc(96 * (3 + (uint64_t)k.n + (k.n - 1) + k.n_mid)));
+    ZKCHK(n2.alloc(192 * (2 + (uint64_t)k.n)));
+    ZKCHK(zk_groth16_pk_derive_lagrange_sets(handle, 7, n1.p, n2.p));
+    return zk_groth16_pk_install_lagrange(handle, n1.p, n2.p, 0, 1);
 }
 int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
     Groth16Key* kp;

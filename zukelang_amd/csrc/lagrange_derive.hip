@@ -422,33 +422,34 @@ template <class T> static int derive_set(const DeriveTables& t, const uint8_t* d
 
 // Pools of a key in the reference's layout (device, dense affine)  g1 = a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid,  g2 = b2 | d2 | ti2[n+2]
 // -> the Lagrange-form pools  g1' = a | d1 | b1 | [l_i]_1 (n) | [lambda_t Z/delta]_1 (n-1) | ltd_mid,  g2' = b2 | d2 | [l_i]_2 (n)  (device, dense affine).
-int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, DevBuf& out_g1, DevBuf& out_g2, hipStream_t s) {
+// The three derived sets are independent of one another: `sets` selects them (bit 0: [l_i]_1, bit 1: [l_i]_2, bit 2: the h bases) -- N ranks of
+// a node derive one set each and broadcast it instead of N redundant derivations (zk_groth16_pk_derive_lagrange_sets).  The copied parts
+// (a | d1 | b1, ltd_mid, b2 | d2) are always written; a set that is not selected leaves its region of the output untouched.
+int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, uint8_t* out_g1, uint8_t* out_g2, uint32_t sets, hipStream_t s) {
     const uint32_t n = f.n;
-    const uint64_t p1n = 3 + (uint64_t)n + (n - 1) + n_mid, p2n = 2 + (uint64_t)n;
-    ZKCHK(out_g1.alloc(96 * p1n));
-    ZKCHK(out_g2.alloc(192 * p2n));
     const uint64_t o_ti = 3, o_tz = 3 + ((uint64_t)n + 2), o_lt = o_tz + (n - 1);
-    HIPCHK(hipMemcpyAsync(out_g1.p, d_g1, 96 * 3, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(out_g1.as<uint8_t>() + 96 * (3 + (uint64_t)n + (n - 1)), d_g1 + 96 * o_lt, 96 * n_mid, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(out_g2.p, d_g2, 192 * 2, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(out_g1, d_g1, 96 * 3, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(out_g1 + 96 * (3 + (uint64_t)n + (n - 1)), d_g1 + 96 * o_lt, 96 * n_mid, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(out_g2, d_g2, 192 * 2, hipMemcpyDeviceToDevice, s));
     if (n == 1) {      // one gate: l_0 = 1, the Lagrange point IS [tau^0]
-        HIPCHK(hipMemcpyAsync(out_g1.as<uint8_t>() + 96 * 3, d_g1 + 96 * o_ti, 96, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(out_g2.as<uint8_t>() + 192 * 2, d_g2 + 192 * 2, 192, hipMemcpyDeviceToDevice, s));
+        if (sets & 1) HIPCHK(hipMemcpyAsync(out_g1 + 96 * 3, d_g1 + 96 * o_ti, 96, hipMemcpyDeviceToDevice, s));
+        if (sets & 2) HIPCHK(hipMemcpyAsync(out_g2 + 192 * 2, d_g2 + 192 * 2, 192, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
         return ZK_OK;
     }
-    {
+    if (sets & 3) {
         ScopedTimer tm("lagrange_derive", s);
         DeriveTables t0;
         ZKCHK(derive_tables_build(t0, f, 0, s));
-        ZKCHK(derive_set<Fp>(t0, d_g1 + 96 * o_ti, n, out_g1.as<uint8_t>() + 96 * 3, s));
-        ZKCHK(derive_set<Fp2H>(t0, d_g2 + 192 * 2, n, out_g2.as<uint8_t>() + 192 * 2, s));
+        if (sets & 1) ZKCHK(derive_set<Fp>(t0, d_g1 + 96 * o_ti, n, out_g1 + 96 * 3, s));
+        if (sets & 2) ZKCHK(derive_set<Fp2H>(t0, d_g2 + 192 * 2, n, out_g2 + 192 * 2, s));
     }
-    if (n > 1) {
+    if (sets & 4) {
         DeriveTables tn;                       // the points n .. 2n-2 of the h values
         ZKCHK(derive_tables_build(tn, f, n, s));
-        ZKCHK(derive_set<Fp>(tn, d_g1 + 96 * o_tz, n - 1, out_g1.as<uint8_t>() + 96 * (3 + (uint64_t)n), s));
+        ZKCHK(derive_set<Fp>(tn, d_g1 + 96 * o_tz, n - 1, out_g1 + 96 * (3 + (uint64_t)n), s));
     }
+    HIPCHK(hipStreamSynchronize(s));
     return ZK_OK;
 }
 

@@ -75,7 +75,11 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
 // step 4 of msm_run (msm_acc_g1.hip / msm_acc_g2.hip) for up to 4 MSMs over the same table in one launch (blockIdx.y = job)
 static constexpr uint32_t MAX_ACC_JOBS = 4;
 // waves per SIMD of the accumulate kernels (msm_acc.cuh compiles to them, msm_workspace_alloc sizes the chunks for whole rounds of them)
-static constexpr uint32_t ACC_WAVES_G1 = 3, ACC_WAVES_G2 = 2;
+// Measured alternatives (round 3, same box A/B at 2^16 and 2^20): G1 at THREE waves fits 168 registers (15 of them spilled once the table entry no
+// longer sits in scratch) and is no faster, alone or pipelined -- the chip runs at its power cap while proving (1.3 kW, 2.23 GHz) and the mixed
+// addition alone, operands in registers, runs at this kernel's rate (scripts/proto/madd_rate.hip); G2 at ONE wave (293 registers, no spill) is 4 %
+// slower alone at 2^20, 13 % at 2^16, and 1 % slower pipelined than two waves with 40 spilled registers.
+static constexpr uint32_t ACC_WAVES_G1 = 2, ACC_WAVES_G2 = 2;
 struct AccJobs {
     const uint32_t* offsets[MAX_ACC_JOBS];
     const uint32_t* sorted[MAX_ACC_JOBS];

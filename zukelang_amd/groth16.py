@@ -271,6 +271,52 @@ class Groth16:
         O(n log^2 n) scalar multiplications, no tau needed); the proofs stay byte-identical, the per-proof basis conversion disappears."""
         _lib.check(_lib.lib().zk_groth16_pk_derive_lagrange(self.handle))
 
+    def derive_lagrange_shared(self, rank, world):
+        """The derivation shared by the `world` ranks of a node (every rank holds the key whole, as uploaded): the three derived sets are
+        independent, so each is derived ONCE -- set 0 ([l_i]_1) and set 2 (the h bases) on ranks 0 and 2 (both on rank 0 of a two-rank
+        world), set 1 ([l_i]_2) on rank 1 -- broadcast from its owner (RCCL on device memory; gloo through the host in the CPU rehearsals)
+        and installed as this rank's shard (zk_groth16_pk_install_lagrange).  Same pools, same proofs as derive_lagrange() + shard(); the
+        wall time is the longest single set instead of the sum of all three on every rank."""
+        import torch
+        import torch.distributed as dist
+        L = _lib.lib()
+        if world == 1:
+            return self.derive_lagrange()
+        n1, n2 = C.c_uint64(), C.c_uint64()
+        _lib.check(L.zk_groth16_lagrange_pool_sizes(self.handle, C.byref(n1), C.byref(n2)))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t1 = torch.zeros(96 * n1.value, dtype=torch.uint8, device=dev)
+        t2 = torch.zeros(192 * n2.value, dtype=torch.uint8, device=dev)
+        owner = [0, 1, 0] if world == 2 else [0, 1, 2]
+        mask = sum(1 << s for s in range(3) if owner[s] == rank)
+        rc = L.zk_groth16_pk_derive_lagrange_sets(self.handle, C.c_uint32(mask), C.c_void_p(t1.data_ptr()), C.c_void_p(t2.data_ptr()))
+        worst = agree_on_status(rc)
+        if worst != 0:
+            if rc == worst:
+                _lib.check(rc)
+            raise _lib.ZkError(worst, "a peer rank failed while deriving its set of the Lagrange-form pools")
+        n = self.circuit.n
+        regions = [(t1, 96 * 3, 96 * (3 + n)), (t2, 192 * 2, 192 * (2 + n)), (t1, 96 * (3 + n), 96 * (3 + n + n - 1))]
+        on_device = dist.get_backend() == "nccl"
+        for s, (t, lo, hi) in enumerate(regions):
+            if hi <= lo:
+                continue
+            part = t[lo:hi]
+            if on_device:
+                dist.broadcast(part, src=owner[s])
+            else:
+                host = part.cpu()
+                dist.broadcast(host, src=owner[s])
+                part.copy_(host)
+        torch.cuda.current_stream().synchronize()
+        rc = L.zk_groth16_pk_install_lagrange(self.handle, C.c_void_p(t1.data_ptr()), C.c_void_p(t2.data_ptr()), C.c_uint32(rank), C.c_uint32(world))
+        worst = agree_on_status(rc)
+        if worst != 0:
+            if rc == worst:
+                _lib.check(rc)
+            raise _lib.ZkError(worst, "a peer rank failed while installing the derived pools")
+        self.rank, self.world = rank, world
+
     def shard(self, rank, world):
         """Turns a key uploaded whole (and possibly derived into its Lagrange form) into `rank`'s shard of a point-sharded prover
         (zk_groth16_pk_shard): afterwards prove_rs / prove_async / prove_wait run the all-gather + combine of the sharded path."""
