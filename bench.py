@@ -293,6 +293,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     else:
         prover = Groth16(cs, pk, rank, world, lagrange=lagrange)
     prover.set_witness(w)
+    w_host = RC.fr_bytes(w) if args.host_witness else None          # --host-witness: every proof gets the witness as a HOST buffer (one PCIe copy per proof)
     pps = args.proofs_per_step
     nproofs = steps * pps
     nwarm = warmup * pps
@@ -327,11 +328,11 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
         last = None
         for i in range(count):
             if depth == 1:
-                last = prover.prove_rs(None, *rs[(first + i) % len(rs)])
+                last = prover.prove_rs(w_host, *rs[(first + i) % len(rs)])
                 continue
             if i >= depth:
                 last = prover.prove_wait(i % depth)
-            prover.prove_async(None, *rs[(first + i) % len(rs)], i % depth)
+            prover.prove_async(w_host, *rs[(first + i) % len(rs)], i % depth)
         if depth > 1:
             for i in range(max(0, count - depth), count):
                 last = prover.prove_wait(i % depth)
@@ -635,6 +636,8 @@ def main():
     ap.add_argument("--derive-lagrange-upto", type=int, default=20, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
                     "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.7 s at 2^16, 9.5 s at 2^18, 45 s at 2^20, 3.6 min at 2^22) and "
                     "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
+    ap.add_argument("--host-witness", action="store_true", help="one GPU: hand the witness over as a host buffer with every proof (the PCIe-inclusive rate of DESIGN.md 8) instead of "
+                    "proving from the copy made resident by zk_groth16_set_witness; never the headline")
     ap.add_argument("--derived-only", action="store_true", help="profiling runs: derive the key's Lagrange form right after the upload and measure only that path "
                     "(the default measures the key as uploaded first: its kernels would mix into rocprofv3's per-kernel statistics)")
     ap.add_argument("--tau-power-key", action="store_true", help="N > 1: keep the key in tau-power form (sharded at upload) instead of deriving the Lagrange form on every rank")
@@ -739,7 +742,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "groth16_prove, iterated-cubic R1CS (u -> u^3+u+3), BLS12-381, key+circuit+witness resident in HBM"
+            "config": {"workload": "groth16_prove, iterated-cubic R1CS (u -> u^3+u+3), BLS12-381, " + ("key+circuit resident in HBM, witness handed over as a HOST buffer with every proof (PCIe-inclusive)" if args.host_witness else "key+circuit+witness resident in HBM")
                                    + (", LAGRANGE-FORM KEY EXTENSION (not the reference key format)" if args.lagrange_key else "")
                                    + (", reference-format key (tau powers) uploaded, its Lagrange form DERIVED on the device once (zk_groth16_pk_derive_lagrange); tau_power_form = the same key before the derivation" if head.get("derive_lagrange_s") is not None else ""),
                        "step": "%d consecutive proofs of the pipelined prover (pipeline not drained between steps)" % args.proofs_per_step,
