@@ -98,10 +98,12 @@ typedef struct {
  *   g2: b2 | d2 | ti2[n+2]
  *   mid[k] != 0  <=>  variable k is in Dom(ltd_mid) (= circuit.mids, groth16.ml:74-79).
  * Uploads once, precomputes the per-n tables of the Fr stage, returns a handle.
- * Base points (here, in zk_msm_g1/g2 and in the Pinocchio upload) are checked for a canonical encoding and the curve equation
- * (ZK_ERR_ARG / ZK_ERR_NOT_ON_CURVE) and are otherwise TRUSTED to lie in the prime-order subgroup G1 / G2, as every point an
- * OCaml host obtained from Bls12_381.G1/G2 does (of_bytes_exn / of_compressed_bytes_exn reject anything else, curve.ml:199-212).
- * The entry points that take points from outside -- zk_g1/g2_decompress, zk_pairing_*, zk_*_verify -- do check the subgroup. */
+ * KEY points (here, in the sharded / Lagrange-form uploads and in the Pinocchio upload) are checked the way the reference checks them on the way in
+ * (of_bytes_exn / of_compressed_bytes_exn, curve.ml:199-212): canonical encoding (ZK_ERR_ARG), curve equation and membership of the prime-order
+ * subgroup, [r] P = O on the device (both ZK_ERR_NOT_ON_CURVE; 0.3 s of a 2^20-constraint upload; ZK_KEY_SUBGROUP_CHECK=0 in the environment skips the
+ * subgroup part for keys that were checked before).  The per-call bases of zk_msm_g1/g2 are checked for encoding and curve equation only and otherwise
+ * TRUSTED to lie in G1 / G2, as every point an OCaml host obtained from Bls12_381.G1/G2 does.
+ * The entry points that take points from outside -- zk_g1/g2_decompress, zk_pairing_*, zk_*_verify -- check the subgroup on the host. */
 int zk_groth16_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                          const uint8_t* mid /* m */, const uint8_t* pk_g1, size_t pk_g1_points,
                          const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);

@@ -65,3 +65,47 @@ def test_pinocchio_slot_misuse():
     with pytest.raises(_lib.ZkError):
         pr.prove_wait(3)                                   # slot never used
     pr.close()
+
+
+def _point_outside_the_subgroup():
+    """a point of E(Fp): y^2 = x^3 + 4 whose order does not divide r (the cofactor part of the curve group)"""
+    x = 0
+    while True:
+        x += 1
+        y2 = (x ** 3 + 4) % P.P
+        y = pow(y2, (P.P + 1) // 4, P.P)
+        if y * y % P.P == y2:
+            pt = (P.Fp1(x), P.Fp1(y))
+            if P.pt_mul(pt, P.R) is not None:
+                return pt
+
+
+def test_key_points_outside_the_prime_order_subgroup_are_rejected_at_upload():
+    """The reference's keys hold Bls12_381.G1/G2 values, which of_bytes_exn / of_compressed_bytes_exn (curve.ml:199-212) refuse to build from a point
+    of the curve outside the r-torsion; a key uploaded as raw bytes gets the same check on the device ([r] P = O), for both protocols.  Identity
+    points stay legal and a point off the curve is still its own error."""
+    cs, w = RC.iterated_cubic(8, 3)
+    rng = seeded(0xE46)
+    pk, _ = Groth16.keygen(rng, cs)
+    Groth16(cs, pk).close()                                              # the honest key passes
+    bad = P.g1_to_bytes(_point_outside_the_subgroup())
+    for idx in (0, 5, len(pk.g1) // 96 - 1):
+        g1 = np.array(pk.g1, dtype=np.uint8, copy=True)
+        g1[96 * idx:96 * idx + 96] = np.frombuffer(bad, dtype=np.uint8)
+        with pytest.raises(_lib.ZkError) as e:
+            Groth16(cs, type(pk)(g1, pk.g2))
+        assert e.value.code == -2 and "subgroup" in str(e.value)
+    inf = np.zeros(96, dtype=np.uint8); inf[0] = 0x40
+    g1 = np.array(pk.g1, dtype=np.uint8, copy=True)
+    g1[96 * 4:96 * 5] = inf                                              # the identity is a member of every subgroup
+    Groth16(cs, type(pk)(g1, pk.g2)).close()
+    off = np.array(pk.g1, dtype=np.uint8, copy=True)
+    off[96 * 3 + 95] ^= 1
+    with pytest.raises(_lib.ZkError) as e:
+        Groth16(cs, type(pk)(off, pk.g2))
+    assert e.value.code == -2 and "subgroup" not in str(e.value)
+    pkp, _ = PIN.ZK.keygen(seeded(0xE47), cs)
+    g1p = np.array(pkp.g1, dtype=np.uint8, copy=True)
+    g1p[96 * 2:96 * 3] = np.frombuffer(bad, dtype=np.uint8)
+    with pytest.raises(_lib.ZkError):
+        PIN.ZK(cs, type(pkp)(g1p, pkp.g2))

@@ -52,7 +52,8 @@ struct MsmWorkspace {
 };
 
 uint32_t msm_auto_window(uint64_t n, bool precomp);
-int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
+// check_subgroup: also require [r] P = O of every point (proving keys: the reference's of_bytes_exn raises otherwise, curve.ml:199-212)
+int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s, bool check_subgroup = false);
 // d_affine: n DENSE affine points (96 / 192 B each); it must stay valid until the stream has run the table build
 int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
 // base points [lo, lo + count) of the set (window 0 of the table) back in the dense affine format, exact

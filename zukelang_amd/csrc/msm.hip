@@ -121,6 +121,25 @@ __global__ __launch_bounds__(64) void k_proof_to_bytes(const uint8_t* g1, uint32
     else aff_encode(out + off.g2[b - n1], xyzz_to_aff(xyzz_load<Fp2>(g2 + 384 * (size_t)(b - n1))));
 }
 
+// ------------------------------------------------------------------ prime-order subgroup check of uploaded KEY points: [r] P = O
+// The reference's points come from Bls12_381.G1/G2.of_bytes_exn / of_compressed_bytes_exn (curve.ml:199-212), which raise on a point of the curve
+// that lies outside the r-torsion; a key uploaded to the library as raw bytes gets the same treatment here.  Plain double-and-add over the bits of r
+// (a compile-time constant: the branch is wave-uniform), out-of-line group operations: ~255 doublings + 127 additions per point, 0.3 s of a 2^20 key.
+__device__ static const uint32_t FR_ORDER_BITS[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+template <class F> __global__ __launch_bounds__(128) void k_subgroup_check(const uint8_t* __restrict__ dense, uint64_t n, int* flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int B = FieldOps<F>::WORDS * 8;
+    const Aff<F> p = aff_load<F>(dense + B * i);
+    if (aff_is_inf(p)) return;
+    Xyzz<F> acc = xyzz_from_aff(p);                      // the top bit (254) of r
+    for (int b = 253; b >= 0; b--) {
+        acc = xyzz_dbl(acc);
+        if ((FR_ORDER_BITS[b >> 5] >> (b & 31)) & 1u) xyzz_madd(acc, p);
+    }
+    if (!xyzz_is_inf(acc)) atomicOr(flag, 4);
+}
+
 // ------------------------------------------------------------------ base tables: table[j*n + i] = 2^(c*j) * P_i, j < nw
 // `dense` holds the n base points in the dense affine format (what the key arrived as); the table takes them -- and with nw > 1 their
 // multiples by 2^(c j) -- in the 128-byte record layout of ec.cuh (TableLayout).
@@ -977,7 +996,7 @@ int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine,
     ZKCHK(bases_setup(b, curve, n, c, precomp));
     return curve == CURVE_G1 ? bases_finish<Fp>(b, d_affine, s) : bases_finish<Fp2>(b, d_affine, s);
 }
-int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s) {
+int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s, bool check_subgroup) {
     ZKCHK(bases_setup(b, curve, n, c, precomp));
     DevBuf raw, dense, flag;
     ZKCHK(raw.alloc(aff_bytes(curve) * n));
@@ -986,11 +1005,17 @@ int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, ui
     HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
     HIPCHK(hipMemcpyAsync(raw.p, host_bytes, aff_bytes(curve) * n, hipMemcpyHostToDevice, s));
     ZKCHK(points_bytes_to_affine(curve, dense.p, raw.p, n, flag.as<int>(), s));
+    if (check_subgroup) {
+        ScopedTimer t("subgroup_check", s);
+        if (curve == CURVE_G1) hipLaunchKernelGGL(k_subgroup_check<Fp>, grid_for(n, 128), dim3(128), 0, s, (const uint8_t*)dense.as<uint8_t>(), n, flag.as<int>());
+        else hipLaunchKernelGGL(k_subgroup_check<Fp2>, grid_for(n, 128), dim3(128), 0, s, (const uint8_t*)dense.as<uint8_t>(), n, flag.as<int>());
+    }
     int h = 0;
     HIPCHK(hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (h & 2) ZK_FAIL(ZK_ERR_ARG, "point encoding: compressed flag set or coordinate >= p");
     if (h & 1) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "a base point is not on the curve");
+    if (h & 4) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "a key point is on the curve but outside the prime-order subgroup (of_bytes_exn, curve.ml:199-212)");
     ZKCHK((curve == CURVE_G1 ? bases_finish<Fp>(b, dense.p, s) : bases_finish<Fp2>(b, dense.p, s)));
     HIPCHK(hipStreamSynchronize(s));          // `dense` is released on return: the table build has read it
     return ZK_OK;

@@ -48,6 +48,12 @@ struct PinSlot {
     }
 };
 static constexpr uint32_t PIN_MAX_SLOTS = 15;
+// key points are checked like the reference checks them on the way in (of_bytes_exn, curve.ml:199-212: encoding, curve, prime-order subgroup);
+// ZK_KEY_SUBGROUP_CHECK=0 skips the subgroup part (see groth16.hip)
+static bool key_subgroup_check() {
+    static const bool chk = !(getenv("ZK_KEY_SUBGROUP_CHECK") && atoi(getenv("ZK_KEY_SUBGROUP_CHECK")) == 0);
+    return chk;
+}
 struct PinKey {
     uint32_t n = 0, m = 0, n_mid = 0;
     FrStage fr;
@@ -148,7 +154,7 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     auto pool1 = [&](int idx, const uint8_t* base, uint64_t cnt, std::initializer_list<const uint8_t*> extras) -> int {
         buf.assign(base, base + 96 * cnt);
         for (auto e : extras) buf.insert(buf.end(), e, e + 96);
-        return msm_bases_from_bytes(k.g1[idx], CURVE_G1, buf.data(), buf.size() / 96, 0, true, c.stream);
+        return msm_bases_from_bytes(k.g1[idx], CURVE_G1, buf.data(), buf.size() / 96, 0, true, c.stream, key_subgroup_check());
     };
     ZKCHK(pool1(0, VV, nm, {ONES + 96 * 0}));
     ZKCHK(pool1(1, YY, nm, {ONES + 96 * 1}));
@@ -159,7 +165,7 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     auto pool2 = [&](int idx, const uint8_t* base, const uint8_t* extra) -> int {
         buf.assign(base, base + 192 * nm);
         buf.insert(buf.end(), extra, extra + 192);
-        return msm_bases_from_bytes(k.g2[idx], CURVE_G2, buf.data(), nm + 1, 0, true, c.stream);
+        return msm_bases_from_bytes(k.g2[idx], CURVE_G2, buf.data(), nm + 1, 0, true, c.stream, key_subgroup_check());
     };
     ZKCHK(pool2(0, WW, ONES2));
     ZKCHK(pool2(1, WAW, ONES2 + 192));
