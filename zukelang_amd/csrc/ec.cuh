@@ -132,7 +132,7 @@ template <class F, bool Q_MAY_BE_INF = true> FF_INLINE void xyzz_madd_impl(Xyzz<
     const auto PP = fe_sqr(P);
     const auto PPP = fe_mul(P, PP);
     const auto Q = fe_mul(acc.x, PP);
-    const auto X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    const auto X3 = fe_sub_sub_dbl(fe_sqr(R), PPP, Q);          // R^2 - PPP - 2 Q, one carry pass
     const auto Y3 = fe_mul_sub(R, fe_sub(Q, X3), acc.y, PPP);
     acc.x = X3;
     acc.y = Y3;
@@ -158,7 +158,7 @@ template <class F, bool Q_MAY_BE_INF = true> FF_INLINE void xyzz_mmadd_impl(Xyzz
     const auto PP = fe_sqr(P);
     const auto PPP = fe_mul(P, PP);
     const auto Q = fe_mul(acc.x, PP);
-    const auto X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    const auto X3 = fe_sub_sub_dbl(fe_sqr(R), PPP, Q);          // R^2 - PPP - 2 Q, one carry pass
     const auto Y3 = fe_mul_sub(R, fe_sub(Q, X3), acc.y, PPP);
     acc.x = X3;
     acc.y = Y3;
@@ -186,7 +186,7 @@ template <class F> FF_INLINE void xyzz_add_impl(Xyzz<F>& acc, const Xyzz<F>& q) 
     const auto PP = fe_sqr(P);
     const auto PPP = fe_mul(P, PP);
     const auto Q = fe_mul(U1, PP);
-    const auto X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    const auto X3 = fe_sub_sub_dbl(fe_sqr(R), PPP, Q);          // R^2 - PPP - 2 Q, one carry pass
     const auto Y3 = fe_mul_sub(R, fe_sub(Q, X3), S1, PPP);
     acc.x = X3;
     acc.y = Y3;

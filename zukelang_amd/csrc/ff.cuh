@@ -291,8 +291,8 @@ template <class P> FF_INLINE void fe_store(void* p, const Fe<P>& a) {
 
 // ================================================================== Fp: 14 limbs x 29 bits, R = 2^406
 // Invariants of every FpB<B> held in registers:
-//   value < B * p;   limbs 0..12 <= 2^29 + 3 ("weakly normalised"), limb 13 holds the rest (small).
-// Column bound of the product: 14 (2^29+3)^2 + 14 (2^29)^2 + carry < 2^62.9.
+//   value < B * p;   limbs 0..12 <= 2^29 + 7 ("weakly normalised": one carry pass over limbs < 2^32 leaves at most 2^29 - 1 + 7), limb 13 holds the rest (small).
+// Column bound of the product: 14 (2^29+7)^2 + 14 (2^29)^2 + carry < 2^62.9.
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -373,6 +373,31 @@ template <int A, int B> FF_INLINE FpB<A + fp_ks(B)> fe_sub(const FpB<A>& a, cons
 #pragma unroll
     for (int i = 0; i < FPL; i++) r.v[i] = a.v[i] + (FP29_KP[KI][i] - b.v[i]);
     fp_carry(r.v);
+    return r;
+}
+// a - b - 2 c + K p in ONE carry pass, K = fp_ks(B + 2 C): X3 = R^2 - PPP - 2 Q of every group addition (composed from fe_sub / fe_dbl it was three carry
+// passes).  The WIDE spread of K p (limbs >= 2^31 - 4) covers b_i + 2 c_i <= 3 (2^29 + 7) without a borrow and keeps every limb below 2^32.
+template <int A, int B, int C> FF_INLINE FpB<A + fp_ks(B + 2 * C)> fe_sub_sub_dbl(const FpB<A>& a, const FpB<B>& b, const FpB<C>& c) {
+    constexpr int KI = fp_ki(fp_ks(B + 2 * C));
+    static_assert(KI >= 1 && KI < FP29_NK, "subtrahend bound out of range");
+    FpB<A + fp_ks(B + 2 * C)> r;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) r.v[i] = a.v[i] + (FP29_KPW[KI][i] - b.v[i] - (c.v[i] << 1));
+    fp_carry(r.v);
+    return r;
+}
+// K p - a WITHOUT a carry pass (narrow spread: limbs in [1, 2^30]): legal only as the second LEFT factor of the fused double product below, whose
+// columns then hold 14 (2^29+7)^2 + 14 (2^30)(2^29+7) + 14 (2^29)(2^29) + carry < 56 * 2^58 * (1 + 2^-20) < 2^64.
+template <int K> struct FpLazyNeg {
+    static constexpr int BOUND = K;
+    uint32_t v[FPL];
+};
+template <int A> FF_INLINE FpLazyNeg<fp_ks(A)> fe_neg_lazy(const FpB<A>& a) {
+    constexpr int KI = fp_ki(fp_ks(A));
+    static_assert(KI < FP29_NK, "bound too large");
+    FpLazyNeg<fp_ks(A)> r;
+#pragma unroll
+    for (int i = 0; i < FPL; i++) r.v[i] = FP29_KPN[KI][i] - a.v[i];
     return r;
 }
 template <int A> FF_INLINE FpB<fp_ks(A)> fe_neg(const FpB<A>& a) {
@@ -673,6 +698,9 @@ template <int A, int B> FF_INLINE bool fe_eq(const Fp2B<A>& a, const Fp2B<B>& b)
 template <int A, int B> FF_INLINE Fp2B<A + B> fe_add(const Fp2B<A>& a, const Fp2B<B>& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
 template <int A, int B> FF_INLINE Fp2B<A + fp_ks(B)> fe_sub(const Fp2B<A>& a, const Fp2B<B>& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
 template <int A> FF_INLINE Fp2B<fp_ks(A)> fe_neg(const Fp2B<A>& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+template <int A, int B, int C> FF_INLINE Fp2B<A + fp_ks(B + 2 * C)> fe_sub_sub_dbl(const Fp2B<A>& a, const Fp2B<B>& b, const Fp2B<C>& c) {
+    return {fe_sub_sub_dbl(a.c0, b.c0, c.c0), fe_sub_sub_dbl(a.c1, b.c1, c.c1)};
+}
 template <int A> FF_INLINE Fp2B<2 * A> fe_dbl(const Fp2B<A>& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
 // Karatsuba: 3 base multiplications.  c0 = t0 - t1 < 6p, c1 = s - (t0 + t1) < 10p
 template <int A, int B> FF_INLINE Fp2B<10> fe_mul(const Fp2B<A>& a, const Fp2B<B>& b) {
@@ -726,6 +754,7 @@ template <int A, int B> FF_INLINE Fp2HB<A + B> fe_add(const Fp2HB<A>& a, const F
 template <int A, int B> FF_INLINE Fp2HB<A + fp_ks(B)> fe_sub(const Fp2HB<A>& a, const Fp2HB<B>& b) { return {fe_sub(a.v, b.v)}; }
 template <int A, int B> FF_INLINE bool fe_eq(const Fp2HB<A>& a, const Fp2HB<B>& b) { return fe_is_zero(fe_sub(a, b)); }
 template <int A> FF_INLINE Fp2HB<fp_ks(A)> fe_neg(const Fp2HB<A>& a) { return {fe_neg(a.v)}; }
+template <int A, int B, int C> FF_INLINE Fp2HB<A + fp_ks(B + 2 * C)> fe_sub_sub_dbl(const Fp2HB<A>& a, const Fp2HB<B>& b, const Fp2HB<C>& c) { return {fe_sub_sub_dbl(a.v, b.v, c.v)}; }
 template <int A> FF_INLINE Fp2HB<2 * A> fe_dbl(const Fp2HB<A>& a) { return {fe_dbl(a.v)}; }
 // Fp2 product on a lane pair as ONE fused double product per lane, (x1 y1 + x2 y2) / R with a single
 // Montgomery reduction (28 + 14 partial products per column still fit 64 bits):
@@ -771,9 +800,8 @@ FF_INLINE void fp2h_mul_body(uint32_t* __restrict__ r, const uint32_t* __restric
         const uint32_t ao = (uint32_t)__builtin_amdgcn_mov_dpp((int)a[i], 0xB1, 0xF, 0xF, true);
         bo[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)b[i], 0xB1, 0xF, 0xF, true);
         x1[i] = c1 ? ao : a[i];
-        x2[i] = c1 ? a[i] : FP29_KP[KI][i] - ao;
+        x2[i] = c1 ? a[i] : FP29_KPN[KI][i] - ao;          // 256 p - a1, narrow spread, NO carry pass: a lazy left factor (see fe_neg_lazy), limbs <= 2^30
     }
-    fp_carry(x2);
     fp_mul2_limbs(r, x1, b, x2, bo);
 }
 __device__ __noinline__ static FpRaw fp2h_mul_call(FP_ARGS(a), FP_ARGS(b)) {
@@ -828,7 +856,7 @@ __device__ __noinline__ static FpRaw fp_mul2_call(FP_ARGS(a), FP_ARGS(b), const 
 }
 template <int A, int B, int C, int D> FF_INLINE FpB<2> fe_mul_sub(const FpB<A>& a, const FpB<B>& b, const FpB<C>& c, const FpB<D>& d) {
     static_assert((long long)A * B + (long long)fp_ks(C) * D <= FP_MUL_BUDGET, "operand bounds exceed the Montgomery headroom");
-    const auto nc = fe_neg(c);
+    const auto nc = fe_neg_lazy(c);          // no carry pass: the fused product's columns have room for ONE factor of limbs <= 2^30
 #ifdef ZK_FP_INLINE_MUL
     FpB<2> r;
     fp_mul2_limbs(r.v, a.v, b.v, nc.v, d.v);

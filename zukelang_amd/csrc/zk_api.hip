@@ -110,7 +110,7 @@ __global__ void k_bench_mul_fp(uint32_t* out, uint32_t iters) {
 // operand pair through the SAME lazy-reduction code paths the group law uses (bounded adds / subs, products,
 // squares, fused double products, the zero test on unreduced values, inversion, full reduction, lane-pair Fp2)
 // and stores fully reduced plain integers (dense words) for comparison with host big-integer arithmetic.
-static constexpr int FP_SELFTEST_OUTS = 18;
+static constexpr int FP_SELFTEST_OUTS = 22;
 __global__ void k_fp_selftest(uint32_t* __restrict__ out, const uint32_t* __restrict__ a_words, const uint32_t* __restrict__ b_words, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;                      // n is even and pairs (2k, 2k+1) stay together: the lane-pair ops below are uniform
@@ -151,6 +151,14 @@ __global__ void k_fp_selftest(uint32_t* __restrict__ out, const uint32_t* __rest
     put(15, fp_from_mont(fe_mul_inline(a, b)));
     put(16, fp_from_mont(fe_inv_fast(fe_add(fe_dbl(a), fe_neg(a)))));                  // lockstep inversion (fp_inv.cuh) of a lazily reduced a
     put(17, fp_from_mont(fe_inv_fast(x).v));                                            // ... and of the lane pair's Fp2 value
+    // round 3: a - b - 2 c in one carry pass (X3 of every group addition), on products and on lazily reduced operands at the at-rest bound
+    put(18, fp_from_mont(fe_sub_sub_dbl(fe_sqr(a), fe_mul(a, b), fe_mul(b, fe_add(a, b)))));                    // a^2 - a b - 2 b (a + b)
+    const Fp big = Fp(fe_sub(fe_dbl(fe_dbl(fe_dbl(fe_dbl(a)))), b));                                             // 16 a - b as a value < 64 p with unreduced limbs
+    put(19, fp_from_mont(fe_sub_sub_dbl(a, big, big)));                                                          // a - 3 (16 a - b)
+    // the fused double product with its lazily negated factor (fe_neg_lazy: no carry pass) at the at-rest bound: a b - (16 a - b) b
+    put(20, fp_from_mont(fe_mul_sub(a, b, big, b)));
+    // lane-pair Fp2 product whose left operand is lazily reduced at the at-rest bound: (16 x - y) * y
+    put(21, fp_from_mont(fe_mul(Fp2H(big), y).v));
 }
 
 }  // namespace zk
