@@ -285,8 +285,8 @@ int zk_sync(void);                                 /* waits for everything the l
  * kind | 4: one wave on the whole chip (dependent-chain latency).  kind | 8: the best rate over 2 / 4 / 6 / 8 waves per SIMD. */
 int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s);
 /* Field-layer self-test hook (tests/test_gpu_field.py): for each of n (even) operand pairs a_i, b_i < p (48-byte little-endian
- * integers) the device evaluates 22 base-field expressions through the lazy-reduction code paths of the group law and
- * returns them fully reduced (22 x 48 B per pair, little-endian); pairs (2k, 2k+1) also act as one Fp2 operand pair. */
+ * integers) the device evaluates 23 base-field expressions through the lazy-reduction code paths of the group law and
+ * returns them fully reduced (23 x 48 B per pair, little-endian); pairs (2k, 2k+1) also act as one Fp2 operand pair. */
 int zk_selftest_fp(const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
 
 #if defined(__GNUC__)

@@ -1,5 +1,5 @@
 """GPU parity of the base-field layer (14 x 29-bit limbs, lazy reduction, value bounds in the type):
-zk_selftest_fp evaluates 22 expressions per operand pair through the same code paths the group law uses;
+zk_selftest_fp evaluates 23 expressions per operand pair through the same code paths the group law uses;
 the expected values are Python big-integer arithmetic mod p.  Edge operands: 0, 1, p-1, values whose limbs are
 all-ones at the 29-bit boundaries, a = b, a + b = p."""
 import ctypes as C
@@ -13,7 +13,7 @@ from zukelang_amd import _lib
 
 pytestmark = pytest.mark.gpu
 p = P.P
-NOUT = 22
+NOUT = 23
 
 
 def le48(x):
@@ -76,3 +76,4 @@ def test_field_battery_matches_big_integers():
         assert get(i, 20) == (x * y - big * y) % p, (i, "fe_mul_sub with a lazily negated factor", hex(x), hex(y))
         b0, b1 = (16 * x0 - y0) % p, (16 * x1 - y1) % p
         assert get(i, 21) == ((b0 * y0 - b1 * y1) % p, (b0 * y1 + b1 * y0) % p)[c], (i, "fp2 lane-pair product, lazily reduced left operand")
+        assert get(i, 22) == ((b0 * b0 - b1 * b1) % p, 2 * b0 * b1 % p)[c], (i, "fp2 lane-pair square with the lazy difference")

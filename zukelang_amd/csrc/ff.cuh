@@ -823,6 +823,8 @@ template <int A, int B> FF_INLINE Fp2HB<2> fe_mul(const Fp2HB<A>& a, const Fp2HB
 #endif
 }
 // c0 lane: (a0 + a1)(a0 - a1)     c1 lane: 2 a0 a1
+// The difference a0 - a1 stays LAZY (narrow spread of K p, no carry pass: limbs <= 2^29 + 7 + 2^30): it is one factor of a plain product whose other
+// factor is weakly normalised -- 14 (2^29+7)(1.5 * 2^30 + 5) + 14 * 2^58 + carry < 56 * 2^58 * (1 + 2^-20) < 2^64 per column.
 template <int A> FF_INLINE Fp2HB<4> fe_sqr(const Fp2HB<A>& a) {
     const bool c1 = pair_comp() != 0;
     const FpB<A> ao = pair_swap(a.v);
@@ -833,10 +835,9 @@ template <int A> FF_INLINE Fp2HB<4> fe_sqr(const Fp2HB<A>& a) {
 #pragma unroll
     for (int i = 0; i < FPL; i++) {
         x.v[i] = c1 ? ao.v[i] : a.v.v[i] + ao.v[i];
-        y.v[i] = c1 ? a.v.v[i] : a.v.v[i] + (FP29_KP[KI][i] - ao.v[i]);
+        y.v[i] = c1 ? a.v.v[i] : a.v.v[i] + (FP29_KPN[KI][i] - ao.v[i]);
     }
     fp_carry(x.v);
-    fp_carry(y.v);
     const FpB<2> m = fe_mul(x, y);
     FpB<4> r;
 #pragma unroll

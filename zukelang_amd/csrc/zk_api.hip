@@ -110,7 +110,7 @@ __global__ void k_bench_mul_fp(uint32_t* out, uint32_t iters) {
 // operand pair through the SAME lazy-reduction code paths the group law uses (bounded adds / subs, products,
 // squares, fused double products, the zero test on unreduced values, inversion, full reduction, lane-pair Fp2)
 // and stores fully reduced plain integers (dense words) for comparison with host big-integer arithmetic.
-static constexpr int FP_SELFTEST_OUTS = 22;
+static constexpr int FP_SELFTEST_OUTS = 23;
 __global__ void k_fp_selftest(uint32_t* __restrict__ out, const uint32_t* __restrict__ a_words, const uint32_t* __restrict__ b_words, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;                      // n is even and pairs (2k, 2k+1) stay together: the lane-pair ops below are uniform
@@ -159,6 +159,7 @@ __global__ void k_fp_selftest(uint32_t* __restrict__ out, const uint32_t* __rest
     put(20, fp_from_mont(fe_mul_sub(a, b, big, b)));
     // lane-pair Fp2 product whose left operand is lazily reduced at the at-rest bound: (16 x - y) * y
     put(21, fp_from_mont(fe_mul(Fp2H(big), y).v));
+    put(22, fp_from_mont(fe_sqr(Fp2H(big)).v));                                                                 // lane-pair square with its lazy difference, at the at-rest bound
 }
 
 }  // namespace zk
