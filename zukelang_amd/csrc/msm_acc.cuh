@@ -28,6 +28,74 @@ template <class F> FF_INLINE Aff<F> table_rec_point(const TabRec& a, bool negate
     return r;
 }
 
+// ---- zz and zzz of a lane's accumulator PARKED in LDS between their two uses (G2 on lane pairs, products expanded in place): they are read at the top
+// of a mixed addition (U2 = x2 ZZ, S2 = y2 ZZZ) and again at its end (ZZ PP, ZZZ PPP); in between they only occupied 28 of the 256 registers a lane has
+// at two waves per SIMD, and the kernel spilled 46.  Layout [zz | zzz][16-byte piece][lane]: conflict-free 128-bit LDS accesses.
+FF_INLINE uint32_t* park_limbs(Fp& a) { return a.v; }
+FF_INLINE uint32_t* park_limbs(Fp2H& a) { return a.v.v; }
+FF_INLINE const uint32_t* park_limbs(const Fp& a) { return a.v; }
+FF_INLINE const uint32_t* park_limbs(const Fp2H& a) { return a.v.v; }
+template <class F> struct ZPark {
+    uint4* buf;                                              // [2][4][128] in LDS
+    uint32_t lane;
+    FF_INLINE F get(int which) const {
+        asm volatile("" ::: "memory");                      // a fresh read every time: the point of parking is NOT to keep the value in registers
+        uint32_t w[16];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint4 x = buf[(which * 4 + p) * 128 + lane];
+            w[4 * p] = x.x; w[4 * p + 1] = x.y; w[4 * p + 2] = x.z; w[4 * p + 3] = x.w;
+        }
+        F r;
+#pragma unroll
+        for (int i = 0; i < FPL; i++) park_limbs(r)[i] = w[i];
+        return r;
+    }
+    FF_INLINE void put(int which, const F& a) {
+        const uint32_t* l = park_limbs(a);
+        buf[(which * 4 + 0) * 128 + lane] = make_uint4(l[0], l[1], l[2], l[3]);
+        buf[(which * 4 + 1) * 128 + lane] = make_uint4(l[4], l[5], l[6], l[7]);
+        buf[(which * 4 + 2) * 128 + lane] = make_uint4(l[8], l[9], l[10], l[11]);
+        buf[(which * 4 + 3) * 128 + lane] = make_uint4(l[12], l[13], 0u, 0u);
+        asm volatile("" ::: "memory");
+    }
+};
+// xyzz_madd_impl<F, false> (ec.cuh) with acc = (ax, ay, park[0], park[1]): the same operations in the same order on the same values
+template <class F> FF_INLINE void xyzz_madd_parked(F& ax, F& ay, ZPark<F>& pk, const Aff<F>& q) {
+    {
+        const F zz = pk.get(0);
+        if (fe_is_zero(zz)) {                            // the accumulator is the identity
+            ax = q.x;
+            ay = q.y;
+            pk.put(0, FieldOps<F>::one());
+            pk.put(1, FieldOps<F>::one());
+            return;
+        }
+    }
+    const auto U2 = fe_mul(q.x, pk.get(0));
+    const auto S2 = fe_mul(q.y, pk.get(1));
+    const auto P = fe_sub(U2, ax);
+    const auto R = fe_sub(S2, ay);
+    if (fe_is_zero(P)) {
+        Xyzz<F> t{ax, ay, pk.get(0), pk.get(1)};
+        xyzz_madd_equal_x(t, fe_is_zero(R));
+        ax = t.x;
+        ay = t.y;
+        pk.put(0, t.zz);
+        pk.put(1, t.zzz);
+        return;
+    }
+    const auto PP = fe_sqr(P);
+    const auto PPP = fe_mul(P, PP);
+    const auto Q = fe_mul(ax, PP);
+    const auto X3 = fe_sub_sub_dbl(fe_sqr(R), PPP, Q);
+    const auto Y3 = fe_mul_sub(R, fe_sub(Q, X3), ay, PPP);
+    ax = X3;
+    ay = Y3;
+    pk.put(0, F(fe_mul(pk.get(0), PP)));
+    pk.put(1, F(fe_mul(pk.get(1), PPP)));
+}
+
 // RAW = false: the sorted entries are table references (index | sign).  RAW = true (the finisher of the batch-affine rounds,
 // msm_ba.cuh): entry `pos` is the affine point at pts + pos * 2 * RawLayout<F>::ELEM in the raw limb layout, identity = (0, 0).
 // GLDS = true (G1, table references): the record of step i+1 travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, per-lane source address, no
@@ -41,6 +109,9 @@ template <class F, bool RAW, bool GLDS> struct AccWaves { static constexpr int N
 template <class F, bool RAW, bool GLDS = false, bool MMADD = true>
 __global__ __launch_bounds__(128, (AccWaves<F, RAW, GLDS>::N)) void k_msm_accumulate(const uint8_t* __restrict__ table, AccJobs jobs, uint32_t nb, uint32_t chunk) {
     static_assert(!GLDS || !RAW, "the LDS-DMA look-ahead serves table references");
+    constexpr bool PARK = GLDS && std::is_same<F, Fp2H>::value && !MMADD;          // G2 with the products expanded in place: ZZ / ZZZ parked in LDS
+    __shared__ uint4 park_buf[PARK ? 2 : 1][PARK ? 4 : 1][PARK ? 128 : 1];
+    ZPark<F> zpark{&park_buf[0][0][0], threadIdx.x};
     __shared__ uint4 la_buf[GLDS ? 2 : 1][GLDS ? TAB_REC_WORDS / 4 : 1][GLDS ? 64 : 1];      // [wave][16-byte piece][lane]
     const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
     const uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
@@ -77,6 +148,7 @@ __global__ __launch_bounds__(128, (AccWaves<F, RAW, GLDS>::N)) void k_msm_accumu
     uint32_t seg_start = pos;
     bool first = true;
     Xyzz<F> acc = xyzz_inf<F>();
+    if constexpr (PARK) { zpark.put(0, acc.zz); zpark.put(1, acc.zzz); }          // PARK: acc.zz / acc.zzz of the struct are scratch, the truth is in LDS
     // (G2: the products are calls, which drain outstanding loads anyway -- only the reference is fetched ahead there)
     constexpr int RB = RawLayout<F>::ELEM;
     const uint8_t* __restrict__ pts = jobs.pts[blockIdx.y];
@@ -116,9 +188,11 @@ __global__ __launch_bounds__(128, (AccWaves<F, RAW, GLDS>::N)) void k_msm_accumu
         if (pos == bend) {                              // run finished inside the chunk
             const bool complete = seg_start == bstart;
             uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
+            if constexpr (PARK) { acc.zz = zpark.get(0); acc.zzz = zpark.get(1); }
             xyzz_store_raw<F>(dst, acc);
             first = false;
             acc = xyzz_inf<F>();
+            if constexpr (PARK) { zpark.put(0, acc.zz); zpark.put(1, acc.zzz); }
             kb++; bstart = bend; bend = bend2;
             while (bend == bstart) { kb++; bend = offsets[kb + 1]; }        // empty buckets: rare, the only dependent load left
             bend2 = kb + 2 <= nb ? offsets[kb + 2] : bend;                    // consumed at the next border
@@ -143,7 +217,8 @@ __global__ __launch_bounds__(128, (AccWaves<F, RAW, GLDS>::N)) void k_msm_accumu
         // Second step of the chunk (a wave-uniform test): every lane holds the identity (run border just crossed) or
         // the single affine point of step one, so the 6-product addition of two affine points does.
         // Table entries are never the identity (the sort filters identity bases): only the raw-point path tests for it.
-        if constexpr (MMADD) {
+        if constexpr (PARK) xyzz_madd_parked<F>(acc.x, acc.y, zpark, p);
+        else if constexpr (MMADD) {
             if (pos == pos0 + 1) xyzz_mmadd_impl<F, RAW>(acc, p);
             else xyzz_madd_impl<F, RAW>(acc, p);
         } else xyzz_madd_impl<F, RAW>(acc, p);
@@ -151,6 +226,7 @@ __global__ __launch_bounds__(128, (AccWaves<F, RAW, GLDS>::N)) void k_msm_accumu
     {
         const bool complete = (seg_start == bstart) && (end == bend);
         uint8_t* dst = complete ? buckets + (uint64_t)XB * kb : (first ? head + (uint64_t)XB * t : tail + (uint64_t)XB * t);
+        if constexpr (PARK) { acc.zz = zpark.get(0); acc.zzz = zpark.get(1); }
         xyzz_store_raw<F>(dst, acc);
     }
 }
