@@ -20,6 +20,7 @@
 // disappear; this is the mode the resident proving key uses.
 #include "ec.cuh"
 #include "msm.cuh"
+#include "msm_tail.cuh"
 
 #include <stdlib.h>
 #include <string.h>
@@ -541,28 +542,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint3
 // point: half the registers and two instead of three dependent base-field products per Fp2 product --
 // these kernels are chains of dependent additions run by a few waves, so latency is what they cost).
 template <class T> struct Lanes { static constexpr uint32_t N = RawLayout<T>::LANES; };
-// The reduction kernels serve several MSMs of one proof in ONE launch (blockIdx.z = job): the MSMs share the base
-// set (hence bucket count, chunk length, window plan) and differ in the scalars, so their reductions are the same
-// launch geometry on different buffers -- one latency-bound chain per proof and curve instead of one per MSM.
-static constexpr uint32_t MAX_TAIL_JOBS = 8;
-struct TailJob {
-    const uint32_t* offsets;
-    uint8_t* buckets;
-    const uint8_t* head;
-    const uint8_t* tail;
-    uint32_t* worklist;
-    uint8_t* red;
-    uint8_t* wsum;
-    uint8_t* out;
-    uint32_t nb, chunk;          // buckets of this MSM, sorted entries per accumulate chunk
-};
-// Jobs [0, n1) are G1 products (T = Fp), jobs [n1, n1 + n2) G2 products (T = Fp2H): ONE launch per step serves both
-// curves, with the launch geometry of the larger one (blocks and lanes a job has no use for leave at once).
-struct TailJobs {
-    TailJob j[MAX_TAIL_JOBS];
-    uint32_t n1;
-};
-static constexpr uint32_t FIXUP_SERIAL_MAX = 16;
 static constexpr uint32_t BA_FINISH_CHUNK = 8;       // sorted entries per lane of the XYZZ accumulate that follows the batch-affine rounds
 template <class T> FF_INLINE void fixup_body(const TailJob& job) {
     constexpr int XB = RawLayout<T>::XYZZ;
@@ -658,9 +637,6 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixup_big(TailJobs jobs) {
 //   final         2^lb * V1 + V0 (and Horner over windows in classic mode)        depth ~ lb + 1
 // ~45 links instead of the ~100+ of per-lane running sums, and 2x the bucket reads (cheap).
 // Empty buckets are recognised from the sort's offsets, so the bucket array is never cleared.
-struct DigitPlan {
-    uint32_t nbw, lb, nd0, nd1;
-};
 // 16 points per digit value: every lane sums cnt/16 buckets serially, then a 4-level tree.  (One value per 64-point
 // workgroup -- 2-4 buckets per lane, 6 levels -- finishes sooner but keeps four times as many waves busy for two thirds
 // of that time; with a dozen proofs in flight SIMD time is what counts.)  NT threads hold NT / lanes points.
@@ -708,7 +684,6 @@ template <bool WIDE> __global__ __launch_bounds__(DS_THREADS, WIDE ? 2 : 1) void
 // A suffix scan (log2 rounds of "point d += point d + 2^r") followed by a tree sum over t = 1..cnt-1: 2 log2(DW_POINTS) = 16
 // dependent additions, every one an exchange through LDS, no doublings and no per-point double-and-add (the first version
 // multiplied each S[d] by d with 8 doublings + up to 8 additions before a 9-level tree: 25 links, 265 spilled registers).
-static constexpr uint32_t DW_POINTS = 256;
 FF_INLINE uint32_t* lane_limbs(Fp& a) { return a.v; }
 FF_INLINE uint32_t* lane_limbs(Fp2H& a) { return a.v.v; }
 FF_INLINE uint32_t dw_groups(uint32_t cnt) { return (cnt + DW_POINTS - 1) / DW_POINTS; }
@@ -898,14 +873,6 @@ __global__ void k_acc_stats(const uint32_t* __restrict__ offsets, uint32_t nb, u
 
 // ================================================================== host side
 static inline dim3 grid_for(uint64_t n, unsigned threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
-static inline DigitPlan digit_plan(uint32_t c) {
-    DigitPlan p;
-    p.nbw = 1u << (c - 1);
-    p.lb = (c + 1) / 2;
-    p.nd0 = 1u << p.lb;
-    p.nd1 = (p.nbw >> p.lb) + 1;
-    return p;
-}
 
 uint32_t msm_auto_window(uint64_t n, bool precomp) {
     // work ~ nw * n additions + buckets * (2 reduce additions); pick the c minimizing it, capped so the
@@ -1118,7 +1085,11 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     ZKCHK(w.worklist.alloc(4 * (size_t)(w.nbuckets + 1)));
     const DigitPlan dp = digit_plan(b.c);
     ZKCHK(w.red.alloc(XB * (size_t)(dp.nd0 + dp.nd1) * (b.precomp ? 1 : b.nw)));
-    ZKCHK(w.wsum.alloc(XB * (size_t)((dp.nd0 + DW_POINTS - 1) / DW_POINTS + (dp.nd1 + DW_POINTS - 1) / DW_POINTS) * (b.precomp ? 1 : b.nw)));      // one point per group of digit values and window
+    {
+        const size_t lanes_form = (size_t)((dp.nd0 + DW_POINTS - 1) / DW_POINTS + (dp.nd1 + DW_POINTS - 1) / DW_POINTS) * (b.precomp ? 1 : b.nw);      // one point per group of digit values and window
+        const size_t slots_form = tail_wsum_points(dp, b.precomp ? 1 : b.nw);
+        ZKCHK(w.wsum.alloc(XB * (lanes_form > slots_form ? lanes_form : slots_form)));
+    }
     return ZK_OK;
 }
 
@@ -1284,25 +1255,32 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     const uint32_t count = n1 + n2;
     const char* fam = n2 == 0 ? "msm_reduce_g1" : (n1 == 0 ? "msm_reduce_g2" : "msm_reduce");
     ScopedTimer t(fam, s);
-    dim3 gf = grid_for(max_lanes, 128);
-    gf.z = count;
-    {
-        ScopedTimer t1("msm_reduce:fixup", s);
-        hipLaunchKernelGGL(k_msm_fixup, gf, dim3(128), 0, s, jobs);
-        hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
-    }
     const DigitPlan dp = digit_plan(b.c);
-    const uint32_t dwg0 = (dp.nd0 + DW_POINTS - 1) / DW_POINTS, dwg1 = (dp.nd1 + DW_POINTS - 1) / DW_POINTS;      // groups of digit values per half
-    // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 2 values; G1: 8)
     const bool wide = dp.nd0 > DW_POINTS;
-    const uint32_t per_wg = wide ? (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, true>::N : DS_THREADS / DsGroup<Fp, true>::N)
-                                 : (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, false>::N : DS_THREADS / DsGroup<Fp, false>::N);
-    {
+    // bucket sums -> digit sums: on slots (msm_tail.hip) where the chain is latency-bound, one lane per point where the launch is throughput-bound
+    // (msm_tail.cuh).  ZK_TAIL_SLOTS = 0 / 1 forces one form (A/B runs); ZK_TAIL_WEIGHT_SLOTS = 0 keeps the one-lane weighting step of round 2.
+    static const int force = ZK_ENV("ZK_TAIL_SLOTS") ? atoi(ZK_ENV("ZK_TAIL_SLOTS")) : -1;
+    static const bool weight_slots = !(ZK_ENV("ZK_TAIL_WEIGHT_SLOTS") && atoi(ZK_ENV("ZK_TAIL_WEIGHT_SLOTS")) == 0);
+    if (force < 0 ? !wide : force != 0) {
+        ZKCHK(msm_tail_sums_slots(jobs, count, n2, max_nb, nwin, b.c, s));
+    } else {
+        dim3 gf = grid_for(max_lanes, 128);
+        gf.z = count;
+        {
+            ScopedTimer t1("msm_reduce:fixup", s);
+            hipLaunchKernelGGL(k_msm_fixup, gf, dim3(128), 0, s, jobs);
+            hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
+        }
+        // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 2 values; G1: 8)
+        const uint32_t per_wg = wide ? (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, true>::N : DS_THREADS / DsGroup<Fp, true>::N)
+                                     : (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, false>::N : DS_THREADS / DsGroup<Fp, false>::N);
         ScopedTimer t2("msm_reduce:digit_sums", s);
         const dim3 gd((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count);
         if (wide) hipLaunchKernelGGL(k_msm_digit_sums<true>, gd, dim3(DS_THREADS), 0, s, jobs, dp);
         else hipLaunchKernelGGL(k_msm_digit_sums<false>, gd, dim3(DS_THREADS), 0, s, jobs, dp);
     }
+    if (weight_slots) return msm_tail_weight_slots(jobs, count, n2, nwin, b.c, s);
+    const uint32_t dwg0 = (dp.nd0 + DW_POINTS - 1) / DW_POINTS, dwg1 = (dp.nd1 + DW_POINTS - 1) / DW_POINTS;      // groups of digit values per half
     {
         ScopedTimer t3("msm_reduce:digit_weight", s);
         if (dwg0 + dwg1 == 2) hipLaunchKernelGGL(k_msm_digit_weight<false>, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
