@@ -631,12 +631,11 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixup_big(TailJobs jobs) {
 // A lone wave issues one instruction every ~4 cycles, so a chain of dependent EC additions costs
 // ~15 us per link whatever the chip is doing: the reduction must be SHALLOW, not merely parallel.
 // Write w = hi * 2^lb + lo.  Then R = sum_lo lo * S0[lo] + 2^lb * sum_hi hi * S1[hi] with the digit
-// sums S0[d] = sum of buckets whose low digit is d, S1[d] = those whose high digit is d:
-//   digit_sums    16 points per (digit, value): strided loads + LDS tree         depth ~ 8-16 + 4
-//   digit_weight  d * S[d] by double-and-add (d < 2^lb), LDS tree over d         depth ~ 2 lb + 8
-//   final         2^lb * V1 + V0 (and Horner over windows in classic mode)        depth ~ lb + 1
-// ~45 links instead of the ~100+ of per-lane running sums, and 2x the bucket reads (cheap).
+// sums S0[d] = sum of buckets whose low digit is d, S1[d] = those whose high digit is d.  Two adds per bucket, ~2x the bucket reads (cheap).
 // Empty buckets are recognised from the sort's offsets, so the bucket array is never cleared.
+// The kernels below (one lane, or lane pair, per point) are the form for windows ABOVE 16 bits, where 2^17+ buckets make fixup and
+// digit sums throughput-bound; up to 2^15 buckets, and for the weighting of the digit sums at every width, msm_tail.hip runs the chain
+// on four slots per point.
 // 16 points per digit value: every lane sums cnt/16 buckets serially, then a 4-level tree.  (One value per 64-point
 // workgroup -- 2-4 buckets per lane, 6 levels -- finishes sooner but keeps four times as many waves busy for two thirds
 // of that time; with a dozen proofs in flight SIMD time is what counts.)  NT threads hold NT / lanes points.
@@ -646,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void k_msm_fixup_big(TailJobs jobs) {
 // additions + 6 tree levels instead of 32-128 + 4
 template <class T, bool WIDE> struct DsGroup { static constexpr uint32_t N = WIDE ? 64 : 16; };
 template <bool WIDE> struct DsGroup<Fp2H, WIDE> { static constexpr uint32_t N = WIDE ? 64 : 32; };
-static constexpr int DS_THREADS = 128, DW_THREADS = 512;
+static constexpr int DS_THREADS = 128;
 template <class T, int NT, bool WIDE> FF_INLINE void digit_sums_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT]) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint8_t* __restrict__ buckets = job.buckets;
@@ -679,122 +678,6 @@ template <bool WIDE> __global__ __launch_bounds__(DS_THREADS, WIDE ? 2 : 1) void
     __shared__ uint32_t lds[LANE_POINT_WORDS][DS_THREADS];
     if (blockIdx.z < jobs.n1) digit_sums_body<Fp, DS_THREADS, WIDE>(jobs.j[blockIdx.z], p, lds);
     else digit_sums_body<Fp2H, DS_THREADS, WIDE>(jobs.j[blockIdx.z], p, lds);
-}
-// V[win][k] = sum_d d * S[win][k][d], d < cnt <= DW_POINTS, as the sum of all suffix sums: sum_{t>=1} (sum_{d>=t} S[d]).
-// A suffix scan (log2 rounds of "point d += point d + 2^r") followed by a tree sum over t = 1..cnt-1: 2 log2(DW_POINTS) = 16
-// dependent additions, every one an exchange through LDS, no doublings and no per-point double-and-add (the first version
-// multiplied each S[d] by d with 8 doublings + up to 8 additions before a 9-level tree: 25 links, 265 spilled registers).
-FF_INLINE uint32_t* lane_limbs(Fp& a) { return a.v; }
-FF_INLINE uint32_t* lane_limbs(Fp2H& a) { return a.v.v; }
-FF_INLINE uint32_t dw_groups(uint32_t cnt) { return (cnt + DW_POINTS - 1) / DW_POINTS; }
-// acc += k * tg, out of line: the one-off group term must not cost the round loop of the kernel its registers
-template <class T> __device__ __noinline__ void dw_group_term(Xyzz<T>* acc, const Xyzz<T>* tg, uint32_t k) {
-    const Xyzz<T> m = xyzz_mul_u32_inl(*tg, k);
-    xyzz_add_impl(*acc, m);
-}
-// More than DW_POINTS digit values per half (windows above 16 bits): the values go in GROUPS of DW_POINTS, one workgroup each.  With
-// d = DW_POINTS g + j:  sum_d d S[d] = sum_g ( sum_j j S[g][j]  +  DW_POINTS g * sum_j S[g][j] ) -- the first term is the scan form on the
-// group, the plain sum T_g is point 0 of the suffix scan (kept aside in LDS before it is dropped), and DW_POINTS g * T_g costs 8-11 doublings
-// on one point after the tree.  k_msm_final adds the groups' contributions.  (The first version of the wide path multiplied every S[d] by d
-// with a 10-bit double-and-add: 265 spilled registers, 2.5 ms of a 2^20 proof's latency.)
-template <class T, int NT, bool GROUPED> FF_INLINE void digit_weight_body(const TailJob& job, DigitPlan p, uint32_t (*lds)[NT], uint32_t (*keep)[4]) {
-    constexpr int XB = RawLayout<T>::XYZZ;
-    const uint8_t* __restrict__ S = job.red;
-    uint8_t* __restrict__ V = job.wsum;
-    constexpr uint32_t LP = Lanes<T>::N;
-    const uint32_t g0 = dw_groups(p.nd0), g1 = dw_groups(p.nd1);
-    const uint32_t k = blockIdx.x < g0 ? 0u : 1u, grp = k ? blockIdx.x - g0 : blockIdx.x;
-    const uint32_t win = blockIdx.y, t = threadIdx.x, pt = t / LP;
-    const uint32_t cnt = k == 0 ? p.nd0 : p.nd1;
-    const uint8_t* base = S + (uint64_t)XB * ((uint64_t)win * (p.nd0 + p.nd1) + (k == 0 ? 0 : p.nd0));
-    const bool mine = pt < DW_POINTS;                       // G1 jobs use half of the workgroup's lanes; everyone keeps the barriers
-    const uint32_t d = grp * DW_POINTS + pt;                // this point's digit value
-    Xyzz<T> acc = xyzz_inf<T>();
-    if (mine && d >= 1 && d < cnt) acc = xyzz_load_raw<T>(base + (uint64_t)XB * d);
-    // rounds 0..7: suffix scan, partner = pt + 2^r;  round 8: drop point 0 (weight 0 inside the group);  rounds 8..15: tree, partner = pt + 128 >> (r-8)
-    for (uint32_t r = 0; r < 16; r++) {
-        const bool scan = r < 8;
-        const uint32_t step = scan ? (1u << r) : (DW_POINTS / 2) >> (r - 8);
-        if (r == 8 && pt == 0) {
-            if (GROUPED && grp) {                           // T_g = the sum of the whole group: needed with the weight DW_POINTS * grp
-#pragma unroll
-                for (int l = 0; l < FPL; l++) {
-                    keep[l][t] = lane_limbs(acc.x)[l]; keep[FPL + l][t] = lane_limbs(acc.y)[l];
-                    keep[2 * FPL + l][t] = lane_limbs(acc.zz)[l]; keep[3 * FPL + l][t] = lane_limbs(acc.zzz)[l];
-                }
-            }
-            acc = xyzz_inf<T>();
-        }
-        __syncthreads();
-        if (mine) {
-#pragma unroll
-            for (int l = 0; l < FPL; l++) {
-                lds[l][t] = lane_limbs(acc.x)[l]; lds[FPL + l][t] = lane_limbs(acc.y)[l];
-                lds[2 * FPL + l][t] = lane_limbs(acc.zz)[l]; lds[3 * FPL + l][t] = lane_limbs(acc.zzz)[l];
-            }
-        }
-        __syncthreads();
-        const bool act = mine && (scan ? pt + step < DW_POINTS : pt < step);
-        if (act) {
-            Xyzz<T> q;
-            const uint32_t src = t + step * LP;
-#pragma unroll
-            for (int l = 0; l < FPL; l++) {
-                lane_limbs(q.x)[l] = lds[l][src]; lane_limbs(q.y)[l] = lds[FPL + l][src];
-                lane_limbs(q.zz)[l] = lds[2 * FPL + l][src]; lane_limbs(q.zzz)[l] = lds[3 * FPL + l][src];
-            }
-            xyzz_add_impl(acc, q);
-        }
-    }
-    if (t < LP) {
-        if (GROUPED && grp) {
-            Xyzz<T> tg;
-#pragma unroll
-            for (int l = 0; l < FPL; l++) {
-                lane_limbs(tg.x)[l] = keep[l][t]; lane_limbs(tg.y)[l] = keep[FPL + l][t];
-                lane_limbs(tg.zz)[l] = keep[2 * FPL + l][t]; lane_limbs(tg.zzz)[l] = keep[3 * FPL + l][t];
-            }
-            dw_group_term<T>(&acc, &tg, grp * DW_POINTS);
-        }
-        xyzz_store_raw<T>(V + (uint64_t)XB * ((uint64_t)win * (g0 + g1) + blockIdx.x), acc);
-    }
-}
-// GROUPED = false: at most DW_POINTS digit values per half (windows up to 16 bits, the default path): no group term is compiled in
-template <bool GROUPED> __global__ __launch_bounds__(DW_THREADS) void k_msm_digit_weight(TailJobs jobs, DigitPlan p) {
-    __shared__ uint32_t lds[LANE_POINT_WORDS][DW_THREADS];
-    __shared__ uint32_t keep[LANE_POINT_WORDS][4];          // T_g of the group: the limbs of point 0 (one lane, or a lane pair)
-    if (blockIdx.z < jobs.n1) digit_weight_body<Fp, DW_THREADS, GROUPED>(jobs.j[blockIdx.z], p, lds, keep);
-    else digit_weight_body<Fp2H, DW_THREADS, GROUPED>(jobs.j[blockIdx.z], p, lds, keep);
-}
-// W_j = 2^lb * V[j][1] + V[j][0]; result = sum_j 2^(c*j) * W_j by Horner from the top window (one point).
-// The result leaves in the DENSE, fully reduced layout (it is an output of the library).
-template <class T> FF_INLINE void final_body(const TailJob& job, uint32_t nw, uint32_t c, uint32_t lb, uint32_t g0, uint32_t g1) {
-    constexpr int XB = RawLayout<T>::XYZZ;
-    if (threadIdx.x >= Lanes<T>::N) return;
-    const uint8_t* __restrict__ V = job.wsum;
-    uint8_t* __restrict__ out = job.out;
-    Xyzz<T> acc = xyzz_inf<T>();
-    for (uint32_t j = nw; j-- > 0;) {
-        if (j != nw - 1)
-            for (uint32_t k = 0; k < c; k++) acc = xyzz_dbl_impl(acc);
-        const uint8_t* Vw = V + (uint64_t)XB * ((uint64_t)j * (g0 + g1));      // the window's group sums: g0 of the low digit, g1 of the high one
-        Xyzz<T> hi = xyzz_load_raw<T>(Vw + (uint64_t)XB * g0);
-        for (uint32_t g = 1; g < g1; g++) {
-            const Xyzz<T> q = xyzz_load_raw<T>(Vw + (uint64_t)XB * (g0 + g));
-            xyzz_add_impl(hi, q);
-        }
-        for (uint32_t k = 0; k < lb; k++) hi = xyzz_dbl_impl(hi);
-        xyzz_add_impl(acc, hi);
-        for (uint32_t g = 0; g < g0; g++) {
-            const Xyzz<T> lo = xyzz_load_raw<T>(Vw + (uint64_t)XB * g);
-            xyzz_add_impl(acc, lo);
-        }
-    }
-    xyzz_store<T>(out, acc);
-}
-__global__ __launch_bounds__(64) void k_msm_final(TailJobs jobs, uint32_t nw, uint32_t c, uint32_t lb, uint32_t g0, uint32_t g1) {
-    if (blockIdx.z < jobs.n1) final_body<Fp>(jobs.j[blockIdx.z], nw, c, lb, g0, g1);
-    else final_body<Fp2H>(jobs.j[blockIdx.z], nw, c, lb, g0, g1);
 }
 template <class F> __global__ void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
     constexpr int XB = FieldOps<F>::WORDS * 16;
@@ -1085,11 +968,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     ZKCHK(w.worklist.alloc(4 * (size_t)(w.nbuckets + 1)));
     const DigitPlan dp = digit_plan(b.c);
     ZKCHK(w.red.alloc(XB * (size_t)(dp.nd0 + dp.nd1) * (b.precomp ? 1 : b.nw)));
-    {
-        const size_t lanes_form = (size_t)((dp.nd0 + DW_POINTS - 1) / DW_POINTS + (dp.nd1 + DW_POINTS - 1) / DW_POINTS) * (b.precomp ? 1 : b.nw);      // one point per group of digit values and window
-        const size_t slots_form = tail_wsum_points(dp, b.precomp ? 1 : b.nw);
-        ZKCHK(w.wsum.alloc(XB * (lanes_form > slots_form ? lanes_form : slots_form)));
-    }
+    ZKCHK(w.wsum.alloc(XB * tail_wsum_points(dp, b.precomp ? 1 : b.nw)));        // block sums of the weighting step (msm_tail.cuh)
     return ZK_OK;
 }
 
@@ -1258,9 +1137,8 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     const DigitPlan dp = digit_plan(b.c);
     const bool wide = dp.nd0 > DW_POINTS;
     // bucket sums -> digit sums: on slots (msm_tail.hip) where the chain is latency-bound, one lane per point where the launch is throughput-bound
-    // (msm_tail.cuh).  ZK_TAIL_SLOTS = 0 / 1 forces one form (A/B runs); ZK_TAIL_WEIGHT_SLOTS = 0 keeps the one-lane weighting step of round 2.
+    // (msm_tail.cuh).  ZK_TAIL_SLOTS = 0 / 1 forces one form (A/B runs).  Digit sums -> product: always msm_tail.hip.
     static const int force = ZK_ENV("ZK_TAIL_SLOTS") ? atoi(ZK_ENV("ZK_TAIL_SLOTS")) : -1;
-    static const bool weight_slots = !(ZK_ENV("ZK_TAIL_WEIGHT_SLOTS") && atoi(ZK_ENV("ZK_TAIL_WEIGHT_SLOTS")) == 0);
     if (force < 0 ? !wide : force != 0) {
         ZKCHK(msm_tail_sums_slots(jobs, count, n2, max_nb, nwin, b.c, s));
     } else {
@@ -1279,19 +1157,7 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
         if (wide) hipLaunchKernelGGL(k_msm_digit_sums<true>, gd, dim3(DS_THREADS), 0, s, jobs, dp);
         else hipLaunchKernelGGL(k_msm_digit_sums<false>, gd, dim3(DS_THREADS), 0, s, jobs, dp);
     }
-    if (weight_slots) return msm_tail_weight_slots(jobs, count, n2, nwin, b.c, s);
-    const uint32_t dwg0 = (dp.nd0 + DW_POINTS - 1) / DW_POINTS, dwg1 = (dp.nd1 + DW_POINTS - 1) / DW_POINTS;      // groups of digit values per half
-    {
-        ScopedTimer t3("msm_reduce:digit_weight", s);
-        if (dwg0 + dwg1 == 2) hipLaunchKernelGGL(k_msm_digit_weight<false>, dim3(2, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
-        else hipLaunchKernelGGL(k_msm_digit_weight<true>, dim3(dwg0 + dwg1, nwin, count), dim3(DW_THREADS), 0, s, jobs, dp);
-    }
-    {
-        ScopedTimer t4("msm_reduce:final", s);
-        hipLaunchKernelGGL(k_msm_final, dim3(1, 1, count), dim3(64), 0, s, jobs, nwin, b.c, dp.lb, dwg0, dwg1);
-    }
-    HIPCHK(hipGetLastError());
-    return ZK_OK;
+    return msm_tail_weight_slots(jobs, count, n2, nwin, b.c, s);
 }
 int msm_reduce(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s) {
     return b.curve == CURVE_G1 ? msm_reduce_mixed(&b, ws, outs, count, nullptr, nullptr, nullptr, 0, s)

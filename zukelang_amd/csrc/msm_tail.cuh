@@ -38,7 +38,7 @@ static inline DigitPlan digit_plan(uint32_t c) {
     p.nd1 = (p.nbw >> p.lb) + 1;
     return p;
 }
-static constexpr uint32_t DW_POINTS = 256;       // digit values one workgroup of the weighting step takes (one-lane-per-point chain of msm.hip)
+static constexpr uint32_t DW_POINTS = 256;       // more digit values per half than this (windows above 16 bits): the WIDE forms of the sums kernels
 // msm_tail.hip weights the digit sums in blocks of 2^bw values, at most 32 blocks per half; its buffer: T_b | L_b per block and window, then one W per window
 static inline uint32_t tail_bw_log(const DigitPlan& p) { return p.lb > 5 ? p.lb - 5 : 0; }
 static inline size_t tail_wsum_points(const DigitPlan& p, uint32_t nwin) {
