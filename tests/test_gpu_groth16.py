@@ -325,6 +325,34 @@ def test_config3_window_sweep_is_parity_checked():
             os.environ["ZK_MSM_WINDOW"] = old
 
 
+def test_every_window_width_reduces_to_the_same_proof():
+    """The bucket reduction changes shape with the window width (msm_tail.hip: blocks of 2^bw digit values, bw = 0 up to 10-bit windows and
+    1..6 above; fix-up per bucket or per chunk border; sums on slots up to 16 bits, on lanes above): every width from 2 to 22 bits on one
+    small resident key must give the trapdoor oracle's bytes (groth16.ml:116-161)."""
+    n = 1 << 10
+    cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0101)))
+    rng = seeded_rng(0x5EED0102)
+    toxic = [rng() for _ in range(5)]
+    r, s = rng(), rng()
+    L, R_, Oo = csrs(cs)
+    e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
+    pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
+    expect = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    old = os.environ.get("ZK_MSM_WINDOW")
+    try:
+        for c in range(2, 23):
+            os.environ["ZK_MSM_WINDOW"] = str(c)          # read by the library when the key's base tables are built
+            prover = Groth16(cs, pk)
+            proof = prover.prove_rs(w, r, s)
+            prover.close()
+            assert (proof.a, proof.b, proof.c) == expect, "window %d" % c
+    finally:
+        if old is None:
+            os.environ.pop("ZK_MSM_WINDOW", None)
+        else:
+            os.environ["ZK_MSM_WINDOW"] = old
+
+
 SWEEP_WINDOWS = (12, 14, 15, 17, 20)      # 17, 20: beyond the LDS histogram -- the two-level counting sort
 
 

@@ -543,7 +543,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint3
 // these kernels are chains of dependent additions run by a few waves, so latency is what they cost).
 template <class T> struct Lanes { static constexpr uint32_t N = RawLayout<T>::LANES; };
 static constexpr uint32_t BA_FINISH_CHUNK = 8;       // sorted entries per lane of the XYZZ accumulate that follows the batch-affine rounds
-template <class T> FF_INLINE void fixup_body(const TailJob& job) {
+// BY_CHUNK = false: one worker (lane, or lane pair) per BUCKET.  BY_CHUNK = true: one worker per CHUNK BORDER -- worker t looks up the bucket of the last
+// entry of chunk t (binary search in the offsets) and owns the bucket's fix-up if the run starts in chunk t and goes on beyond it.  With more buckets
+// than chunks (windows above 16 bits: 2^19 buckets, runs of ~26 entries inside chunks of ~200) one bucket in eight crosses a border: per bucket, a
+// wave ran the additions with a few of its lanes (PMC at 2^20: 317 M wave instructions per proof for work worth 7 M on full waves).
+template <class T, bool BY_CHUNK> FF_INLINE void fixup_body(const TailJob& job) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint32_t* __restrict__ offsets = job.offsets;
     uint8_t* __restrict__ buckets = job.buckets;
@@ -551,12 +555,24 @@ template <class T> FF_INLINE void fixup_body(const TailJob& job) {
     const uint8_t* __restrict__ tail = job.tail;
     uint32_t* __restrict__ worklist = job.worklist;
     const uint32_t chunk = job.chunk;
-    const uint32_t kb = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<T>::N;
-    if (kb >= job.nb) return;
+    const uint32_t worker = (blockIdx.x * blockDim.x + threadIdx.x) / Lanes<T>::N;
+    uint32_t kb = worker;
+    if constexpr (BY_CHUNK) {
+        const uint64_t last = ((uint64_t)worker + 1) * chunk - 1;      // last entry of chunk `worker`
+        if (last + 1 >= offsets[job.nb]) return;                        // nothing sorted beyond it: no border
+        uint32_t lo = 0, hi = job.nb;                                   // first index whose offset exceeds `last`, minus one: the (non-empty) bucket of that entry
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (offsets[mid] > (uint32_t)last) hi = mid;
+            else lo = mid + 1;
+        }
+        kb = lo - 1;
+    } else if (kb >= job.nb) return;
     const uint32_t s = offsets[kb], e = offsets[kb + 1];
     if (e == s) return;                                 // empty bucket: nobody reads its slot
     const uint32_t t0 = s / chunk, t1 = (e - 1) / chunk;
     if (t0 == t1) return;                               // whole run inside one chunk: written directly
+    if (BY_CHUNK && t0 != worker) return;               // the run began in an earlier chunk: that chunk's worker has it
     if (t1 - t0 > FIXUP_SERIAL_MAX) {
         if ((threadIdx.x & (Lanes<T>::N - 1)) == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = kb;
         return;
@@ -568,9 +584,9 @@ template <class T> FF_INLINE void fixup_body(const TailJob& job) {
     }
     xyzz_store_raw<T>(buckets + (uint64_t)XB * kb, acc);
 }
-__global__ __launch_bounds__(128, 2) void k_msm_fixup(TailJobs jobs) {
-    if (blockIdx.z < jobs.n1) fixup_body<Fp>(jobs.j[blockIdx.z]);
-    else fixup_body<Fp2H>(jobs.j[blockIdx.z]);
+template <bool BY_CHUNK> __global__ __launch_bounds__(128, 2) void k_msm_fixup(TailJobs jobs) {
+    if (blockIdx.z < jobs.n1) fixup_body<Fp, BY_CHUNK>(jobs.j[blockIdx.z]);
+    else fixup_body<Fp2H, BY_CHUNK>(jobs.j[blockIdx.z]);
 }
 // sum of the accumulators of the NT / lanes points of a workgroup, result in point 0
 // (GROUP = points per independent sum, a power of two; 0 = the whole workgroup: result in point 0 of every group)
@@ -1117,7 +1133,7 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     const uint32_t nwin = b.precomp ? 1 : b.nw;
     TailJobs jobs{};
     jobs.n1 = n1;
-    uint64_t max_lanes = 0;
+    uint64_t max_lanes = 0, max_chunks = 0;
     uint32_t max_nb = 0;
     for (uint32_t i = 0; i < n1 + n2; i++) {
         MsmWorkspace& w = i < n1 ? *ws1[i] : *ws2[i - n1];
@@ -1130,6 +1146,8 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
         const uint64_t lanes = (uint64_t)w.nbuckets * (i < n1 ? 1 : 2);
         if (lanes > max_lanes) max_lanes = lanes;
         if (w.nbuckets > max_nb) max_nb = w.nbuckets;
+        const uint64_t chunks = w.red_chunk == w.chunk ? w.nthreads : ~(uint64_t)0;      // after batch-affine rounds the chunk count is not the workspace's: per bucket
+        if (chunks > max_chunks) max_chunks = chunks;
     }
     const uint32_t count = n1 + n2;
     const char* fam = n2 == 0 ? "msm_reduce_g1" : (n1 == 0 ? "msm_reduce_g2" : "msm_reduce");
@@ -1142,11 +1160,20 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     if (force < 0 ? !wide : force != 0) {
         ZKCHK(msm_tail_sums_slots(jobs, count, n2, max_nb, nwin, b.c, s));
     } else {
-        dim3 gf = grid_for(max_lanes, 128);
-        gf.z = count;
         {
             ScopedTimer t1("msm_reduce:fixup", s);
-            hipLaunchKernelGGL(k_msm_fixup, gf, dim3(128), 0, s, jobs);
+            // one worker per bucket, or per chunk border where those are fewer (k_msm_fixup)
+            const uint32_t lanes_per = n2 ? 2 : 1;
+            static const bool by_chunk_ok = !(ZK_ENV("ZK_FIXUP_BY_CHUNK") && atoi(ZK_ENV("ZK_FIXUP_BY_CHUNK")) == 0);      // A/B switch
+            if (by_chunk_ok && max_chunks < max_nb) {
+                dim3 gf = grid_for(max_chunks * lanes_per, 128);
+                gf.z = count;
+                hipLaunchKernelGGL(k_msm_fixup<true>, gf, dim3(128), 0, s, jobs);
+            } else {
+                dim3 gf = grid_for(max_lanes, 128);
+                gf.z = count;
+                hipLaunchKernelGGL(k_msm_fixup<false>, gf, dim3(128), 0, s, jobs);
+            }
             hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
         }
         // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 2 values; G1: 8)
