@@ -13,7 +13,7 @@ PREFIX = [   # kernel name prefix -> bench.py family, per-proof kernels only (fi
     ("k_msm_accumulate<FpB", "msm_accumulate_g1"), ("k_msm_accumulate<Fp2HB", "msm_accumulate_g2"),
     ("k_ba_round<FpB", "msm_accumulate_g1"), ("k_ba_round<Fp2HB", "msm_accumulate_g2"), ("k_ba_plan", "msm_accumulate_g1"),
     ("k_msm_count", "msm_sort"), ("k_msm_scatter", "msm_sort"), ("k_scan", "msm_sort"), ("k_sort_", "msm_sort"),
-    ("k_msm_fixup", "msm_reduce"), ("k_msm_digit_", "msm_reduce"), ("k_msm_final", "msm_reduce"),
+    ("k_msm_fixup", "msm_reduce"), ("k_msm_digit_", "msm_reduce"), ("k_msm_final", "msm_reduce"), ("k_tail_", "msm_reduce"),
     ("k_proof_to_bytes", "proof_to_bytes"), ("k_groth16_scalars", "groth16_scalars"),
     ("k_ntt_", "ntt"), ("k_tree_levels_fused", "ntt"),
     ("k_spmv", "fr_pointwise"), ("k_check_r1cs", "fr_pointwise"), ("k_fr_to_mont_flag2", "fr_pointwise"), ("k_scale_pad", "fr_pointwise"), ("k_reverse_pad", "fr_pointwise"), ("k_lag_", "fr_pointwise"),
