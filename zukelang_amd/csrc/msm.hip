@@ -916,8 +916,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     static const uint64_t target_threads = getenv("ZK_MSM_TARGET_THREADS") ? (uint64_t)atoll(getenv("ZK_MSM_TARGET_THREADS")) : 256 * 1024;   // tuning knob
     uint32_t chunk = (uint32_t)((maxN + target_threads - 1) / target_threads);
     static const uint32_t chunk_min = getenv("ZK_MSM_CHUNK_MIN") ? (uint32_t)atoi(getenv("ZK_MSM_CHUNK_MIN")) : 16;   // tuning knob
-    static const uint32_t round_min = getenv("ZK_MSM_ROUND_MIN") ? (uint32_t)atoi(getenv("ZK_MSM_ROUND_MIN")) : 64;   // tuning knob
-    if (launch_entries && chunk >= round_min) {            // short chunks (small keys) already fill whole rounds: at 2^16, 2 rounds of 16-entry chunks beat 1 round of 32
+    if (launch_entries && chunk >= 64) {            // short chunks (small keys) already fill whole rounds: at 2^16, 2 rounds of 16-entry chunks beat 1 round of 32; 48 instead of 64 (the G2 product of a 2^20 key: one round of 208 instead of four of 52) measures the same
         // The caller knows how many sorted entries ONE accumulate launch carries (several products over these bases, e.g. Groth16's A and C):
         // cut it into a WHOLE number of rounds of the chip's resident lanes (256 CUs x 4 SIMDs x 3 (G1) or 2 (G2) waves x 64 lanes, half as many
         // chunks for the lane pairs of G2).  Every lane does the same number of additions, so a launch whose chunks fill 2.65 rounds costs three (2^20
