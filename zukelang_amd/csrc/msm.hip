@@ -546,7 +546,7 @@ static constexpr uint32_t BA_FINISH_CHUNK = 8;       // sorted entries per lane 
 // BY_CHUNK = false: one worker (lane, or lane pair) per BUCKET.  BY_CHUNK = true: one worker per CHUNK BORDER -- worker t looks up the bucket of the last
 // entry of chunk t (binary search in the offsets) and owns the bucket's fix-up if the run starts in chunk t and goes on beyond it.  With more buckets
 // than chunks (windows above 16 bits: 2^19 buckets, runs of ~26 entries inside chunks of ~200) one bucket in eight crosses a border: per bucket, a
-// wave ran the additions with a few of its lanes (PMC at 2^20: 317 M wave instructions per proof for work worth 7 M on full waves).
+// wave ran the additions with a few of its lanes (PMC at 2^20: 317 M wave instructions per proof; 153 M per border).
 template <class T, bool BY_CHUNK> FF_INLINE void fixup_body(const TailJob& job) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint32_t* __restrict__ offsets = job.offsets;
@@ -1155,27 +1155,32 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     const DigitPlan dp = digit_plan(b.c);
     const bool wide = dp.nd0 > DW_POINTS;
     // bucket sums -> digit sums: on slots (msm_tail.hip) where the chain is latency-bound, one lane per point where the launch is throughput-bound
-    // (msm_tail.cuh).  ZK_TAIL_SLOTS = 0 / 1 forces one form (A/B runs).  Digit sums -> product: always msm_tail.hip.
+    // (msm_tail.cuh).  ZK_TAIL_SLOTS = 0 / 1 forces one form of the digit sums, ZK_TAIL_FIXUP_SLOTS = 1 puts the fix-up on slots (A/B runs, latency-first
+    // deployments).  Digit sums -> product: always msm_tail.hip.
     static const int force = ZK_ENV("ZK_TAIL_SLOTS") ? atoi(ZK_ENV("ZK_TAIL_SLOTS")) : -1;
-    if (force < 0 ? !wide : force != 0) {
-        ZKCHK(msm_tail_sums_slots(jobs, count, n2, max_nb, nwin, b.c, s));
+    static const int force_fixup = ZK_ENV("ZK_TAIL_FIXUP_SLOTS") ? atoi(ZK_ENV("ZK_TAIL_FIXUP_SLOTS")) : -1;
+    const bool sums_on_slots = force < 0 ? !wide : force != 0;
+    if (force_fixup > 0) {                                 // default: lanes at every width (fewer instructions: +1.5 % proofs/s at 2^16, +0.8 % at 2^18; slots: -0.3 ms of a lone 2^18 proof)
+        ZKCHK(msm_tail_fixup_slots(jobs, count, n2, max_nb, s));
     } else {
-        {
-            ScopedTimer t1("msm_reduce:fixup", s);
-            // one worker per bucket, or per chunk border where those are fewer (k_msm_fixup)
-            const uint32_t lanes_per = n2 ? 2 : 1;
-            static const bool by_chunk_ok = !(ZK_ENV("ZK_FIXUP_BY_CHUNK") && atoi(ZK_ENV("ZK_FIXUP_BY_CHUNK")) == 0);      // A/B switch
-            if (by_chunk_ok && max_chunks < max_nb) {
-                dim3 gf = grid_for(max_chunks * lanes_per, 128);
-                gf.z = count;
-                hipLaunchKernelGGL(k_msm_fixup<true>, gf, dim3(128), 0, s, jobs);
-            } else {
-                dim3 gf = grid_for(max_lanes, 128);
-                gf.z = count;
-                hipLaunchKernelGGL(k_msm_fixup<false>, gf, dim3(128), 0, s, jobs);
-            }
-            hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
+        ScopedTimer t1("msm_reduce:fixup", s);
+        // one worker per bucket, or per chunk border where those are fewer (k_msm_fixup)
+        const uint32_t lanes_per = n2 ? 2 : 1;
+        static const bool by_chunk_ok = !(ZK_ENV("ZK_FIXUP_BY_CHUNK") && atoi(ZK_ENV("ZK_FIXUP_BY_CHUNK")) == 0);      // A/B switch
+        if (by_chunk_ok && max_chunks < max_nb) {
+            dim3 gf = grid_for(max_chunks * lanes_per, 128);
+            gf.z = count;
+            hipLaunchKernelGGL(k_msm_fixup<true>, gf, dim3(128), 0, s, jobs);
+        } else {
+            dim3 gf = grid_for(max_lanes, 128);
+            gf.z = count;
+            hipLaunchKernelGGL(k_msm_fixup<false>, gf, dim3(128), 0, s, jobs);
         }
+        hipLaunchKernelGGL(k_msm_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(256), 0, s, jobs);
+    }
+    if (sums_on_slots) {
+        ZKCHK(msm_tail_digit_sums_slots(jobs, count, n2, nwin, b.c, s));
+    } else {
         // workgroups sized for the curve with fewer digit values per workgroup (G2: 128 lanes = 64 points = 2 values; G1: 8)
         const uint32_t per_wg = wide ? (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, true>::N : DS_THREADS / DsGroup<Fp, true>::N)
                                      : (n2 ? DS_THREADS / 2 / DsGroup<Fp2H, false>::N : DS_THREADS / DsGroup<Fp, false>::N);

@@ -47,11 +47,15 @@ static inline size_t tail_wsum_points(const DigitPlan& p, uint32_t nwin) {
 }
 
 // msm_tail.hip: the reduction with every point spread over four slots of a wave (ec_slots.cuh); nwin = bucket sets (1 for resident tables).
-//   sums:   fixup + digit sums (bucket sums -> S in `red`).  Latency-bound up to 2^15 buckets, where the four slots pay; above (windows of more than
-//           16 bits) these two launches are bound by the chip's throughput and the one-lane-per-point kernels of msm.hip do the same work in fewer
-//           instructions (2^20 constraints, c = 20, a dozen proofs in flight: 54.5 against 52.5 M constraints/s).
-//   weight: S -> the product (block weights, combine, Horner over the windows): a few hundred points, always on slots.
-int msm_tail_sums_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t max_nb, uint32_t nwin, uint32_t c, hipStream_t s);
+//   fixup:      chunk partial sums -> bucket sums.  OPTIONAL (ZK_TAIL_FIXUP_SLOTS=1): this step is bound by the chip's throughput at every size (one
+//               addition per chunk border), where a slot addition costs 16 slot-products and four copies of the non-multiply work for 14 useful
+//               products -- the one-lane kernels of msm.hip are the default (+1.5 % proofs/s at 2^16); on slots a lone 2^18 proof is 0.3 ms shorter.
+//   digit sums: bucket sums -> S in `red`.  Latency-bound up to 2^15 buckets, where the four slots pay (same instruction count, 0.42 -> 0.24 ms of a
+//               lone 2^16 proof); above (windows of more than 16 bits) throughput-bound: the one-lane-per-point kernel of msm.hip
+//               (2^20 constraints, c = 20, a dozen proofs in flight: 54.5 against 52.5 M constraints/s with both sums steps on slots).
+//   weight:     S -> the product (block weights, combine, Horner over the windows): a few hundred points, always on slots.
+int msm_tail_fixup_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t max_nb, hipStream_t s);
+int msm_tail_digit_sums_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t nwin, uint32_t c, hipStream_t s);
 int msm_tail_weight_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t nwin, uint32_t c, hipStream_t s);
 
 }  // namespace zk

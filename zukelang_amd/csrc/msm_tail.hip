@@ -276,26 +276,27 @@ __global__ __launch_bounds__(64) void k_tail_windows(TailJobs jobs, uint32_t nw,
 }
 
 // ================================================================== host side
-int msm_tail_sums_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t max_nb, uint32_t nwin, uint32_t c, hipStream_t s) {
+int msm_tail_fixup_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t max_nb, hipStream_t s) {
     const uint32_t lanes_per_point = n2 ? SlotGeom<Fp2H>::G : SlotGeom<Fp>::G;
-    {
-        ScopedTimer t1("msm_reduce:fixup", s);
-        const uint64_t lanes = (uint64_t)max_nb * lanes_per_point;
-        hipLaunchKernelGGL(k_tail_fixup, dim3((unsigned)((lanes + FX_THREADS - 1) / FX_THREADS), 1, count), dim3(FX_THREADS), 0, s, jobs);
-        hipLaunchKernelGGL(k_tail_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(FXB_THREADS), 0, s, jobs);
-    }
+    ScopedTimer t1("msm_reduce:fixup", s);
+    const uint64_t lanes = (uint64_t)max_nb * lanes_per_point;
+    hipLaunchKernelGGL(k_tail_fixup, dim3((unsigned)((lanes + FX_THREADS - 1) / FX_THREADS), 1, count), dim3(FX_THREADS), 0, s, jobs);
+    hipLaunchKernelGGL(k_tail_fixup_big, dim3(max_nb < 256 ? max_nb : 256, 1, count), dim3(FXB_THREADS), 0, s, jobs);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+int msm_tail_digit_sums_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t nwin, uint32_t c, hipStream_t s) {
+    const uint32_t lanes_per_point = n2 ? SlotGeom<Fp2H>::G : SlotGeom<Fp>::G;
     const DigitPlan dp = digit_plan(c);
     const bool wide = dp.nd0 > DW_POINTS;
-    {
-        ScopedTimer t2("msm_reduce:digit_sums", s);
-        // workgroups sized for the curve with fewer digit values per workgroup
-        const uint32_t nt = wide ? DsThreads<true>::N : DsThreads<false>::N;
-        const uint32_t per_wg = wide ? nt / lanes_per_point / (n2 ? DsPoints<Fp2H, true>::N : DsPoints<Fp, true>::N)
-                                     : nt / lanes_per_point / (n2 ? DsPoints<Fp2H, false>::N : DsPoints<Fp, false>::N);
-        const dim3 gd((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count);
-        if (wide) hipLaunchKernelGGL(k_tail_digit_sums<true>, gd, dim3(nt), 0, s, jobs, dp);
-        else hipLaunchKernelGGL(k_tail_digit_sums<false>, gd, dim3(nt), 0, s, jobs, dp);
-    }
+    ScopedTimer t2("msm_reduce:digit_sums", s);
+    // workgroups sized for the curve with fewer digit values per workgroup
+    const uint32_t nt = wide ? DsThreads<true>::N : DsThreads<false>::N;
+    const uint32_t per_wg = wide ? nt / lanes_per_point / (n2 ? DsPoints<Fp2H, true>::N : DsPoints<Fp, true>::N)
+                                 : nt / lanes_per_point / (n2 ? DsPoints<Fp2H, false>::N : DsPoints<Fp, false>::N);
+    const dim3 gd((dp.nd0 + dp.nd1 + per_wg - 1) / per_wg, nwin, count);
+    if (wide) hipLaunchKernelGGL(k_tail_digit_sums<true>, gd, dim3(nt), 0, s, jobs, dp);
+    else hipLaunchKernelGGL(k_tail_digit_sums<false>, gd, dim3(nt), 0, s, jobs, dp);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
