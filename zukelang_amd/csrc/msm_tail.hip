@@ -1,7 +1,8 @@
 // Bucket reduction (steps 5-7 of msm_run) with every point spread over four slots of a wave: ec_slots.cuh explains the group law,
 // msm_tail.cuh the buffers.  A dependent addition costs 4 product times instead of the 14 of one lane per point:
 //
-//   fixup         a bucket whose run of sorted entries was cut by chunk borders: the partial sums of its chunks, one GROUP per bucket
+//   fixup         a bucket whose run of sorted entries was cut by chunk borders: the partial sums of its chunks, one GROUP per bucket (OPTIONAL,
+//                 ZK_TAIL_FIXUP_SLOTS=1: this step is throughput-bound and runs on lanes by default, msm_tail.cuh)
 //   digit_sums    S0[d] = sum of the buckets whose low digit is d, S1[d] = those whose high digit is d   (16-64 groups per digit value + LDS tree)
 //   block_weight  sum_j j * S[d] and sum_j S[d] over blocks of 8-64 digit values (suffix scan + tree through LDS, one small workgroup per block)
 //   combine       the blocks of both halves -> the product: 2^lb * V1 + V0, one workgroup per product
