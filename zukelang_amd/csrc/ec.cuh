@@ -218,27 +218,6 @@ template <class F> FF_INLINE Aff<F> xyzz_to_aff(const Xyzz<F>& p) {
     const auto izzz = fe_mul(i, p.zz);
     return {fe_mul(p.x, izz), fe_mul(p.y, izzz)};
 }
-// k * p for a small non-negative k (bucket index weights), double-and-add from the top bit
-template <class F> FF_INLINE Xyzz<F> xyzz_mul_u32(const Xyzz<F>& p, uint32_t k) {
-    Xyzz<F> acc = xyzz_inf<F>();
-    for (int b = 31 - __builtin_clz(k | 1); b >= 0; b--) {
-        acc = xyzz_dbl(acc);
-        if ((k >> b) & 1) xyzz_add(acc, p);
-    }
-    return acc;
-}
-
-// same with the group operations expanded in place (field products stay out of line): for kernels whose
-// points live in registers from load to store
-template <class F> FF_INLINE Xyzz<F> xyzz_mul_u32_inl(const Xyzz<F>& p, uint32_t k) {
-    Xyzz<F> acc = xyzz_inf<F>();
-    for (int b = 31 - __builtin_clz(k | 1); b >= 0; b--) {
-        acc = xyzz_dbl_impl(acc);
-        if ((k >> b) & 1) xyzz_add_impl(acc, p);
-    }
-    return acc;
-}
-
 // ---- memory layout: affine points are stored as consecutive Montgomery coordinates
 //      (G1: x | y = 96 B; G2: x.c0 | x.c1 | y.c0 | y.c1 = 192 B), XYZZ as x | y | zz | zzz.
 //      Memory always holds fully reduced coordinates as 12 dense 32-bit words (48 B).

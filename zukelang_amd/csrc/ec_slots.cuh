@@ -124,15 +124,4 @@ template <class T> FF_INLINE void xyzz_add_slots(T& own, const T& qs, const T& q
     const B18 Y3 = fe_sub(m4, w);
     own = slot_select<T>(s == 3, slot_select<T>(s == 2, slot_select<T>(s == 1, w, Y3), m3), m4);
 }
-// k * p (k >= 0 small), double-and-add from the top bit; ps = coordinate s of p
-template <class T> FF_INLINE T xyzz_mul_u32_slots(const T& ps, uint32_t k) {
-    const T px = slot_fetch(ps, slot_addr<T>(slot_id<T>() ^ 2));
-    T acc = slot_zero<T>();
-    for (int b = 31 - __builtin_clz(k | 1); b >= 0; b--) {
-        acc = xyzz_dbl_slots(acc);
-        if ((k >> b) & 1) xyzz_add_slots(acc, ps, px);
-    }
-    return acc;
-}
-
 }  // namespace zk
