@@ -2,11 +2,15 @@
 //   V0  product scanning, one 64-bit accumulator per column (the shipped form, ff.cuh fp_mul_limbs): 2(k+1) DEPENDENT multiply-adds per column
 //   V1  operand scanning (row-wise, 15 lazily carried 64-bit column accumulators): the 28 multiply-adds of a row are independent
 //   V2  product scanning with TWO accumulators per column (a b part | m p part), joined once per column
-// Prints G products/s for 1, 2, 3, 4, 6 waves per SIMD and the single-wave latency; checks that the three forms agree.
+//   V3  product scanning with ONE chain per column forced by inline v_mad_u64_u32 (no join of the shifted carry: 26 instructions fewer per product)
+// Prints G products/s for 1, 2, 3, 4, 6 waves per SIMD and the single-wave latency; checks that the forms agree.
 // RESULT (round 3, profiles/r03_mul_forms.txt): as a bare dependent chain V1 / V2 reach 77 G products/s at 2 waves per SIMD where V0 reaches 70
 // (78.5 for all three from 3 waves up) -- but swapped into the library (ff.cuh / fr29.cuh, A/B on one box: gpurun_out/r03c) the accumulate
 // kernels, the proofs per second and even the library's own multiplier benchmark did not move (G1 accumulate 9.79 vs 9.83 ms at 2^20): inside
 // a group addition the multiply-add chains are not what the SIMDs wait for.  The shipped form stays V0.
+// V3: the compiler (LLVM's reassociation ranks the shifted carry highest and adds it LAST, hence the separate chain per column and its join) cannot be
+// talked out of the join in C++, and every inline-asm block is followed by a wait state (s_nop 0: 759 of them in a loop of two products), so the
+// forced chain is slower at every occupancy (45.7 / 70.6 / 76.8 G products/s at 1 / 2 / 6 waves per SIMD against 64.2 / 71.3 / 78.7).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -95,9 +99,47 @@ __device__ __forceinline__ void mul_v2(uint32_t* r, const uint32_t* a, const uin
     r[L - 1] = (uint32_t)acc;
 }
 
+// V3  product scanning with ONE chain per column, forced: the multiply-adds are inline v_mad_u64_u32 (opaque to the reassociation that makes the
+//     compiler start every column's sum at zero and JOIN it to the shifted carry with a v_lshl_add_u64: 26 instructions per product)
+__device__ __forceinline__ uint64_t mad_vv(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(cy) : "v"(a), "v"(b));
+    return c;
+}
+__device__ __forceinline__ uint64_t mad_vs(uint32_t a, uint32_t b, uint64_t c) {     // b: a constant (scalar register)
+    uint64_t cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(c), "=s"(cy) : "v"(a), "s"(b));
+    return c;
+}
+__device__ __forceinline__ void mul_v3(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    uint64_t acc = 0;
+    uint32_t m[L];
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc = mad_vv(a[i], b[k - i], acc);
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = mad_vs(m[i], P29[k - i], acc);
+        m[k] = ((uint32_t)acc * NINV) & MASK;
+        acc = mad_vs(m[k], P29[0], acc);
+        acc >>= W;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) acc = mad_vv(a[i], b[k - i], acc);
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) acc = mad_vs(m[i], P29[k - i], acc);
+        r[k - L] = (uint32_t)acc & MASK;
+        acc >>= W;
+    }
+    r[L - 1] = (uint32_t)acc;
+}
+
 template <int V> __device__ __forceinline__ void mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
     if (V == 0) mul_v0(r, a, b);
     else if (V == 1) mul_v1(r, a, b);
+    else if (V == 3) mul_v3(r, a, b);
     else mul_v2(r, a, b);
 }
 template <int V> __global__ void k_bench(uint32_t* out, uint32_t iters) {
@@ -233,7 +275,7 @@ template <int V> static void run(uint32_t* d, const char* name) {
 int main() {
     uint32_t* d;
     hipMalloc(&d, 4096);
-    uint32_t ha[L], hb[L], r0[L], r1[L], r2[L];
+    uint32_t ha[L], hb[L], r0[L], r1[L], r2[L], r3[L];
     for (int i = 0; i < L; i++) { ha[i] = (0x9e3779b9u * (i + 1)) & MASK; hb[i] = (0x85ebca6bu * (i + 7)) & MASK; }
     ha[L - 1] &= 0xffff; hb[L - 1] &= 0xffff;
     uint32_t *da = d + 64, *db = d + 128;
@@ -242,11 +284,13 @@ int main() {
     k_one<0><<<1, 1>>>(d, da, db); hipMemcpy(r0, d, sizeof r0, hipMemcpyDeviceToHost);
     k_one<1><<<1, 1>>>(d, da, db); hipMemcpy(r1, d, sizeof r1, hipMemcpyDeviceToHost);
     k_one<2><<<1, 1>>>(d, da, db); hipMemcpy(r2, d, sizeof r2, hipMemcpyDeviceToHost);
+    k_one<3><<<1, 1>>>(d, da, db); hipMemcpy(r3, d, sizeof r3, hipMemcpyDeviceToHost);
     int same = 1;
-    for (int i = 0; i < L; i++) same &= (r0[i] == r1[i]) & (r0[i] == r2[i]);
+    for (int i = 0; i < L; i++) same &= (r0[i] == r1[i]) & (r0[i] == r2[i]) & (r0[i] == r3[i]);
     printf("forms agree: %s\n", same ? "yes" : "NO");
     run<0>(d, "V0 product scanning, one accumulator (shipped)");
     run<1>(d, "V1 operand scanning, 15 lazily carried column accumulators");
     run<2>(d, "V2 product scanning, two accumulators per column");
+    run<3>(d, "V3 product scanning, ONE chain per column forced with inline v_mad_u64_u32 (no join)");
     return same ? 0 : 1;
 }
