@@ -38,7 +38,11 @@ struct Slot {
     uint8_t* wit_pinned = nullptr;      // pinned staging copy of a witness handed over as a host buffer (allocated at first use): the caller's
                                         // buffer is read before the call returns, as the header promises, whatever memory it lives in
     bool busy = false, serial = false;
+    // ZK_GRAPH=1: the whole proof of this slot captured ONCE per shape (streams forked or not | raw partial sums | witness from the host) and replayed
+    hipGraphExec_t graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~Slot() {
+        for (hipGraphExec_t g : graph)
+            if (g) (void)hipGraphExecDestroy(g);
         if (s0) { (void)hipStreamDestroy(s0); if (!serial) { (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2); } }
         if (fork) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join1); (void)hipEventDestroy(join2); (void)hipEventDestroy(done); }
         if (host) (void)hipHostFree(host);
@@ -233,17 +237,25 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
 
 // First half of a proof: Fr stage -> the three scalar vectors (canonical Fr, FULL pool lengths p1, p1, p2)
 // written to dA / dC / dB (device memory; the slot's own buffers in the single-call path).
-static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, void* dA, void* dC, void* dB) {
+// The host half of scalars_enqueue: witness (when handed over as a host buffer) and r | s into the slot's pinned staging memory.
+static int stage_inputs(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s) {
     if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call the matching _wait first");
-    const void* wit = k.wit_resident.p;
     if (sol) {
         if (!sl.wit_pinned) HIPCHK(hipHostMalloc((void**)&sl.wit_pinned, 32 * (size_t)k.m, hipHostMallocDefault));
         memcpy(sl.wit_pinned, sol, 32 * (size_t)k.m);
-        HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sl.wit_pinned, 32 * (size_t)k.m, hipMemcpyHostToDevice, sl.s0));
-        wit = sl.wit_raw.p;
     } else if (!k.have_witness) ZK_FAIL(ZK_ERR_ARG, "no witness: pass sol or call zk_groth16_set_witness first");
     memcpy(sl.host + 392, r, 32);
     memcpy(sl.host + 424, s, 32);
+    return ZK_OK;
+}
+// staged = true: stage_inputs has run (graph capture / replay: the stream operations below read the pinned staging memory when they EXECUTE)
+static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, void* dA, void* dC, void* dB, bool staged = false) {
+    if (!staged) ZKCHK(stage_inputs(k, sl, sol, r, s));
+    const void* wit = k.wit_resident.p;
+    if (sol) {
+        HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sl.wit_pinned, 32 * (size_t)k.m, hipMemcpyHostToDevice, sl.s0));
+        wit = sl.wit_raw.p;
+    }
     HIPCHK(hipMemcpyAsync(sl.rs.p, sl.host + 392, 64, hipMemcpyHostToDevice, sl.s0));
     const uint32_t *v, *w;
     if (k.lagrange) {          // values a = L w, b = R w and h on the shifted points: no basis conversion
@@ -265,13 +277,17 @@ static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const ui
 // Second half: the three MSMs over this rank's slice of the pools.  dA / dC / dB point at the scalars of
 // that slice ((hi1-lo1), (hi1-lo1), (hi2-lo2) elements).  {C on s0, B on s1, A on s2} -> affine bytes (or raw
 // XYZZ partial sums) -> pinned host buffer.
-static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC, const void* dB, bool raw) {
-    // fork onto the slot's extra streams only while no other proof is in flight on this key (and never when ZK_SLOT_STREAMS forces it)
+// fork onto the slot's extra streams only while no other proof is in flight on this key (and never when ZK_SLOT_STREAMS forces it)
+static bool runs_serial(Groth16Key& k, Slot& sl) {
     bool serial = sl.serial;
     if (ctx().profiling >= 2) serial = true;      // the per-family event timers want un-overlapped launches (bench.py's one-proof-in-flight pass)
     if (!serial && !ZK_ENV("ZK_SLOT_STREAMS"))
         for (uint32_t i = 0; i < MAX_SLOTS; i++)
             if (k.slots[i] && k.slots[i].get() != &sl && k.slots[i]->busy) serial = true;
+    return serial;
+}
+static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC, const void* dB, bool raw, int force_serial = -1) {
+    const bool serial = force_serial < 0 ? runs_serial(k, sl) : force_serial != 0;
     char* res = sl.results.as<char>();
     char* out = sl.out_dev.as<char>();
     const size_t g1b = xyzz_bytes(CURVE_G1);
@@ -317,6 +333,34 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
 }
 // Enqueues one whole proof on the slot's streams and returns without waiting.
 static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, bool raw) {
+    static const bool graphs = ZK_ENV("ZK_GRAPH") && atoi(ZK_ENV("ZK_GRAPH")) != 0;
+    if (graphs && !ctx().profiling) {
+        // One hipGraph per slot and proof shape, captured from the very calls below the first time and replayed afterwards: a proof is ~60 stream
+        // operations whose arguments never change (the slot owns every buffer; witness, r, s travel through its pinned staging memory).
+        ZKCHK(stage_inputs(k, sl, sol, r, s));
+        const bool serial = runs_serial(k, sl);
+        hipGraphExec_t& ge = sl.graph[(serial ? 1 : 0) | (raw ? 2 : 0) | (sol ? 4 : 0)];
+        if (!ge) {
+            HIPCHK(hipStreamBeginCapture(sl.s0, hipStreamCaptureModeThreadLocal));
+            int rc = scalars_enqueue(k, sl, sol, r, s, sl.scalA.p, sl.scalC.p, sl.scalB.p, true);
+            if (rc == ZK_OK)
+                rc = msms_enqueue(k, sl, sl.scalA.as<char>() + 32 * k.lo1, sl.scalC.as<char>() + 32 * k.lo1, sl.scalB.as<char>() + 32 * k.lo2, raw, serial ? 1 : 0);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(sl.s0, &g);
+            if (rc != ZK_OK) {
+                if (g) (void)hipGraphDestroy(g);
+                return rc;
+            }
+            HIPCHK(e);
+            const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            HIPCHK(ei);
+        }
+        HIPCHK(hipGraphLaunch(ge, sl.s0));
+        HIPCHK(hipEventRecord(sl.done, sl.s0));
+        sl.busy = true;
+        return ZK_OK;
+    }
     ZKCHK(scalars_enqueue(k, sl, sol, r, s, sl.scalA.p, sl.scalC.p, sl.scalB.p));
     ZKCHK(msms_enqueue(k, sl, sl.scalA.as<char>() + 32 * k.lo1, sl.scalC.as<char>() + 32 * k.lo1, sl.scalB.as<char>() + 32 * k.lo2, raw));
     HIPCHK(hipEventRecord(sl.done, sl.s0));
