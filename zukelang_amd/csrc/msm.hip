@@ -303,10 +303,15 @@ __global__ void k_msm_scatter(SortJobs jobs, DigitArgs a) {
 // fall out of the same scan.
 static constexpr uint32_t SORT_THREADS = 1024;
 static constexpr uint32_t SORT_MAX_BUCKETS = 32768;
+// LDS_BINS: counters the kernel reserves -- SORT_MAX_BUCKETS (128 KiB: one workgroup per CU and hardly any LDS left for the accumulate kernels of the
+// other proofs in flight) or SORT_FEW_BINS for the 512 coarse bins of the two-level sort's first level (2 KiB: the sort of a 2^20 proof no longer
+// evicts the accumulate workgroups from the compute units it runs on)
+static constexpr uint32_t SORT_FEW_BINS = 512;
+template <uint32_t LDS_BINS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(SortJobs jobs, DigitArgs a, uint64_t per_wg, uint32_t nb) {
     const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
     uint32_t* __restrict__ wgcount = jobs.wgcount[blockIdx.y];
-    __shared__ uint32_t hist[SORT_MAX_BUCKETS];
+    __shared__ uint32_t hist[LDS_BINS];
     const uint32_t wg = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) hist[b] = 0;
     __syncthreads();
@@ -333,12 +338,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(SortJobs jobs, 
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) wgcount[(uint64_t)wg * nb + b] = hist[b];   // [workgroup][bucket]: coalesced
 }
+template <uint32_t LDS_BINS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(SortJobs jobs, DigitArgs a, uint64_t per_wg, uint32_t nb) {
     const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
     const uint32_t* __restrict__ base = jobs.wgcount[blockIdx.y];
     const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
     uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
-    __shared__ uint32_t cur[SORT_MAX_BUCKETS];
+    __shared__ uint32_t cur[LDS_BINS];
     const uint32_t wg = blockIdx.x;
     for (uint32_t b = threadIdx.x; b < nb; b += SORT_THREADS) cur[b] = offsets[b] + base[(uint64_t)wg * nb + b];
     __syncthreads();
@@ -1036,6 +1042,7 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
         if (w.sort_fine_bits) {
             // level 1 over the coarse bins (its counts / offsets / cursor live in `coarse`), level 2 writes the real offsets and references
             const uint32_t bins = w.nbuckets >> w.sort_fine_bits;
+            if (bins > SORT_FEW_BINS) ZK_FAIL(ZK_ERR_ARG, "two-level sort: more coarse bins than its first level reserves counters for");
             SortJobs l1 = sj;
             for (uint32_t i = 0; i < count; i++) {
                 uint32_t* c3 = ws[i]->coarse.as<uint32_t>();
@@ -1044,23 +1051,23 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             DigitArgs d1 = da;
             d1.coarse_shift = w.sort_fine_bits;
             const uint64_t total = sm ? b.n : b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
-            hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
+            hipLaunchKernelGGL(k_sort_count_lds<SORT_FEW_BINS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
             dim3 gc = grid_for(bins, 256);
             gc.y = count;
             hipLaunchKernelGGL(k_sort_colscan, gc, dim3(256), 0, s, l1, bins, w.sort_wgs);
             hipLaunchKernelGGL(k_scan, dim3(count), dim3(1024), 0, s, l1, bins);
-            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
+            hipLaunchKernelGGL(k_sort_scatter_lds<SORT_FEW_BINS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
             SortJobs l2 = sj;
             for (uint32_t i = 0; i < count; i++) l2.cursor[i] = l1.offsets[i];          // the coarse offsets (k_scan wrote offsets = cursor; the scatter advanced neither: it ranks in LDS)
             hipLaunchKernelGGL(k_sort_fine, dim3(bins, count), dim3(SORT_THREADS), 0, s, l2, w.sort_fine_bits, bins, w.nbuckets);
         } else if (w.sort_wgs) {
             const uint64_t total = sm ? b.n : b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
-            hipLaunchKernelGGL(k_sort_count_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
+            hipLaunchKernelGGL(k_sort_count_lds<SORT_MAX_BUCKETS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
             dim3 gc = grid_for(w.nbuckets, 256);
             gc.y = count;
             hipLaunchKernelGGL(k_sort_colscan, gc, dim3(256), 0, s, sj, w.nbuckets, w.sort_wgs);
             hipLaunchKernelGGL(k_scan, dim3(count), dim3(1024), 0, s, sj, w.nbuckets);
-            hipLaunchKernelGGL(k_sort_scatter_lds, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
+            hipLaunchKernelGGL(k_sort_scatter_lds<SORT_MAX_BUCKETS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
         } else {
             for (uint32_t i = 0; i < count; i++) HIPCHK(hipMemsetAsync(ws[i]->counts.p, 0, 4 * (size_t)(w.nbuckets + 1), s));
             dim3 g = grid_for(b.n * b.nw, 256);
