@@ -944,9 +944,13 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     w.sort_wgs = 0;
     w.sort_fine_bits = 0;
     static constexpr uint32_t COARSE_BINS = 512;
-    if (b.precomp && w.nbuckets > SORT_MAX_BUCKETS && w.nbuckets / COARSE_BINS <= SORT_MAX_FINE && maxN >= ((uint64_t)1 << 22) &&
-        !(getenv("ZK_SORT_TWO_LEVEL") && atoi(getenv("ZK_SORT_TWO_LEVEL")) == 0)) {
-        // windows above 16 bits: two levels (ZK_SORT_TWO_LEVEL=0 falls back to the global-atomic sort, for A/B)
+    // Two levels from 2^15 buckets and 2^20 (scalar, window) pairs up.  Above 2^15 buckets the histogram does not fit LDS; AT 2^15 it does (the
+    // single-level sort below), but its 128 KiB per workgroup evict the accumulate workgroups of the other proofs in flight from every compute unit
+    // the sort runs on: two levels (2 KiB + 20 KiB of LDS) measure +1.6 % proofs/s at 2^16, +1.9 % at 2^18 with the same single-proof latency.
+    // ZK_SORT_TWO_LEVEL=0: never (A/B; above 2^15 buckets that is the global-atomic sort); ZK_SORT_TWO_LEVEL_MIN: log2 of the pair threshold.
+    const int two_level = getenv("ZK_SORT_TWO_LEVEL") ? atoi(getenv("ZK_SORT_TWO_LEVEL")) : 1;
+    const int two_level_min = getenv("ZK_SORT_TWO_LEVEL_MIN") ? atoi(getenv("ZK_SORT_TWO_LEVEL_MIN")) : (w.nbuckets > SORT_MAX_BUCKETS ? 22 : 20);
+    if (b.precomp && w.nbuckets >= SORT_MAX_BUCKETS && w.nbuckets / COARSE_BINS <= SORT_MAX_FINE && maxN >= ((uint64_t)1 << two_level_min) && two_level != 0) {
         w.sort_fine_bits = ceil_log2(w.nbuckets / COARSE_BINS);
         uint64_t wgs = maxN / (4 * (uint64_t)COARSE_BINS);
         w.sort_wgs = (uint32_t)(wgs > 256 ? 256 : wgs);
