@@ -353,6 +353,40 @@ def test_every_window_width_reduces_to_the_same_proof():
             os.environ["ZK_MSM_WINDOW"] = old
 
 
+@pytest.mark.parametrize("c", [16, 19])
+def test_every_form_of_the_bucket_reduction_gives_the_same_proof(c):
+    """The reduction picks per step between one lane (pair) per point and four slots per point (msm.hip: msm_reduce_mixed; ZK_TAIL_SLOTS,
+    ZK_TAIL_FIXUP_SLOTS, ZK_FIXUP_BY_CHUNK select a form, read per call): every combination, at a width on either side of the 2^15-bucket
+    switch, must reproduce the trapdoor oracle's bytes (groth16.ml:116-161)."""
+    n = 1 << 12
+    cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0201)))
+    rng = seeded_rng(0x5EED0202)
+    toxic = [rng() for _ in range(5)]
+    r, s = rng(), rng()
+    L, R_, Oo = csrs(cs)
+    e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
+    pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
+    expect = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    names = ("ZK_MSM_WINDOW", "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK")
+    old = {k: os.environ.get(k) for k in names}
+    try:
+        os.environ["ZK_MSM_WINDOW"] = str(c)              # read by the library when the key's base tables are built
+        prover = Groth16(cs, pk)
+        for sums in ("0", "1"):
+            for fix in ("0", "1"):
+                for chunk in ("0", "1"):
+                    os.environ["ZK_TAIL_SLOTS"], os.environ["ZK_TAIL_FIXUP_SLOTS"], os.environ["ZK_FIXUP_BY_CHUNK"] = sums, fix, chunk
+                    proof = prover.prove_rs(w, r, s)
+                    assert (proof.a, proof.b, proof.c) == expect, "window %d sums-on-slots %s fixup-on-slots %s by-chunk %s" % (c, sums, fix, chunk)
+        prover.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 SWEEP_WINDOWS = (12, 14, 15, 17, 20)      # 17, 20: beyond the LDS histogram -- the two-level counting sort
 
 

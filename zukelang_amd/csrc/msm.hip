@@ -1168,8 +1168,11 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     // bucket sums -> digit sums: on slots (msm_tail.hip) where the chain is latency-bound, one lane per point where the launch is throughput-bound
     // (msm_tail.cuh).  ZK_TAIL_SLOTS = 0 / 1 forces one form of the digit sums, ZK_TAIL_FIXUP_SLOTS = 1 puts the fix-up on slots (A/B runs, latency-first
     // deployments).  Digit sums -> product: always msm_tail.hip.
-    static const int force = ZK_ENV("ZK_TAIL_SLOTS") ? atoi(ZK_ENV("ZK_TAIL_SLOTS")) : -1;
-    static const int force_fixup = ZK_ENV("ZK_TAIL_FIXUP_SLOTS") ? atoi(ZK_ENV("ZK_TAIL_FIXUP_SLOTS")) : -1;
+    // (read per call, not cached: tests/test_gpu_msm.py flips them inside one process to hold every form to the oracle; three getenv per proof)
+    const char* e_sums = getenv("ZK_TAIL_SLOTS");
+    const char* e_fix = getenv("ZK_TAIL_FIXUP_SLOTS");
+    const char* e_chunk = getenv("ZK_FIXUP_BY_CHUNK");
+    const int force = e_sums ? atoi(e_sums) : -1, force_fixup = e_fix ? atoi(e_fix) : -1;
     const bool sums_on_slots = force < 0 ? !wide : force != 0;
     if (force_fixup > 0) {                                 // default: lanes at every width (fewer instructions: +1.5 % proofs/s at 2^16, +0.8 % at 2^18; slots: -0.3 ms of a lone 2^18 proof)
         ZKCHK(msm_tail_fixup_slots(jobs, count, n2, max_nb, s));
@@ -1177,7 +1180,7 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
         ScopedTimer t1("msm_reduce:fixup", s);
         // one worker per bucket, or per chunk border where those are fewer (k_msm_fixup)
         const uint32_t lanes_per = n2 ? 2 : 1;
-        static const bool by_chunk_ok = !(ZK_ENV("ZK_FIXUP_BY_CHUNK") && atoi(ZK_ENV("ZK_FIXUP_BY_CHUNK")) == 0);      // A/B switch
+        const bool by_chunk_ok = !(e_chunk && atoi(e_chunk) == 0);      // A/B switch
         if (by_chunk_ok && max_chunks < max_nb) {
             dim3 gf = grid_for(max_chunks * lanes_per, 128);
             gf.z = count;
