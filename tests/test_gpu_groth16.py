@@ -149,6 +149,46 @@ def test_pipelined_proofs_equal_serial_ones():
     prover.close()
 
 
+def test_graph_replay_gives_the_same_proofs():
+    """ZK_GRAPH=1 (groth16.hip prove_enqueue): every slot captures its proof into a hipGraph the first time and replays it afterwards -- with new
+    (r, s), a resident witness or one handed over as a host buffer, alone (streams forked) or with other proofs in flight.  Same bytes as the plain
+    stream launches and as the oracle; an unsatisfied witness still raises."""
+    cs, w = RC.iterated_cubic(512, 0xFEDCBA)
+    rng = seeded_rng(78)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, _ = Groth16.keygen(lambda: next(it), cs)
+    prover = Groth16(cs, pk)
+    rs = [(rng(), rng()) for _ in range(6)]
+    plain = [prover.prove_rs(w, r, s) for r, s in rs]
+    t = O.groth16_prove_trapdoor(cs.n, cs.m, *csrs(cs), cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rs[0][0]), P.fr_to_bytes(rs[0][1]))
+    assert (plain[0].a, plain[0].b, plain[0].c) == t
+    old = os.environ.get("ZK_GRAPH")
+    os.environ["ZK_GRAPH"] = "1"
+    try:
+        assert [prover.prove_rs(w, r, s) for r, s in rs] == plain            # capture, then five replays (witness from the host, forked streams)
+        prover.set_witness(w)
+        depth, got = 3, [None] * len(rs)
+        for i, (r, s) in enumerate(rs):                                      # resident witness, three slots in flight: other graphs per slot
+            if i >= depth:
+                got[i - depth] = prover.prove_wait(i % depth)
+            prover.prove_async(None, r, s, i % depth)
+        for i in range(len(rs) - depth, len(rs)):
+            got[i] = prover.prove_wait(i % depth)
+        assert got == plain
+        bad = list(w)
+        bad[3] = (bad[3] + 1) % RC.FR_MODULUS
+        with pytest.raises(Exception):
+            prover.prove_rs(bad, 1, 2)
+        assert prover.prove_rs(w, *rs[1]) == plain[1]                        # and the slot is usable afterwards
+    finally:
+        if old is None:
+            os.environ.pop("ZK_GRAPH", None)
+        else:
+            os.environ["ZK_GRAPH"] = old
+        prover.close()
+
+
 @pytest.mark.parametrize("log_n", [16, 18, 20, 22])
 def test_full_size_trapdoor_and_verify(log_n):
     """BASELINE configs 2 (2^16) and up: expected proof bytes from the trapdoor evaluation (exact at

@@ -333,7 +333,8 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
 }
 // Enqueues one whole proof on the slot's streams and returns without waiting.
 static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, bool raw) {
-    static const bool graphs = ZK_ENV("ZK_GRAPH") && atoi(ZK_ENV("ZK_GRAPH")) != 0;
+    const char* eg = getenv("ZK_GRAPH");                   // read per proof (one getenv): tests switch it inside one process
+    const bool graphs = eg && atoi(eg) != 0;
     if (graphs && !ctx().profiling) {
         // One hipGraph per slot and proof shape, captured from the very calls below the first time and replayed afterwards: a proof is ~60 stream
         // operations whose arguments never change (the slot owns every buffer; witness, r, s travel through its pinned staging memory).
