@@ -407,7 +407,7 @@ def test_every_form_of_the_bucket_reduction_gives_the_same_proof(c):
     e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
     pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
     expect = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
-    names = ("ZK_MSM_WINDOW", "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK")
+    names = ("ZK_MSM_WINDOW", "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE")
     old = {k: os.environ.get(k) for k in names}
     try:
         os.environ["ZK_MSM_WINDOW"] = str(c)              # read by the library when the key's base tables are built
@@ -418,6 +418,14 @@ def test_every_form_of_the_bucket_reduction_gives_the_same_proof(c):
                     os.environ["ZK_TAIL_SLOTS"], os.environ["ZK_TAIL_FIXUP_SLOTS"], os.environ["ZK_FIXUP_BY_CHUNK"] = sums, fix, chunk
                     proof = prover.prove_rs(w, r, s)
                     assert (proof.a, proof.b, proof.c) == expect, "window %d sums-on-slots %s fixup-on-slots %s by-chunk %s" % (c, sums, fix, chunk)
+        for k in names[1:]:
+            os.environ.pop(k, None)
+        # ... and the forms of the bucket ACCUMULATION the A/B switches select (msm_acc_g1.hip / msm_acc_g2.hip): register instead of LDS-DMA
+        # look-ahead, the 6-product second step of a chunk, G2 with its products out of line
+        for glds, mm, g2i in (("0", "0", "1"), ("1", "1", "1"), ("0", "1", "0"), ("1", "0", "0")):
+            os.environ["ZK_ACC_G1_GLDS"], os.environ["ZK_ACC_G1_MMADD"], os.environ["ZK_ACC_G2_INLINE"] = glds, mm, g2i
+            proof = prover.prove_rs(w, r, s)
+            assert (proof.a, proof.b, proof.c) == expect, "window %d G1 LDS look-ahead %s second step %s G2 inline %s" % (c, glds, mm, g2i)
         prover.close()
     finally:
         for k, v in old.items():

@@ -9,9 +9,10 @@
 
 namespace zk {
 int msm_accumulate_launch_g1(uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s) {
-    // ZK_ACC_G1_GLDS=0: the register look-ahead (A/B of the LDS-DMA look-ahead; read once)
-    static const bool glds = !(getenv("ZK_ACC_G1_GLDS") && atoi(getenv("ZK_ACC_G1_GLDS")) == 0);
-    static const bool mm = getenv("ZK_ACC_G1_MMADD") && atoi(getenv("ZK_ACC_G1_MMADD")) != 0;      // A/B: the 6-product second step (more code)
+    // ZK_ACC_G1_GLDS=0: the register look-ahead (A/B of the LDS-DMA look-ahead).  Read per launch: the GPU suite holds every form to the oracle in one process.
+    const char *eg = getenv("ZK_ACC_G1_GLDS"), *em = getenv("ZK_ACC_G1_MMADD");
+    const bool glds = !(eg && atoi(eg) == 0);
+    const bool mm = em && atoi(em) != 0;      // A/B: the 6-product second step (more code)
     if (glds && !mm) hipLaunchKernelGGL((k_msm_accumulate<Fp, false, true, false>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
     else if (glds) hipLaunchKernelGGL((k_msm_accumulate<Fp, false, true>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
     else hipLaunchKernelGGL((k_msm_accumulate<Fp, false, false>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
