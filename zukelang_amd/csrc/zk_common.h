@@ -81,7 +81,9 @@ struct ScopedTimer {
 
 void profile_count(const char* name, uint64_t add);      // no-op unless profiling level 2 is on
 
-// Environment knobs are read ONCE per process (tuning / test switches; a getenv per launch is a libc lock + string scan on the proof's hot path).
+// Environment knobs are read ONCE per process (tuning switches; a getenv per launch is a libc lock + string scan on the proof's hot path).  The
+// exception: the handful of kernel-FORM switches of the MSM (msm.hip msm_reduce_mixed, msm_acc_g1/g2.hip, groth16.hip ZK_GRAPH), read per proof so that
+// the GPU tests can hold every form to the oracle inside one process.
 static inline const char* env_once(const char* name, const char** cache, bool* done) {
     if (!*done) { *cache = getenv(name); *done = true; }
     return *cache;
