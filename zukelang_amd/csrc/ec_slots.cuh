@@ -12,6 +12,9 @@
 // Four product times per link instead of fourteen, for five operand exchanges between the slots (ds_bpermute, 14 limbs each: ~3 % of the
 // instructions of one product step).  Doubling (dbl-2008-s-1) has three levels.  Same formulas, same special cases and therefore the same
 // group elements as xyzz_add_impl / xyzz_dbl_impl of ec.cuh; coordinates differ from theirs only by lazy-reduction representatives.
+// (The reference's G.add / G.double behind curve.ml:159-191, delegated to opam bls12-381.)  A slot addition executes 16 slot-products and four copies of
+// the non-multiply work for 14 useful products: it pays where a launch is bound by its chain, not where it is bound by the chip's throughput
+// (msm_tail.cuh says which steps of the reduction are which).
 //
 // All lanes of a group (4 slots) must be active and follow the same control flow through these functions: every predicate below is made
 // group-uniform by fetching it from the slot that owns it.
