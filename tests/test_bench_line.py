@@ -1,0 +1,81 @@
+"""The measurement contract's LINE (round-3 verdict: a 24 KB line came back `parsed: null` from the driver): bench.py's final stdout line is built by
+`compact_line` from the full result dict and never exceeds LINE_BUDGET bytes; the detail goes to bench_detail.json and stderr."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _canned():
+    """last round's full result (the line the driver could not parse), committed under profiles/"""
+    return json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
+
+
+def test_compact_line_fits_the_budget_and_round_trips():
+    b = _bench()
+    full = _canned()
+    assert len(json.dumps(full)) > 20000                      # the input really is the oversized line
+    line = b.compact_line(full)
+    assert len(line) < 4096 and b.LINE_BUDGET <= 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity", "other_workloads"):
+        assert k in d, k
+    assert d["metric"] == full["metric"] and d["n_gpus"] == 1 and d["vs_baseline"] is None
+    assert abs(d["value"] / full["value"] - 1) < 1e-4
+    assert d["config"]["workload"].startswith("groth16_prove 2^20") and d["config"]["constraints"] == 1 << 20
+    # every derived-key figure keeps the tau-power figure of the same key beside it
+    assert d["config"]["key_form"] == "tau_powers_uploaded_lagrange_derived_on_device"
+    assert abs(d["config"]["tau_power_value"] / full["config"]["tau_power_form"]["value"] - 1) < 1e-4
+    assert d["config"]["derive_lagrange_s"] == full["config"]["derive_lagrange_s"] and d["config"]["break_even_proofs"] == full["config"]["tau_power_form"]["break_even_proofs"]
+    r = d["roofline"]
+    for k in ("kernel", "bound", "peak", "unit", "algorithmic_bytes_per_launch", "avg_launch_ms", "achieved", "frac", "traffic", "alu_frac"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "constraints/s" and c["n"] == 256 and "infeasible" in c["model_2^20"]
+    assert len(d["other_workloads"]) == len(full["other_workloads"])
+    for o, f in zip(d["other_workloads"], full["other_workloads"]):
+        assert abs(o["value"] / f["value"] - 1) < 1e-4 and o["parity"] is True
+    assert d["parity"].startswith("passed")
+
+
+def test_compact_line_sheds_optional_blocks_rather_than_overflow():
+    b = _bench()
+    full = _canned()
+    full["other_workloads"] = full["other_workloads"] * 12          # 48 workloads: the optional blocks must go, the contract's fields stay
+    line = b.compact_line(full)
+    assert len(line) <= b.LINE_BUDGET
+    d = json.loads(line)
+    assert "other_workloads" not in d and d["roofline"] and d["cpu_baseline"] and d["value"]
+
+
+def test_compact_line_of_a_sharded_run_without_cpu_legs():
+    b = _bench()
+    full = _canned()
+    full.update(n_gpus=8, roofline=None, cpu_baseline=None, cpu_fast_context=None, other_workloads=[], parity=None)
+    full["config"]["sharding"] = "MSM base points over ranks " * 40
+    d = json.loads(b.compact_line(full))
+    assert d["n_gpus"] == 8 and d["roofline"] is None and d["cpu_baseline"] is None and d["parity"] == "skipped" and len(d["config"]["sharding"]) <= 160
+
+
+def test_emit_writes_the_detail_file_and_prints_the_line_last(tmp_path, capsys, monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(b, "DETAIL_FILE", str(tmp_path / "bench_detail.json"))
+    full = _canned()
+    b.emit(full)
+    cap = capsys.readouterr()
+    out_lines = [ln for ln in cap.out.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and len(out_lines[0]) < 4096 and json.loads(out_lines[0])["metric"] == full["metric"]
+    assert cap.err.startswith("BENCH_DETAIL {") and json.loads(cap.err[len("BENCH_DETAIL "):]) == full
+    assert json.load(open(tmp_path / "bench_detail.json")) == full
