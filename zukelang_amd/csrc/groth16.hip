@@ -40,6 +40,7 @@ struct Slot {
     bool busy = false, serial = false;
     // ZK_GRAPH=1: the whole proof of this slot captured ONCE per shape (streams forked or not | raw partial sums | witness from the host) and replayed
     hipGraphExec_t graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t graph_forms = 0;           // hash of the kernel-form switches the graphs were captured under (test mode only)
     ~Slot() {
         for (hipGraphExec_t g : graph)
             if (g) (void)hipGraphExecDestroy(g);
@@ -333,9 +334,24 @@ static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC,
 }
 // Enqueues one whole proof on the slot's streams and returns without waiting.
 static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, bool raw) {
-    const char* eg = getenv("ZK_GRAPH");                   // read per proof (one getenv): tests switch it inside one process
+    const char* eg = ZK_FORM_ENV("ZK_GRAPH");              // cached; per proof only under ZK_TEST_FORMS=1 (tests switch it inside one process)
     const bool graphs = eg && atoi(eg) != 0;
     if (graphs && !ctx().profiling) {
+        // The captured launches freeze the kernel forms that were selected at capture time.  Outside test mode the form switches cannot change (they are
+        // cached); under ZK_TEST_FORMS=1 a slot's graphs are dropped whenever the switches differ from the ones they were captured under.
+        if (forms_live()) {
+            uint64_t h = 1469598103934665603ull;
+            for (const char* name : {"ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE"}) {
+                const char* v = getenv(name);
+                for (const char* q = v ? v : "\x01"; *q; q++) h = (h ^ (uint8_t)*q) * 1099511628211ull;
+                h = (h ^ 0xff) * 1099511628211ull;
+            }
+            if (h != sl.graph_forms) {
+                for (hipGraphExec_t& g : sl.graph)
+                    if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+                sl.graph_forms = h;
+            }
+        }
         // One hipGraph per slot and proof shape, captured from the very calls below the first time and replayed afterwards: a proof is ~60 stream
         // operations whose arguments never change (the slot owns every buffer; witness, r, s travel through its pinned staging memory).
         ZKCHK(stage_inputs(k, sl, sol, r, s));

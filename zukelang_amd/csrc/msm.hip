@@ -924,7 +924,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     static const uint32_t chunk_min = getenv("ZK_MSM_CHUNK_MIN") ? (uint32_t)atoi(getenv("ZK_MSM_CHUNK_MIN")) : 16;   // tuning knob
     if (launch_entries && chunk >= 64) {            // short chunks (small keys) already fill whole rounds: at 2^16, 2 rounds of 16-entry chunks beat 1 round of 32; 48 instead of 64 (the G2 product of a 2^20 key: one round of 208 instead of four of 52) measures the same
         // The caller knows how many sorted entries ONE accumulate launch carries (several products over these bases, e.g. Groth16's A and C):
-        // cut it into a WHOLE number of rounds of the chip's resident lanes (256 CUs x 4 SIMDs x 3 (G1) or 2 (G2) waves x 64 lanes, half as many
+        // cut it into a WHOLE number of rounds of the chip's resident lanes (256 CUs x 4 SIMDs x ACC_WAVES_G1 = ACC_WAVES_G2 = 2 waves x 64 lanes, half as many
         // chunks for the lane pairs of G2).  Every lane does the same number of additions, so a launch whose chunks fill 2.65 rounds costs three (2^20
         // constraints: 157 entries per chunk by the rule above; 208 makes it two rounds).
         const uint64_t round = b.curve == CURVE_G1 ? (uint64_t)256 * 4 * ACC_WAVES_G1 * 64 : (uint64_t)256 * 4 * ACC_WAVES_G2 * 64 / 2;
@@ -1168,10 +1168,10 @@ int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* 
     // bucket sums -> digit sums: on slots (msm_tail.hip) where the chain is latency-bound, one lane per point where the launch is throughput-bound
     // (msm_tail.cuh).  ZK_TAIL_SLOTS = 0 / 1 forces one form of the digit sums, ZK_TAIL_FIXUP_SLOTS = 1 puts the fix-up on slots (A/B runs, latency-first
     // deployments).  Digit sums -> product: always msm_tail.hip.
-    // (read per call, not cached: tests/test_gpu_msm.py flips them inside one process to hold every form to the oracle; three getenv per proof)
-    const char* e_sums = getenv("ZK_TAIL_SLOTS");
-    const char* e_fix = getenv("ZK_TAIL_FIXUP_SLOTS");
-    const char* e_chunk = getenv("ZK_FIXUP_BY_CHUNK");
+    // (cached; read per call only under ZK_TEST_FORMS=1, where the GPU suite flips them inside one process to hold every form to the oracle)
+    const char* e_sums = ZK_FORM_ENV("ZK_TAIL_SLOTS");
+    const char* e_fix = ZK_FORM_ENV("ZK_TAIL_FIXUP_SLOTS");
+    const char* e_chunk = ZK_FORM_ENV("ZK_FIXUP_BY_CHUNK");
     const int force = e_sums ? atoi(e_sums) : -1, force_fixup = e_fix ? atoi(e_fix) : -1;
     const bool sums_on_slots = force < 0 ? !wide : force != 0;
     if (force_fixup > 0) {                                 // default: lanes at every width (fewer instructions: +1.5 % proofs/s at 2^16, +0.8 % at 2^18; slots: -0.3 ms of a lone 2^18 proof)

@@ -103,8 +103,9 @@ template <class F> FF_INLINE void xyzz_madd_parked(F& ax, F& ay, ZPark<F>& pk, c
 // registers per lane in a kernel that sits at the register limit.
 // MMADD = true: the second step of a chunk uses the 6-product addition of two affine points (a second, 25 KB copy of the group law beside the
 // hot loop); false: every step is the general mixed addition -- less code in the instruction cache for 4 more products once per chunk.
-// Waves per SIMD the kernel is compiled for: the G1 table-reference kernel with the LDS-DMA look-ahead fits 168 registers without a spill
-// (ACC_WAVES_G1 = 3, msm.cuh: the host side cuts the chunks for rounds of that many resident waves); every other instantiation keeps two.
+// Waves per SIMD the kernel is compiled for (msm.cuh: ACC_WAVES_G1 = ACC_WAVES_G2 = 2; the host side cuts the chunks for rounds of that many resident
+// waves).  The G1 table-reference kernel with the LDS-DMA look-ahead would fit 168 registers = THREE waves without a spill; measured, it is no faster
+// alone or pipelined (msm.cuh), so every instantiation runs at two.
 template <class F, bool RAW, bool GLDS> struct AccWaves { static constexpr int N = (std::is_same<F, Fp>::value && !RAW && GLDS) ? (int)ACC_WAVES_G1 : (int)ACC_WAVES_G2; };
 template <class F, bool RAW, bool GLDS = false, bool MMADD = true>
 __global__ __launch_bounds__(128, (AccWaves<F, RAW, GLDS>::N)) void k_msm_accumulate(const uint8_t* __restrict__ table, AccJobs jobs, uint32_t nb, uint32_t chunk) {

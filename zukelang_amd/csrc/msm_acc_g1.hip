@@ -9,8 +9,8 @@
 
 namespace zk {
 int msm_accumulate_launch_g1(uint64_t nthreads, const void* table, const AccJobs& jobs, uint32_t count, uint32_t nb, uint32_t chunk, hipStream_t s) {
-    // ZK_ACC_G1_GLDS=0: the register look-ahead (A/B of the LDS-DMA look-ahead).  Read per launch: the GPU suite holds every form to the oracle in one process.
-    const char *eg = getenv("ZK_ACC_G1_GLDS"), *em = getenv("ZK_ACC_G1_MMADD");
+    // ZK_ACC_G1_GLDS=0: the register look-ahead (A/B of the LDS-DMA look-ahead).  Cached; per launch only under ZK_TEST_FORMS=1 (zk_common.h).
+    const char *eg = ZK_FORM_ENV("ZK_ACC_G1_GLDS"), *em = ZK_FORM_ENV("ZK_ACC_G1_MMADD");
     const bool glds = !(eg && atoi(eg) == 0);
     const bool mm = em && atoi(em) != 0;      // A/B: the 6-product second step (more code)
     if (glds && !mm) hipLaunchKernelGGL((k_msm_accumulate<Fp, false, true, false>), dim3((unsigned)((nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);

@@ -15,8 +15,8 @@ int msm_accumulate_launch(Curve curve, uint64_t nthreads, const void* table, con
         return ZK_OK;
     }
     if (curve == CURVE_G1) return msm_accumulate_launch_g1(nthreads, table, jobs, count, nb, chunk, s);
-    const char* ei = getenv("ZK_ACC_G2_INLINE");
-    const bool g2_inline = !(ei && atoi(ei) == 0);      // A/B switch, read per launch (tests)
+    const char* ei = ZK_FORM_ENV("ZK_ACC_G2_INLINE");
+    const bool g2_inline = !(ei && atoi(ei) == 0);      // A/B switch (cached; per launch only under ZK_TEST_FORMS=1)
     if (g2_inline) return msm_accumulate_launch_g2_inline(nthreads, table, jobs, count, nb, chunk, s);
     hipLaunchKernelGGL((k_msm_accumulate<Fp2H, false>), dim3((unsigned)((2 * nthreads + 127) / 128), count), dim3(128), 0, s, (const uint8_t*)table, jobs, nb, chunk);
     HIPCHK(hipGetLastError());

@@ -81,14 +81,18 @@ struct ScopedTimer {
 
 void profile_count(const char* name, uint64_t add);      // no-op unless profiling level 2 is on
 
-// Environment knobs are read ONCE per process (tuning switches; a getenv per launch is a libc lock + string scan on the proof's hot path).  The
-// exception: the handful of kernel-FORM switches of the MSM (msm.hip msm_reduce_mixed, msm_acc_g1/g2.hip, groth16.hip ZK_GRAPH), read per proof so that
-// the GPU tests can hold every form to the oracle inside one process.
-static inline const char* env_once(const char* name, const char** cache, bool* done) {
-    if (!*done) { *cache = getenv(name); *done = true; }
-    return *cache;
+// Environment knobs are read ONCE per process (tuning switches; a getenv per launch is a libc lock + string scan on the proof's hot path): a C++11
+// function-local static per call site, initialised thread-safely by the language.
+#define ZK_ENV(name) ([]() -> const char* { static const char* const v = getenv(name); return v; }())
+// The kernel-FORM switches of a proof (msm.hip msm_reduce_mixed: ZK_TAIL_SLOTS, ZK_TAIL_FIXUP_SLOTS, ZK_FIXUP_BY_CHUNK; msm_acc_g1/g2.hip:
+// ZK_ACC_G1_GLDS, ZK_ACC_G1_MMADD, ZK_ACC_G2_INLINE; groth16.hip: ZK_GRAPH) are cached like every other knob -- a proof costs no getenv at all --
+// unless the process was started with ZK_TEST_FORMS=1 (tests/conftest.py sets it): then they are read per call, so that the GPU suite can hold every
+// form to the oracle inside one process.  forms_live() is that one cached test-mode flag.
+static inline bool forms_live() {
+    static const bool live = [] { const char* e = getenv("ZK_TEST_FORMS"); return e && atoi(e) != 0; }();
+    return live;
 }
-#define ZK_ENV(name) ([]() -> const char* { static const char* v = nullptr; static bool d = false; return ::zk::env_once(name, &v, &d); }())
+#define ZK_FORM_ENV(name) (::zk::forms_live() ? (const char*)getenv(name) : ZK_ENV(name))
 
 static inline uint32_t ceil_log2(uint64_t x) {
     uint32_t l = 0;

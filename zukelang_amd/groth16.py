@@ -668,12 +668,19 @@ class GroupProver:
                     state["fr"] = self._launch_fr(rounds[ri + 1], bases[ri + 1])      # overlaps with this round's and the previous round's products
                 slot0 = half * self.batch
                 state["msm"].append((0, slot0))
+                worst = 0
                 for t in range(cnt):
                     k, owner = t // W, (base + t) % W
                     rv = rv_set[k]
-                    _lib.check(L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(slot0 + t), C.c_void_p(rv[0].data_ptr() + owner * self.len1),
-                                                              C.c_void_p(rv[1].data_ptr() + owner * self.len1), C.c_void_p(rv[2].data_ptr() + owner * self.len2)))
+                    # a launch failure only THIS rank sees (OOM, a HIP error in its slice) must not raise here alone: its peers would wait in the next
+                    # collective until it times out -- keep the code, stop launching, and let all ranks raise together below
+                    rc = L.zk_groth16_msm_partial_async(self.p.handle, C.c_uint32(slot0 + t), C.c_void_p(rv[0].data_ptr() + owner * self.len1),
+                                                        C.c_void_p(rv[1].data_ptr() + owner * self.len1), C.c_void_p(rv[2].data_ptr() + owner * self.len2))
+                    if rc != 0:
+                        worst = min(worst, rc)
+                        break
                     state["msm"][-1] = (t + 1, slot0)
+                self._raise_together(worst, "launching the products of this round")
                 self.rounds_done += 1
                 if pending is not None:
                     state["msm"].pop(0)             # collect waits for every slot of that round itself
