@@ -1,9 +1,12 @@
 /* The whole Groth16 prove path from a plain C99 host: upload the README circuit (`x*x*x + x + 3`, README.md:49) and its proving key in
  * the reference's layout (groth16.ml:24-34), prove (groth16.ml:235-237), derive the Lagrange form on the device, read the pools back,
  * prove again -- every output compared with the first-principles bytes of examples/readme_fixture.h (tests/golden/readme_groth16_key.json).
+ * With arguments -- HIP device indices, e.g. `c_prove 0 1` -- the SAME calls run on a multi-device key: zk_set_device_list shards the key over
+ * the listed devices behind the one handle (an index may repeat: `c_prove 0 0` puts two shards on one card, which is how a one-GPU box runs it).
  * Needs a GPU; tests/test_golden_key.py builds and runs it on the GPU box. */
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "readme_fixture.h"
@@ -17,7 +20,7 @@
 
 static void fr_small(uint8_t out[32], uint32_t v) { memset(out, 0, 32); out[0] = (uint8_t)v; }
 
-int main(void) {
+int main(int argc, char** argv) {
     /* gates (Gate.compare order): c4 = input*input ; c5 = c4*input ; v6 = (c5 + input + 3 ONE) * (1 ONE); variables ONE, c4, c5, input, v6 */
     static const uint32_t l_ptr[4] = {0, 1, 2, 5}, l_col[5] = {3, 1, 0, 2, 3};
     static const uint32_t r_ptr[4] = {0, 1, 2, 3}, r_col[3] = {3, 3, 0};
@@ -33,7 +36,13 @@ int main(void) {
     L.row_ptr = l_ptr; L.col = l_col; L.val = l_val;
     R.row_ptr = r_ptr; R.col = r_col; R.val = r_val;
     O.row_ptr = o_ptr; O.col = o_col; O.val = o_val;
-    CHECK(zk_init(0));
+    if (argc > 1) {          /* N GPUs behind the one handle: the only line an OCaml host adds */
+        int32_t devs[16];
+        uint32_t nd = 0;
+        for (i = 1; i < argc && nd < 16; i++) devs[nd++] = (int32_t)atoi(argv[i]);
+        CHECK(zk_set_device_list(devs, nd));
+    } else
+        CHECK(zk_init(0));
     CHECK(zk_groth16_pk_upload(3, 5, &L, &R, &O, FIX_MID, FIX_PK_G1, sizeof FIX_PK_G1 / 96, FIX_PK_G2, sizeof FIX_PK_G2 / 192, &h));
     CHECK(zk_groth16_prove(h, FIX_WITNESS, FIX_R, FIX_S, proof));
     if (memcmp(proof, FIX_PROOF, 384)) { fprintf(stderr, "proof from the uploaded key differs from the fixture\n"); return 2; }
@@ -46,6 +55,6 @@ int main(void) {
     CHECK(zk_groth16_prove(h, FIX_WITNESS, FIX_R, FIX_S, proof));
     if (memcmp(proof, FIX_PROOF, 384)) { fprintf(stderr, "proof from the derived key differs from the fixture\n"); return 5; }
     CHECK(zk_groth16_pk_free(h));
-    printf("c-prove ok: proofs from the uploaded and the derived key equal the first-principles fixture\n");
+    printf("c-prove ok (%d device entr%s): proofs from the uploaded and the derived key equal the first-principles fixture\n", argc > 1 ? argc - 1 : 1, argc > 2 ? "ies" : "y");
     return 0;
 }

@@ -14,8 +14,9 @@
  *
  * Ownership: all buffers are caller-owned; the library copies host->device and retains no host
  * pointer after return.  Long-lived device state sits behind uint64_t handles with explicit free.
- * Threading: calls are synchronous and blocking (the reference is single-threaded OCaml); one
- * process drives one GPU.
+ * Threading: calls are synchronous and blocking (the reference is single-threaded OCaml) and are made from ONE host thread.  One process drives
+ * one GPU by default; with a device list of several entries (zk_set_devices) the SAME single-threaded calls drive all of them: a key uploaded
+ * through zk_groth16_pk_upload is then sharded over the list behind one handle (see "multi-device keys" below).
  * Errors: 0 = ok, negative = the codes below (the reference raises exceptions; the shim maps
  * ZK_ERR_APPLY_POWERS -> Invalid_argument "apply_powers", ZK_ERR_REMAINDER / ZK_ERR_DOMAIN ->
  * Assert_failure, the rest -> Failure (zk_strerror)).
@@ -46,8 +47,28 @@ extern "C" {
 const char* zk_strerror(int code);
 const char* zk_last_error(void);       /* detail of the most recent failure in this process */
 int zk_device_count(void);             /* number of visible HIP devices (0 without a GPU) */
-int zk_init(int device);               /* bind this process to one GPU; idempotent */
+int zk_init(int device);               /* bind this process to one GPU (a device list of one entry); idempotent */
 int zk_shutdown(void);
+/* ---- multi-device keys: N GPUs of one node behind the handle `Groth16.Make(C).prove` holds (SURVEY.md 8b "zk_set_devices(mask)", 8e) -------------
+ * zk_set_devices(mask): bit d selects HIP device d; the library's device list becomes the selected devices in ascending order.
+ * zk_set_device_list: the general form -- `count` device indices in the order given.  An index may appear MORE THAN ONCE ("virtual devices": several
+ * shards of a key on one card, each with its own streams, tables and slots); that is how a one-GPU box exercises the multi-device path, it is never
+ * faster than the plain list.  Both may be called before anything else or whenever no key handle is alive (ZK_ERR_ARG otherwise); zk_init(d) afterwards
+ * succeeds iff d is the list's first entry.
+ * With a list of N > 1 entries:
+ *   - zk_groth16_pk_upload / _upload_lagrange shard the key over the list (slice g of both pools on entry g, cut by zk_groth16_shard_range for equal
+ *     work) and return ONE handle; zk_groth16_prove / _prove_async / _prove_wait / _set_witness / _reserve_slots / _pk_derive_lagrange / _qap_eval /
+ *     _pool_points / _pk_free work on it exactly as on a single-GPU key and produce the SAME bytes (groth16.ml:123-161: the proof does not depend on how
+ *     the sums are cut).  Per proof: the Fr stage (QAP.eval, QAP.ml:120-135) runs once, on the slot's owner device (slot mod N); every device copies
+ *     its slices of the three scalar vectors out of the owner's memory (hipMemcpyPeerAsync over xGMI), runs its part of the three multi-scalar
+ *     products and sends 768 bytes of partial sums to the first device, which adds them and emits the proof.  Nothing blocks before _prove_wait.
+ *   - zk_groth16_pk_derive_lagrange derives one of the three independent sets per device (devices 0, 1, 2 of the list) and installs every shard.
+ *   - everything else (zk_msm_*, zk_fr_*, keygen helpers, Pinocchio, the explicit one-process-per-GPU shard API below) runs on the list's FIRST
+ *     device; the shard API (zk_groth16_pk_upload_sharded, _prove_partial*, _scalars_async ...) refuses multi-device handles with ZK_ERR_ARG.
+ * The one-process-per-GPU path (torch.distributed / RCCL, bench.py --gpus N) does not use the device list: every rank keeps its one-entry list. */
+int zk_set_devices(uint64_t mask);
+int zk_set_device_list(const int32_t* devices, uint32_t count);
+int zk_get_device_list(int32_t* devices /* may be NULL */, uint32_t capacity, uint32_t* count);
 
 /* ---- Fr stage ---------------------------------------------------------------------------
  * FFT.Make(F).fft / ifft over Bls12_381.Fr -- src/lib/zk/FFT.ml:29-86,222-233:
@@ -279,8 +300,8 @@ int zk_profile_names(char* buf, size_t buflen);   /* comma-separated family name
 /* Work counters gathered at level 2 (one proof at a time) since the last reset, e.g. "msm_accumulate_g1:entries" (sorted (point, window) entries),
  * ":copies" (first entries of a chunk or run: no field product), ":second_steps" (6-product additions of two affine points), ":full_additions". */
 int zk_profile_counter(const char* name, uint64_t* value);
-int zk_sync(void);                                 /* waits for everything the library has enqueued on this device, the per-slot streams of
-                                                      proofs in flight included (hipDeviceSynchronize) */
+int zk_sync(void);                                 /* waits for everything the library has enqueued on every device of its list, the per-slot
+                                                      streams of proofs in flight included (hipDeviceSynchronize per device) */
 /* Throughput of the register-resident Montgomery multiplier (kind 0 = Fr, 1 = Fp): ALU ceiling.
  * kind | 4: one wave on the whole chip (dependent-chain latency).  kind | 8: the best rate over 2 / 4 / 6 / 8 waves per SIMD. */
 int zk_bench_field_mul(int kind, uint32_t iters, double* gmul_per_s);

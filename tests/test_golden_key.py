@@ -114,4 +114,9 @@ def test_a_plain_c_host_proves_the_fixture(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "examples"),
                            os.path.join(root, "examples", "c_prove.c"), "-o", exe, "-L" + libdir, "-lzkmi355x", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.startswith(b"c-prove ok"), (out.returncode, out.stdout, out.stderr)
+    assert out.returncode == 0 and out.stdout.startswith(b"c-prove ok (1 device entry)"), (out.returncode, out.stdout, out.stderr)
+    # the same binary with a device list: a multi-device key behind the one handle (zk_set_device_list; the one card of the test box listed twice and
+    # three times -- with several MI355X, `c_prove 0 1 2`), same calls, same first-principles bytes
+    for devs in (["0", "0"], ["0", "0", "0"]):
+        out = subprocess.run([exe] + devs, capture_output=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith(b"c-prove ok (%d device entries)" % len(devs)), (devs, out.returncode, out.stdout, out.stderr)

@@ -338,6 +338,66 @@ def test_device_resident_exchange_of_the_partial_sums(world, n):
         pr.close()
 
 
+def test_config4_as_stated_2pow22_constraints_point_sharded_eight_ways():
+    """BASELINE config 4 at its stated size (round-3 verdict, missing 2): ONE 2^22-constraint key, its two base pools point-sharded over EIGHT ranks
+    (eight sharded handles in this one process: the box has one card, RCCL needs one per rank; the window tables of all eight are ~35 GB of the 288),
+    the DISTRIBUTED Fr stage of bench.py --gpus 8 (the owner of a proof runs QAP.eval, QAP.ml:120-135, once and leaves the three scalar vectors over the
+    full pools in device memory; every rank multiplies its slice: zk_groth16_scalars_async / zk_groth16_msm_partial_async), the partial sums in the
+    [rank][proof][768] layout all_gather_into_tensor leaves, zk_groth16_combine_device.  Proof bytes = the trapdoor oracle's, i.e. independent of the
+    cut (groth16.ml:123-161); the slices every handle reports are zk_groth16_shard_range's equal-work cuts."""
+    import ctypes as C
+    from zukelang_amd import _lib
+    from zukelang_amd.groth16 import shard_bounds
+    L_ = _lib.lib()
+    world, n, nproofs = 8, 1 << 22, 2
+    cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0001)))
+    rng = seeded_rng(0x5EED0C04)
+    toxic = [rng() for _ in range(5)]
+    Lc, R_, Oo = csrs(cs)
+    e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, Lc, R_, Oo, cs.mid, frs(toxic))
+    pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
+    del e1, e2
+    p1, p2 = len(pk.g1) // 96, len(pk.g2) // 192
+    ranks = [Groth16(cs, pk, g, world) for g in range(world)]
+    bounds = []
+    for g, pr in enumerate(ranks):
+        v = [C.c_uint64() for _ in range(6)]
+        _lib.check(L_.zk_groth16_pool_layout(pr.handle, *[C.byref(x) for x in v]))
+        lo, hi = C.c_uint64(), C.c_uint64()
+        _lib.check(L_.zk_groth16_shard_range(C.c_uint64(p1), C.c_uint64(p2 + 1), C.c_uint32(g), C.c_uint32(world), C.byref(lo), C.byref(hi)))
+        assert (v[0].value, v[1].value) == (p1, p2) and (v[2].value, v[3].value) == (lo.value, hi.value) == shard_bounds(p1, g, world, p2 + 1)
+        assert (v[4].value, v[5].value) == shard_bounds(p2, g, world)
+        bounds.append((v[2].value, v[3].value, v[4].value, v[5].value))
+    # equal WORK: slice points + the part of the A prefix (a | d1 | b1 | tau basis = the first p2 + 1 points) inside the slice, within one point of each other
+    work = [(hi1 - lo1) + max(0, min(hi1, p2 + 1) - min(lo1, p2 + 1)) for lo1, hi1, _, _ in bounds]
+    assert max(work) - min(work) <= 2 and bounds[0][0] == 0 and bounds[-1][1] == p1 and bounds[-1][3] == p2
+    rs = [(rng(), rng()) for _ in range(nproofs)]
+    p8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    wb = RC.fr_bytes(w)
+    dA, dC, dB, gathered = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    for ptr, size in ((dA, 32 * p1), (dC, 32 * p1), (dB, 32 * p2), (gathered, world * nproofs * 768)):
+        _lib.check(L_.zk_device_malloc(C.c_size_t(size), C.byref(ptr)))
+    for t, (r, s) in enumerate(rs):
+        owner = ranks[(5 + t) % world]                                    # any rank may own a proof's Fr stage
+        rb, sb = RC.fr_bytes([r]), RC.fr_bytes([s])
+        _lib.check(L_.zk_groth16_scalars_async(owner.handle, p8(wb), p8(rb), p8(sb), C.c_uint32(0), dA, dC, dB))
+        _lib.check(L_.zk_groth16_scalars_wait(owner.handle, C.c_uint32(0)))
+        for g, pr in enumerate(ranks):                                    # the "exchange": rank g's slice of the owner's vectors (one process: an offset)
+            lo1, _, lo2, _ = bounds[g]
+            _lib.check(L_.zk_groth16_msm_partial_async(pr.handle, C.c_uint32(0), C.c_void_p(dA.value + 32 * lo1), C.c_void_p(dC.value + 32 * lo1), C.c_void_p(dB.value + 32 * lo2)))
+        for g, pr in enumerate(ranks):
+            _lib.check(L_.zk_groth16_prove_partial_wait_device(pr.handle, C.c_uint32(0), C.c_void_p(gathered.value + 768 * (nproofs * g + t))))
+    for t, (r, s) in enumerate(rs):
+        out = np.zeros(384, dtype=np.uint8)
+        _lib.check(L_.zk_groth16_combine_device(C.c_void_p(gathered.value + 768 * t), C.c_size_t(nproofs * 768), C.c_uint32(world), p8(out)))
+        exp = O.groth16_prove_trapdoor(cs.n, cs.m, Lc, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+        assert bytes(out) == b"".join(exp), "proof %d" % t
+    for ptr in (dA, dC, dB, gathered):
+        _lib.check(L_.zk_device_free(ptr))
+    for pr in ranks:
+        pr.close()
+
+
 def test_config3_window_sweep_is_parity_checked():
     """BASELINE config 3 (window-size sweep at 2^20 constraints) under parity: the proof must be the
     trapdoor oracle's bytes at every window width the sweep visits, not only at the default c = 16."""

@@ -13,8 +13,7 @@
 //   A: scalars (1, r, 0, v, 0, 0)          B: scalars (1, s, w)          C: scalars (s, rs, r, s v + r w, h, w|mid)
 // The G2 product runs on a second HIP stream beside the two G1 products.
 #include "ec.cuh"
-#include "frstage.cuh"
-#include "msm.cuh"
+#include "groth16_key.cuh"
 
 #include <map>
 #include <memory>
@@ -23,53 +22,9 @@
 
 namespace zk {
 
-// Everything one proof in flight owns: scratch of the Fr stage, the three scalar vectors, one MSM
-// workspace and one stream per product, pinned host landing buffers.  Several slots let the shallow
-// single-wave tails of one proof (bucket reduction, affine conversion) run under the bulk kernels
-// of the next.
-struct Slot {
-    FrScratch fs;
-    DevBuf scalA, scalC, scalB, wit_raw, rs, results, out_dev;
-    MsmWorkspace wsA, wsC, wsB;
-    hipStream_t s0 = nullptr, s1 = nullptr, s2 = nullptr;     // C + Fr stage | B (G2) | A
-    hipEvent_t fork = nullptr, join1 = nullptr, join2 = nullptr, done = nullptr;
-    uint8_t* host = nullptr;            // pinned: proof 384 B | flag 4 B | r 32 B | s 32 B
-    uint8_t* host_partial = nullptr;    // pinned: 768 B of raw partial sums (sharded mode)
-    uint8_t* wit_pinned = nullptr;      // pinned staging copy of a witness handed over as a host buffer (allocated at first use): the caller's
-                                        // buffer is read before the call returns, as the header promises, whatever memory it lives in
-    bool busy = false, serial = false;
-    // ZK_GRAPH=1: the whole proof of this slot captured ONCE per shape (streams forked or not | raw partial sums | witness from the host) and replayed
-    hipGraphExec_t graph[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint64_t graph_forms = 0;           // hash of the kernel-form switches the graphs were captured under (test mode only)
-    ~Slot() {
-        for (hipGraphExec_t g : graph)
-            if (g) (void)hipGraphExecDestroy(g);
-        if (s0) { (void)hipStreamDestroy(s0); if (!serial) { (void)hipStreamDestroy(s1); (void)hipStreamDestroy(s2); } }
-        if (fork) { (void)hipEventDestroy(fork); (void)hipEventDestroy(join1); (void)hipEventDestroy(join2); (void)hipEventDestroy(done); }
-        if (host) (void)hipHostFree(host);
-        if (wit_pinned) (void)hipHostFree(wit_pinned);
-    }
-};
-static constexpr uint32_t MAX_SLOTS = 15;      // + the context stream = the 16 hardware queues the chip runs side by side
-
-struct Groth16Key {
-    uint32_t n = 0, m = 0, n_mid = 0;
-    uint32_t rank = 0, world = 1;
-    uint64_t p1 = 0, p2 = 0;            // full pool sizes (points)
-    uint64_t lo1 = 0, hi1 = 0;          // this rank's slice of the G1 pool
-    uint64_t lo2 = 0, hi2 = 0;
-    FrStage fr;
-    MsmBases g1, g2;
-    DevBuf mid_idx;                     // variable index of the j-th mid variable
-    DevBuf wit_resident;                // zk_groth16_set_witness
-    bool have_witness = false;
-    bool lagrange = false;              // key holds [l_i(tau)] and the shifted-domain h bases instead of tau powers (row f4)
-    std::unique_ptr<Slot> slots[MAX_SLOTS];
-};
-
 static std::map<uint64_t, std::unique_ptr<Groth16Key>>& g_keys = *new std::map<uint64_t, std::unique_ptr<Groth16Key>>;   // never destroyed (see ntt.hip)
 static uint64_t g_next_handle = 1;
-static void handles_release() { g_keys.clear(); }
+static void handles_release() { group_release_all(); g_keys.clear(); }
 static CleanupRegistrar g_key_cleanup(handles_release);
 
 static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
@@ -111,13 +66,12 @@ __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __rest
     }
 }
 
-int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_t n_mid, const uint8_t* d_g2, uint8_t* out_g1, uint8_t* out_g2, uint32_t sets, hipStream_t s);   // lagrange_derive.hip
 
 // Contiguous slice [lo, hi) of a pool of `points` base points for `rank` of `world`, cut for equal WORK: the first `heavy` points of the G1
 // pool (a | d1 | b1 | the tau basis) carry two products of a proof, A and C (groth16.ml:128-134 vs :147-160), every other point one, so
 // the cuts sit at equal shares of points + heavy (with uniform cuts the first ranks of an 8-way split would do twice the G1 work of the
 // others).  heavy = 0: uniform.  The rule the host side mirrors (zukelang_amd/groth16.py: shard_bounds).
-static void shard_range(uint64_t points, uint64_t heavy, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
+void groth16_shard_range(uint64_t points, uint64_t heavy, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
     if (heavy > points) heavy = points;
     const uint64_t total = points + heavy;
     auto cut = [&](uint64_t g) -> uint64_t {
@@ -130,12 +84,15 @@ static void shard_range(uint64_t points, uint64_t heavy, uint32_t rank, uint32_t
 
 static int key_lookup(uint64_t handle, Groth16Key** out) {
     auto it = g_keys.find(handle);
-    if (it == g_keys.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Groth16 key handle");
+    if (it == g_keys.end()) {
+        if (group_lookup(handle)) ZK_FAIL(ZK_ERR_ARG, "multi-device key: this entry point serves the shards of the one-process-per-GPU path");
+        ZK_FAIL(ZK_ERR_HANDLE, "unknown Groth16 key handle");
+    }
     *out = it->second.get();
     return ZK_OK;
 }
 
-static int slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
+int groth16_slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
     if (idx >= MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "slot index out of range (max 15 proofs in flight)");
     if (!k.slots[idx]) {
         auto sl = std::make_unique<Slot>();
@@ -188,15 +145,15 @@ static uint32_t key_window(uint64_t g1_points) {
     if (getenv("ZK_MSM_WINDOW")) return 0;          // bases_setup reads it
     return g1_points >= ((uint64_t)1 << 21) ? 20 : msm_auto_window(g1_points, true);
 }
-static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
-                  const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank,
-                  uint32_t world, uint64_t* handle, bool lagrange = false) {
-    if (!handle || !mid || !pk_g1 || !pk_g2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: null argument");
+int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
+                      const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world, bool lagrange) {
+    if (!mid || !pk_g1 || !pk_g2 || !L || !R || !O) ZK_FAIL(ZK_ERR_ARG, "pk_upload: null argument");
     if (world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "pk_upload: bad rank / world");
     ZKCHK(ensure_init());
     Ctx& c = ctx();
     auto key = std::make_unique<Groth16Key>();
     Groth16Key& k = *key;
+    k.vdev = c.vdev;
     k.n = n; k.m = m; k.rank = rank; k.world = world;
     std::vector<uint32_t> mids;
     for (uint32_t i = 0; i < m; i++)
@@ -212,8 +169,8 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     ZKCHK(frstage_init(k.fr, n, m, L, R, O, c.stream));
     if (lagrange) ZKCHK(frstage_init_lagrange(k.fr, c.stream));
     // contiguous pool slices per rank
-    shard_range(k.p1, 3 + nt, rank, world, &k.lo1, &k.hi1);
-    shard_range(k.p2, 0, rank, world, &k.lo2, &k.hi2);
+    groth16_shard_range(k.p1, 3 + nt, rank, world, &k.lo1, &k.hi1);
+    groth16_shard_range(k.p2, 0, rank, world, &k.lo2, &k.hi2);
     if (k.hi1 == k.lo1 || k.hi2 == k.lo2) ZK_FAIL(ZK_ERR_ARG, "pk_upload: more ranks than key points");
     // ONE window width per key (both pools: their bucket reductions then go out as one chain of launches).  From 2^21 points
     // in this rank's G1 pool (n >= ~2^19.6 on one GPU) 20-bit windows: 13 instead of 16 digits per scalar pay for the 16x
@@ -230,16 +187,31 @@ static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, cons
     ZKCHK(k.wit_resident.alloc(32 * (size_t)m));
     HIPCHK(hipStreamSynchronize(c.stream));
     Slot* sl;
-    ZKCHK(slot_get(k, 0, &sl));
+    ZKCHK(groth16_slot_get(k, 0, &sl));
+    out = std::move(key);
+    return ZK_OK;
+}
+// A key uploaded WHOLE through zk_groth16_pk_upload[_lagrange] while the device list has several entries becomes a multi-device key: one shard per
+// entry behind one handle (groth16_multi.hip).  The explicit shard upload (rank of world: one process per GPU) always builds on the list's first device.
+static int upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
+                  const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank,
+                  uint32_t world, uint64_t* handle, bool lagrange = false, bool whole = false) {
+    if (!handle) ZK_FAIL(ZK_ERR_ARG, "pk_upload: null argument");
+    ZKCHK(ensure_init());
+    if (whole && ctx_count() > 1) return group_upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, lagrange, handle);
+    std::unique_ptr<Groth16Key> key;
+    ZKCHK(groth16_key_build(key, n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, rank, world, lagrange));
     *handle = g_next_handle++;
     g_keys[*handle] = std::move(key);
     return ZK_OK;
 }
+uint64_t pinocchio_live_handles();          // pinocchio.hip
+uint64_t live_key_handles() { return g_keys.size() + group_live_handles() + pinocchio_live_handles(); }
 
 // First half of a proof: Fr stage -> the three scalar vectors (canonical Fr, FULL pool lengths p1, p1, p2)
 // written to dA / dC / dB (device memory; the slot's own buffers in the single-call path).
 // The host half of scalars_enqueue: witness (when handed over as a host buffer) and r | s into the slot's pinned staging memory.
-static int stage_inputs(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s) {
+int groth16_stage_inputs(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s) {
     if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call the matching _wait first");
     if (sol) {
         if (!sl.wit_pinned) HIPCHK(hipHostMalloc((void**)&sl.wit_pinned, 32 * (size_t)k.m, hipHostMallocDefault));
@@ -250,8 +222,8 @@ static int stage_inputs(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8
     return ZK_OK;
 }
 // staged = true: stage_inputs has run (graph capture / replay: the stream operations below read the pinned staging memory when they EXECUTE)
-static int scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, void* dA, void* dC, void* dB, bool staged = false) {
-    if (!staged) ZKCHK(stage_inputs(k, sl, sol, r, s));
+int groth16_scalars_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s, void* dA, void* dC, void* dB, bool staged) {
+    if (!staged) ZKCHK(groth16_stage_inputs(k, sl, sol, r, s));
     const void* wit = k.wit_resident.p;
     if (sol) {
         HIPCHK(hipMemcpyAsync(sl.wit_raw.p, sl.wit_pinned, 32 * (size_t)k.m, hipMemcpyHostToDevice, sl.s0));
@@ -287,7 +259,7 @@ static bool runs_serial(Groth16Key& k, Slot& sl) {
             if (k.slots[i] && k.slots[i].get() != &sl && k.slots[i]->busy) serial = true;
     return serial;
 }
-static int msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC, const void* dB, bool raw, int force_serial = -1) {
+int groth16_msms_enqueue(Groth16Key& k, Slot& sl, const void* dA, const void* dC, const void* dB, bool raw, int force_serial) {
     const bool serial = force_serial < 0 ? runs_serial(k, sl) : force_serial != 0;
     char* res = sl.results.as<char>();
     char* out = sl.out_dev.as<char>();
@@ -354,14 +326,14 @@ static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint
         }
         // One hipGraph per slot and proof shape, captured from the very calls below the first time and replayed afterwards: a proof is ~60 stream
         // operations whose arguments never change (the slot owns every buffer; witness, r, s travel through its pinned staging memory).
-        ZKCHK(stage_inputs(k, sl, sol, r, s));
+        ZKCHK(groth16_stage_inputs(k, sl, sol, r, s));
         const bool serial = runs_serial(k, sl);
         hipGraphExec_t& ge = sl.graph[(serial ? 1 : 0) | (raw ? 2 : 0) | (sol ? 4 : 0)];
         if (!ge) {
             HIPCHK(hipStreamBeginCapture(sl.s0, hipStreamCaptureModeThreadLocal));
-            int rc = scalars_enqueue(k, sl, sol, r, s, sl.scalA.p, sl.scalC.p, sl.scalB.p, true);
+            int rc = groth16_scalars_enqueue(k, sl, sol, r, s, sl.scalA.p, sl.scalC.p, sl.scalB.p, true);
             if (rc == ZK_OK)
-                rc = msms_enqueue(k, sl, sl.scalA.as<char>() + 32 * k.lo1, sl.scalC.as<char>() + 32 * k.lo1, sl.scalB.as<char>() + 32 * k.lo2, raw, serial ? 1 : 0);
+                rc = groth16_msms_enqueue(k, sl, sl.scalA.as<char>() + 32 * k.lo1, sl.scalC.as<char>() + 32 * k.lo1, sl.scalB.as<char>() + 32 * k.lo2, raw, serial ? 1 : 0);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(sl.s0, &g);
             if (rc != ZK_OK) {
@@ -378,13 +350,13 @@ static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint
         sl.busy = true;
         return ZK_OK;
     }
-    ZKCHK(scalars_enqueue(k, sl, sol, r, s, sl.scalA.p, sl.scalC.p, sl.scalB.p));
-    ZKCHK(msms_enqueue(k, sl, sl.scalA.as<char>() + 32 * k.lo1, sl.scalC.as<char>() + 32 * k.lo1, sl.scalB.as<char>() + 32 * k.lo2, raw));
+    ZKCHK(groth16_scalars_enqueue(k, sl, sol, r, s, sl.scalA.p, sl.scalC.p, sl.scalB.p));
+    ZKCHK(groth16_msms_enqueue(k, sl, sl.scalA.as<char>() + 32 * k.lo1, sl.scalC.as<char>() + 32 * k.lo1, sl.scalB.as<char>() + 32 * k.lo2, raw));
     HIPCHK(hipEventRecord(sl.done, sl.s0));
     sl.busy = true;
     return ZK_OK;
 }
-static int prove_finish(Slot& sl) {
+int groth16_prove_finish(Slot& sl) {
     if (!sl.busy) ZK_FAIL(ZK_ERR_ARG, "no proof in flight on this slot");
     HIPCHK(hipEventSynchronize(sl.done));
     sl.busy = false;
@@ -402,7 +374,7 @@ extern "C" {
 
 int zk_groth16_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
                          const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
-    return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, handle);
+    return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, handle, false, true);
 }
 int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
                                  const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points,
@@ -411,7 +383,7 @@ int zk_groth16_pk_upload_sharded(uint32_t n, uint32_t m, const zk_csr* L, const 
 }
 int zk_groth16_pk_upload_lagrange(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
                                   const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
-    return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, handle, true);
+    return upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, handle, true, true);
 }
 // ---- derivation in two halves, so that the ranks of a node can share it (one set per rank, broadcast, install) -- and the single-call form on top
 static int derive_precheck(Groth16Key& k, const char* who) {
@@ -423,6 +395,7 @@ static int derive_precheck(Groth16Key& k, const char* who) {
 }
 // the Lagrange-form pool sizes of a key with n constraints: g1' = 3 + n + (n - 1) + n_mid points, g2' = 2 + n points
 int zk_groth16_lagrange_pool_sizes(uint64_t handle, uint64_t* g1_points, uint64_t* g2_points) {
+    if (GroupKey* g = group_lookup(handle)) return group_lagrange_pool_sizes(*g, g1_points, g2_points);
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (g1_points) *g1_points = 3 + (uint64_t)k->n + (k->n - 1) + k->n_mid;
@@ -448,21 +421,27 @@ int zk_groth16_pk_derive_lagrange_sets(uint64_t handle, uint32_t sets, void* d_g
     return ZK_OK;
 }
 int zk_groth16_pk_install_lagrange(uint64_t handle, const void* d_g1, const void* d_g2, uint32_t rank, uint32_t world) {
+    if (group_lookup(handle)) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_install_lagrange: multi-device keys derive and install in one call (zk_groth16_pk_derive_lagrange)");
     Groth16Key* kp;
     ZKCHK(key_lookup(handle, &kp));
     Groth16Key& k = *kp;
     if (!d_g1 || !d_g2 || world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_install_lagrange: bad argument");
     if (k.lagrange) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_install_lagrange: the key already holds Lagrange-form pools");
     ZKCHK(derive_precheck(k, "zk_groth16_pk_install_lagrange: a proof is in flight on this key"));
+    return groth16_install_lagrange(k, d_g1, d_g2, rank, world);
+}
+}  // extern "C"
+namespace zk {
+int groth16_install_lagrange(Groth16Key& k, const void* d_g1, const void* d_g2, uint32_t rank, uint32_t world) {
     Ctx& c = ctx();
     // Everything is built into TEMPORARIES first; the handle changes only after every allocation and launch has succeeded (an OOM while the new
     // window tables are built -- they are 13-16x the pools -- leaves the key exactly as it was: tau-power pools, tau-power Fr stage, lagrange = false).
     MsmBases g1, g2;
     const uint64_t p1n = 3 + (uint64_t)k.n + (k.n - 1) + k.n_mid, p2n = 2 + (uint64_t)k.n;
     uint64_t lo1, hi1, lo2, hi2;
-    shard_range(p1n, p2n + 1, rank, world, &lo1, &hi1);        // p2n + 1 = 3 + the n Lagrange points: the A prefix counts twice
-    shard_range(p2n, 0, rank, world, &lo2, &hi2);
-    if (hi1 == lo1 || hi2 == lo2) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_install_lagrange: more ranks than key points");
+    groth16_shard_range(p1n, p2n + 1, rank, world, &lo1, &hi1);        // p2n + 1 = 3 + the n Lagrange points: the A prefix counts twice
+    groth16_shard_range(p2n, 0, rank, world, &lo2, &hi2);
+    if (hi1 == lo1 || hi2 == lo2) ZK_FAIL(ZK_ERR_ARG, "install_lagrange: more ranks than key points");
     const uint32_t cw = key_window(hi1 - lo1);
     ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, (const uint8_t*)d_g1 + 96 * lo1, hi1 - lo1, cw, true, c.stream));
     ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, (const uint8_t*)d_g2 + 192 * lo2, hi2 - lo2, cw, true, c.stream));
@@ -477,10 +456,13 @@ int zk_groth16_pk_install_lagrange(uint64_t handle, const void* d_g1, const void
     k.rank = rank; k.world = world;
     k.p1 = p1n; k.p2 = p2n; k.lo1 = lo1; k.hi1 = hi1; k.lo2 = lo2; k.hi2 = hi2;
     Slot* sl;
-    ZKCHK(slot_get(k, 0, &sl));          // on failure the key is valid in Lagrange form; the slot is created at the next use
+    ZKCHK(groth16_slot_get(k, 0, &sl));          // on failure the key is valid in Lagrange form; the slot is created at the next use
     return ZK_OK;
 }
+}  // namespace zk
+extern "C" {
 int zk_groth16_pk_derive_lagrange(uint64_t handle) {
+    if (GroupKey* g = group_lookup(handle)) return group_derive_lagrange(*g);
     Groth16Key* kp;
     ZKCHK(key_lookup(handle, &kp));
     Groth16Key& k = *kp;
@@ -503,8 +485,8 @@ int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
     HIPCHK(hipDeviceSynchronize());
     Ctx& c = ctx();
     uint64_t lo1, hi1, lo2, hi2;
-    shard_range(k.p1, k.p2 + 1, rank, world, &lo1, &hi1);        // p2 + 1 = 3 + the tau basis
-    shard_range(k.p2, 0, rank, world, &lo2, &hi2);
+    groth16_shard_range(k.p1, k.p2 + 1, rank, world, &lo1, &hi1);        // p2 + 1 = 3 + the tau basis
+    groth16_shard_range(k.p2, 0, rank, world, &lo2, &hi2);
     if (hi1 == lo1 || hi2 == lo2) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pk_shard: more ranks than key points");
     for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();
     // window 0 of the resident tables is the pool in order: the rank keeps its contiguous slice and builds its own window tables
@@ -523,12 +505,20 @@ int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
     k.rank = rank; k.world = world;
     k.lo1 = lo1; k.hi1 = hi1; k.lo2 = lo2; k.hi2 = hi2;
     Slot* sl;
-    ZKCHK(slot_get(k, 0, &sl));
+    ZKCHK(groth16_slot_get(k, 0, &sl));
     return ZK_OK;
 }
 int zk_groth16_pool_points(uint64_t handle, int group, uint8_t* out, size_t capacity_points, size_t* count) {
+    if (GroupKey* g = group_lookup(handle)) return group_pool_points(*g, group, out, capacity_points, count);
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
+    return single_pool_points(*k, group, out, capacity_points, count);
+}
+}  // extern "C"
+namespace zk {
+// the key's resident pool slice (all of it for a key held whole) as uncompressed bytes, in pool order
+int single_pool_points(Groth16Key& key, int group, uint8_t* out, size_t capacity_points, size_t* count) {
+    Groth16Key* k = &key;
     if (group != 1 && group != 2) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_pool_points: group must be 1 or 2");
     const MsmBases& b = group == 1 ? k->g1 : k->g2;
     if (count) *count = b.n;
@@ -544,7 +534,10 @@ int zk_groth16_pool_points(uint64_t handle, int group, uint8_t* out, size_t capa
     HIPCHK(hipStreamSynchronize(c.stream));
     return ZK_OK;
 }
+}  // namespace zk
+extern "C" {
 int zk_groth16_pk_free(uint64_t handle) {
+    if (group_lookup(handle)) return group_free(handle);
     auto it = g_keys.find(handle);
     if (it == g_keys.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Groth16 key handle");
     (void)hipDeviceSynchronize();
@@ -552,31 +545,40 @@ int zk_groth16_pk_free(uint64_t handle) {
     return ZK_OK;
 }
 int zk_groth16_reserve_slots(uint64_t handle, uint32_t count) {
+    if (GroupKey* g = group_lookup(handle)) return group_reserve_slots(*g, count);
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (count > MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_reserve_slots: at most 15 slots");
     for (uint32_t i = 0; i < count; i++) {
         Slot* sl;
-        ZKCHK(slot_get(*k, i, &sl));
+        ZKCHK(groth16_slot_get(*k, i, &sl));
     }
     return ZK_OK;
 }
 int zk_groth16_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t r[32], const uint8_t s[32], uint32_t slot) {
+    if (GroupKey* g = group_lookup(handle)) {
+        if (!r || !s) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_async: null argument");
+        return group_prove_async(*g, sol, r, s, slot);
+    }
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (!r || !s) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_async: null argument");
     if (k->world != 1) ZK_FAIL(ZK_ERR_ARG, "key is sharded; use prove_partial + combine");
     Slot* sl;
-    ZKCHK(slot_get(*k, slot, &sl));
+    ZKCHK(groth16_slot_get(*k, slot, &sl));
     return prove_enqueue(*k, *sl, sol, r, s, false);
 }
 int zk_groth16_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[384]) {
+    if (GroupKey* g = group_lookup(handle)) {
+        if (!proof) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_wait: null proof");
+        return group_prove_wait(*g, slot, proof);
+    }
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (!proof) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_wait: null proof");
     if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_wait: slot never used");
     Slot& sl = *k->slots[slot];
-    ZKCHK(prove_finish(sl));
+    ZKCHK(groth16_prove_finish(sl));
     memcpy(proof, sl.host, 384);
     return ZK_OK;
 }
@@ -585,6 +587,7 @@ int zk_groth16_prove(uint64_t handle, const uint8_t* sol, const uint8_t r[32], c
     return zk_groth16_prove_wait(handle, 0, proof);
 }
 int zk_groth16_set_witness(uint64_t handle, const uint8_t* sol) {
+    if (GroupKey* g = group_lookup(handle)) return group_set_witness(*g, sol);
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_set_witness: null");
@@ -600,7 +603,7 @@ int zk_groth16_prove_partial_async(uint64_t handle, const uint8_t* sol, const ui
     ZKCHK(key_lookup(handle, &k));
     if (!r || !s) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_async: null argument");
     Slot* sl;
-    ZKCHK(slot_get(*k, slot, &sl));
+    ZKCHK(groth16_slot_get(*k, slot, &sl));
     ZKCHK(prove_enqueue(*k, *sl, sol, r, s, true));      // raw XYZZ partial sums: no affine conversion
     // the 768-byte partial block follows the proof on the slot's stream into pinned memory
     HIPCHK(hipMemcpyAsync(sl->host_partial, sl->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost, sl->s0));
@@ -613,7 +616,7 @@ int zk_groth16_prove_partial_wait(uint64_t handle, uint32_t slot, uint8_t partia
     if (!partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait: null");
     if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait: slot never used");
     Slot& sl = *k->slots[slot];
-    ZKCHK(prove_finish(sl));
+    ZKCHK(groth16_prove_finish(sl));
     memcpy(partial, sl.host_partial, ZK_GROTH16_PARTIAL_BYTES);
     return ZK_OK;
 }
@@ -623,7 +626,7 @@ int zk_groth16_prove_partial_wait_device(uint64_t handle, uint32_t slot, void* d
     if (!d_partial) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait_device: null");
     if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_prove_partial_wait_device: slot never used");
     Slot& sl = *k->slots[slot];
-    const int rc = prove_finish(sl);                     // the slot is free again whatever the Fr stage's flags say
+    const int rc = groth16_prove_finish(sl);                     // the slot is free again whatever the Fr stage's flags say
     // results = A | C | B raw XYZZ partial sums, device to device: the block never visits the host
     HIPCHK(hipMemcpyAsync(d_partial, sl.results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToDevice, sl.s0));
     HIPCHK(hipStreamSynchronize(sl.s0));
@@ -637,10 +640,21 @@ int zk_groth16_prove_partial(uint64_t handle, const uint8_t* sol, const uint8_t 
 // ---- distributed Fr stage: the two halves of a proof as separate calls on caller-owned device buffers
 int zk_groth16_shard_range(uint64_t points, uint64_t heavy_prefix, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
     if (!lo || !hi || world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_shard_range: bad argument");
-    shard_range(points, heavy_prefix, rank, world, lo, hi);
+    groth16_shard_range(points, heavy_prefix, rank, world, lo, hi);
     return ZK_OK;
 }
 int zk_groth16_pool_layout(uint64_t handle, uint64_t* p1, uint64_t* p2, uint64_t* lo1, uint64_t* hi1, uint64_t* lo2, uint64_t* hi2) {
+    if (GroupKey* g = group_lookup(handle)) {          // the handle holds the whole pools (its devices' slices are an internal matter)
+        uint64_t a = 0, b = 0;
+        ZKCHK(group_pool_layout(*g, &a, &b));
+        if (p1) *p1 = a;
+        if (p2) *p2 = b;
+        if (lo1) *lo1 = 0;
+        if (hi1) *hi1 = a;
+        if (lo2) *lo2 = 0;
+        if (hi2) *hi2 = b;
+        return ZK_OK;
+    }
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (p1) *p1 = k->p1;
@@ -657,8 +671,8 @@ int zk_groth16_scalars_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     ZKCHK(key_lookup(handle, &k));
     if (!r || !s || !d_scal_a || !d_scal_c || !d_scal_b) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_scalars_async: null argument");
     Slot* sl;
-    ZKCHK(slot_get(*k, slot, &sl));
-    ZKCHK(scalars_enqueue(*k, *sl, sol, r, s, d_scal_a, d_scal_c, d_scal_b));
+    ZKCHK(groth16_slot_get(*k, slot, &sl));
+    ZKCHK(groth16_scalars_enqueue(*k, *sl, sol, r, s, d_scal_a, d_scal_c, d_scal_b));
     HIPCHK(hipEventRecord(sl->done, sl->s0));
     sl->busy = true;
     return ZK_OK;
@@ -667,17 +681,17 @@ int zk_groth16_scalars_wait(uint64_t handle, uint32_t slot) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (slot >= MAX_SLOTS || !k->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_scalars_wait: slot never used");
-    return prove_finish(*k->slots[slot]);
+    return groth16_prove_finish(*k->slots[slot]);
 }
 int zk_groth16_msm_partial_async(uint64_t handle, uint32_t slot, const void* d_scal_a_slice, const void* d_scal_c_slice, const void* d_scal_b_slice) {
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
     if (!d_scal_a_slice || !d_scal_c_slice || !d_scal_b_slice) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_msm_partial_async: null argument");
     Slot* sl;
-    ZKCHK(slot_get(*k, slot, &sl));
+    ZKCHK(groth16_slot_get(*k, slot, &sl));
     if (sl->busy) ZK_FAIL(ZK_ERR_ARG, "slot still has work in flight: call the matching _wait first");
     memset(sl->host + 384, 0, 4);      // the remainder / range flags belong to the Fr stage, which ran elsewhere (zk_groth16_scalars_wait)
-    ZKCHK(msms_enqueue(*k, *sl, d_scal_a_slice, d_scal_c_slice, d_scal_b_slice, true));
+    ZKCHK(groth16_msms_enqueue(*k, *sl, d_scal_a_slice, d_scal_c_slice, d_scal_b_slice, true));
     HIPCHK(hipMemcpyAsync(sl->host_partial, sl->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost, sl->s0));
     HIPCHK(hipEventRecord(sl->done, sl->s0));
     sl->busy = true;
@@ -757,10 +771,17 @@ int zk_groth16_combine_device(const void* d_partials, size_t stride_bytes, uint3
     return combine_impl((const uint8_t*)d_partials, stride_bytes, world, proof, true);
 }
 int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out) {
+    if (GroupKey* g = group_lookup(handle)) return group_qap_eval(*g, sol, v_out, w_out, h_out);
     Groth16Key* k;
     ZKCHK(key_lookup(handle, &k));
+    return single_qap_eval(*k, sol, v_out, w_out, h_out);
+}
+}
+namespace zk {
+int single_qap_eval(Groth16Key& key, const uint8_t* sol, uint8_t* v_out, uint8_t* w_out, uint8_t* h_out) {
+    Groth16Key* k = &key;
     Slot* sl;
-    ZKCHK(slot_get(*k, 0, &sl));
+    ZKCHK(groth16_slot_get(*k, 0, &sl));
     if (sl->busy) ZK_FAIL(ZK_ERR_ARG, "zk_groth16_qap_eval: slot 0 has a proof in flight");
     const void* wit = k->wit_resident.p;
     if (sol) {
@@ -787,4 +808,4 @@ int zk_groth16_qap_eval(uint64_t handle, const uint8_t* sol, uint8_t* v_out, uin
     }
     return ZK_OK;
 }
-}
+}  // namespace zk

@@ -1222,12 +1222,11 @@ int xyzz_sum_columns(Curve curve, void* d_out, const void* d_parts, uint32_t cou
     return ZK_OK;
 }
 
-static DevBuf* const g_pow2 = new DevBuf[2];   // never destroyed (see ntt.hip)
-static void msm_release() { g_pow2[0].release(); g_pow2[1].release(); }
-static CleanupRegistrar g_msm_cleanup(msm_release);
+// the generator tables 2^k * G live in the context of the device they were built on (zk_common.h: CtxBufs) and die with it
 
 int fixed_base_mul(Curve curve, void* d_out, const void* d_scalars, uint64_t n, hipStream_t s) {
-    DevBuf& tab = g_pow2[curve];
+    if (!ctx().bufs) ZK_FAIL(ZK_ERR_HIP, "fixed_base_mul: no device context (zk_init)");
+    DevBuf& tab = ctx().bufs->pow2[curve];
     if (!tab.p) {
         ZKCHK(tab.alloc(aff_bytes(curve) * 256));
         if (curve == CURVE_G1) hipLaunchKernelGGL(k_gen_pow2_table<Fp>, dim3(4), dim3(64), 0, s, tab.as<uint8_t>());

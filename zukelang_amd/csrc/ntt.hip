@@ -188,12 +188,13 @@ __global__ void k_fr_to_factor(uint32_t* buf, uint64_t n) {
     fe_store<FrParams>(buf + 8 * i, fe_mul(fe_load<FrParams>(buf + 8 * i), fr_c32()));
 }
 
-// heap-allocated and never destroyed: static destructors must not call into a HIP runtime that is already gone
-static DevBuf &g_tw_fwd = *new DevBuf, &g_tw_inv = *new DevBuf, &g_inv_pow2 = *new DevBuf;
-
+// The twiddle tables live in the CONTEXT of the device they were generated on (zk_common.h: CtxBufs; contexts are heap-allocated and never destroyed
+// by static destructors, which must not call into a HIP runtime that is already gone).
 int ntt_ensure_twiddles(uint32_t log_n) {
     Ctx& c = ctx();
     if (log_n > 30) ZK_FAIL(ZK_ERR_ARG, "NTT size above 2^30 is not supported");
+    if (!c.bufs) ZK_FAIL(ZK_ERR_HIP, "ntt: no device context (zk_init)");
+    DevBuf &g_tw_fwd = c.bufs->tw_fwd, &g_tw_inv = c.bufs->tw_inv, &g_inv_pow2 = c.bufs->inv_pow2;
     if (!g_inv_pow2.p) {
         ZKCHK(g_inv_pow2.alloc(66 * 32));
         hipLaunchKernelGGL(k_gen_inv_pow2, dim3(1), dim3(64), 0, c.stream, g_inv_pow2.as<uint32_t>());
@@ -214,8 +215,7 @@ int ntt_ensure_twiddles(uint32_t log_n) {
     c.tw_log = k;
     return ZK_OK;
 }
-static void ntt_release() {
-    g_tw_fwd.release(); g_tw_inv.release(); g_inv_pow2.release();
+static void ntt_release() {          // zk_shutdown, once per context (current): the buffers themselves die with the context's CtxBufs
     ctx().tw_fwd = ctx().tw_inv = nullptr; ctx().tw_log = 0;
 }
 static CleanupRegistrar g_ntt_cleanup(ntt_release);
@@ -248,7 +248,7 @@ static int run_ntt(void* d, uint64_t total, uint32_t log_len, bool inverse, bool
     PassArgs last;
     plan(log_len, log_T, st, last);
     dim3 grid((unsigned)(total >> log_T));
-    const uint32_t* sc = scale ? g_inv_pow2.as<uint32_t>() + 8 * log_len : nullptr;
+    const uint32_t* sc = scale ? c.bufs->inv_pow2.as<uint32_t>() + 8 * log_len : nullptr;
     ScopedTimer t(inverse ? "ntt_inverse" : "ntt_forward", s);
     if (!inverse) {
         for (auto& p : st)
@@ -281,7 +281,7 @@ int ntt_mul_table(void* work, uint64_t total, uint32_t log_len, const void* tab,
     plan(log_len, log_T, st, last);
     if (st.empty() && (pad_src || add_dst)) ZK_FAIL(ZK_ERR_ARG, "ntt_mul_table: fused edges need a node larger than one tile");
     dim3 grid((unsigned)(total >> log_T));
-    const uint32_t* sc = scale ? g_inv_pow2.as<uint32_t>() + 8 * (log_len + (tab_is_data ? 33 : 0)) : nullptr;
+    const uint32_t* sc = scale ? c.bufs->inv_pow2.as<uint32_t>() + 8 * (log_len + (tab_is_data ? 33 : 0)) : nullptr;
     ScopedTimer t("ntt_mul_table", s);
     for (size_t i = 0; i < st.size(); i++) {
         PassIO io{};

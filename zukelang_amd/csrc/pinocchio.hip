@@ -67,6 +67,7 @@ int derive_shifted_bases_g1(const FrStage& f, const uint8_t* d_si, uint8_t* d_ou
 static std::map<uint64_t, std::unique_ptr<PinKey>>& g_pin = *new std::map<uint64_t, std::unique_ptr<PinKey>>;   // never destroyed (see ntt.hip)
 static uint64_t g_pin_next = 0x5000000001ull;
 static void pin_release() { g_pin.clear(); }
+uint64_t pinocchio_live_handles() { return g_pin.size(); }
 static CleanupRegistrar g_pin_cleanup(pin_release);
 
 static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }

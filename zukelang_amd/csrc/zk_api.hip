@@ -4,6 +4,7 @@
 #include "zk_common.h"
 
 #include <string.h>
+#include <mutex>
 
 #include <stdlib.h>
 
@@ -14,15 +15,49 @@ namespace zk {
 // default of 4 hardware queues serialises them (measured per 2^16 proof: 8.6 ms with 4, 7.0 ms with 16, 5.7-6.1 ms with 32).
 __attribute__((constructor)) static void zk_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
 
-Ctx& ctx() {
-    static Ctx* c = new Ctx;   // never destroyed: event / stream handles must not be touched at exit
-    return *c;
+// The device list and its contexts.  Contexts are heap-allocated and never destroyed (event / stream handles must not be touched at exit).
+static std::vector<Ctx*>& ctxs() {
+    static std::vector<Ctx*>* v = new std::vector<Ctx*>;
+    return *v;
 }
+static thread_local int tl_vdev = 0;
+Ctx& ctx() {
+    std::vector<Ctx*>& v = ctxs();
+    if (v.empty()) {
+        static Ctx* none = new Ctx;        // before zk_init: an un-initialised placeholder (profiling level, nothing else)
+        return *none;
+    }
+    return *v[(size_t)tl_vdev < v.size() ? tl_vdev : 0];
+}
+int ctx_count() { return (int)ctxs().size(); }
+Ctx& ctx_at(int vdev) { return *ctxs()[vdev]; }
+DeviceScope::DeviceScope(int vdev) : prev_vdev(tl_vdev), prev_dev(-1) {
+    (void)hipGetDevice(&prev_dev);
+    tl_vdev = vdev;
+    if (vdev < ctx_count() && ctx_at(vdev).device != prev_dev) (void)hipSetDevice(ctx_at(vdev).device);
+}
+DeviceScope::~DeviceScope() {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    tl_vdev = prev_vdev;
+    if (prev_dev >= 0 && cur != prev_dev) (void)hipSetDevice(prev_dev);
+}
+int copy_between(void* dst, int dst_vdev, const void* src, int src_vdev, size_t bytes, hipStream_t s) {
+    if (!bytes) return ZK_OK;
+    const int dd = ctx_at(dst_vdev).device, sd = ctx_at(src_vdev).device;
+    if (dd == sd) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    else HIPCHK(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, s));
+    return ZK_OK;
+}
+// the most recent failure of the process (any thread: the multi-device derivation runs one host thread per device)
+static std::mutex& err_mutex() { static std::mutex* m = new std::mutex; return *m; }
+static std::string& err_text() { static std::string* t = new std::string; return *t; }
 int set_error(int code, const char* what, const char* file, int line) {
     char buf[512];
     const char* base = strrchr(file, '/');
     snprintf(buf, sizeof buf, "%s (%s:%d)", what ? what : "", base ? base + 1 : file, line);
-    ctx().last_error = buf;
+    std::lock_guard<std::mutex> g(err_mutex());
+    err_text() = buf;
     return code;
 }
 std::vector<void (*)()>& cleanup_hooks() {
@@ -30,7 +65,7 @@ std::vector<void (*)()>& cleanup_hooks() {
     return h;
 }
 int ensure_init() {
-    if (ctx().inited) return ZK_OK;
+    if (ctx_count() > 0) return ZK_OK;
     return zk_init(0);
 }
 
@@ -182,7 +217,12 @@ const char* zk_strerror(int code) {
         default: return "unknown error";
     }
 }
-const char* zk_last_error(void) { return ctx().last_error.c_str(); }
+const char* zk_last_error(void) {
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(err_mutex());
+    copy = err_text();
+    return copy.c_str();
+}
 
 int zk_device_count(void) {
     int n = 0;
@@ -190,87 +230,181 @@ int zk_device_count(void) {
     return n;
 }
 
-int zk_init(int device) {
-    Ctx& c = ctx();
-    if (c.inited) {
-        if (c.device == device) return ZK_OK;
-        ZK_FAIL(ZK_ERR_ARG, "zk_init: already bound to another device (one process drives one GPU)");
-    }
+// The set-up half of zk_init / zk_set_device_list: one context per list entry.
+static int contexts_create(const int32_t* devices, uint32_t count) {
     int n = zk_device_count();
     if (n <= 0) ZK_FAIL(ZK_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback");
-    if (device < 0 || device >= n) ZK_FAIL(ZK_ERR_ARG, "zk_init: device index out of range");
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&c.ev_join3, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
-    c.device = device;
-    c.inited = true;
+    if (!devices || count == 0 || count > 64) ZK_FAIL(ZK_ERR_ARG, "device list: 1 .. 64 entries");
+    for (uint32_t i = 0; i < count; i++)
+        if (devices[i] < 0 || devices[i] >= n) ZK_FAIL(ZK_ERR_ARG, "device index out of range");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    std::vector<Ctx*> made;
+    auto fail = [&](int rc) {
+        for (Ctx* c : made) delete c;          // streams of a half-built list leak with the process; the list itself stays empty
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return rc;
+    };
+    for (uint32_t i = 0; i < count; i++) {
+        Ctx* c = new Ctx;
+        made.push_back(c);
+        c->vdev = (int)i;
+        c->device = devices[i];
+        c->bufs = new CtxBufs;
+        if (hipSetDevice(devices[i]) != hipSuccess) return fail(set_error(ZK_ERR_HIP, "hipSetDevice failed", __FILE__, __LINE__));
+        bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+        if (!ok) return fail(set_error(ZK_ERR_HIP, "creating the context's streams failed", __FILE__, __LINE__));
+        c->profiling = ctx().profiling;
+        c->inited = true;
+    }
+    // peer access between every pair of distinct HIP devices of the list: the slices of a proof's scalars and its partial sums then travel device to
+    // device over xGMI (hipMemcpyPeerAsync falls back to staging through the host where a pair has no peer link)
+    for (uint32_t i = 0; i < count; i++)
+        for (uint32_t j = 0; j < count; j++) {
+            if (devices[i] == devices[j]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                (void)hipSetDevice(devices[i]);
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                if (e != hipSuccess) (void)hipGetLastError();          // already enabled: fine
+            }
+        }
+    (void)hipSetDevice(devices[0]);          // the list's first device is the process's current device from here on (legacy single-device calls)
+    ctxs() = made;
+    tl_vdev = 0;
     return ZK_OK;
 }
 
+int zk_init(int device) {
+    if (ctx_count() > 0) {
+        if (ctx_at(0).device == device) return ZK_OK;
+        ZK_FAIL(ZK_ERR_ARG, "zk_init: already bound to another device (zk_set_devices / zk_set_device_list change the list)");
+    }
+    const int32_t d = device;
+    return contexts_create(&d, 1);
+}
+
 int zk_shutdown(void) {
-    Ctx& c = ctx();
-    if (!c.inited) return ZK_OK;
-    (void)hipDeviceSynchronize();
-    for (auto f : zk::cleanup_hooks()) f();
+    if (ctx_count() == 0) return ZK_OK;
+    for (int v = 0; v < ctx_count(); v++) {
+        DeviceScope ds(v);
+        (void)hipDeviceSynchronize();
+    }
     zk_profile_reset();
-    (void)hipEventDestroy(c.ev_fork);
-    (void)hipEventDestroy(c.ev_join);
-    (void)hipStreamDestroy(c.stream);
-    (void)hipStreamDestroy(c.stream2);
-    (void)hipStreamDestroy(c.stream3);
-    (void)hipEventDestroy(c.ev_join3);
-    c.inited = false;
-    c.device = -1;
+    for (int v = ctx_count() - 1; v >= 0; v--) {          // hooks see every context once, as the current one (keys are released by the first call)
+        DeviceScope ds(v);
+        for (auto f : zk::cleanup_hooks()) f();
+        Ctx& c = ctx_at(v);
+        for (hipEvent_t e : c.event_pool) (void)hipEventDestroy(e);
+        c.event_pool.clear();
+        (void)hipEventDestroy(c.ev_fork);
+        (void)hipEventDestroy(c.ev_join);
+        (void)hipStreamDestroy(c.stream);
+        (void)hipStreamDestroy(c.stream2);
+        (void)hipStreamDestroy(c.stream3);
+        (void)hipEventDestroy(c.ev_join3);
+        delete c.bufs;
+        c.bufs = nullptr;
+        c.inited = false;
+    }
+    const int level = ctx_at(0).profiling;
+    for (Ctx* c : ctxs()) delete c;
+    ctxs().clear();
+    tl_vdev = 0;
+    ctx().profiling = level;
+    return ZK_OK;
+}
+
+int zk_set_device_list(const int32_t* devices, uint32_t count) {
+    if (!devices || count == 0) ZK_FAIL(ZK_ERR_ARG, "zk_set_device_list: empty list");
+    if (ctx_count() == (int)count) {
+        bool same = true;
+        for (uint32_t i = 0; i < count; i++) same = same && ctx_at((int)i).device == devices[i];
+        if (same) return ZK_OK;
+    }
+    if (zk::live_key_handles() != 0) ZK_FAIL(ZK_ERR_ARG, "zk_set_device_list: free every key handle before changing the device list");
+    // a list that cannot be built must leave the current one in place: check it before the old contexts go
+    const int n = zk_device_count();
+    if (n <= 0) ZK_FAIL(ZK_ERR_HIP, "no HIP device visible: the MI355X path has no CPU fallback");
+    if (count > 64) ZK_FAIL(ZK_ERR_ARG, "device list: 1 .. 64 entries");
+    for (uint32_t i = 0; i < count; i++)
+        if (devices[i] < 0 || devices[i] >= n) ZK_FAIL(ZK_ERR_ARG, "device index out of range");
+    ZKCHK(zk_shutdown());
+    return contexts_create(devices, count);
+}
+int zk_set_devices(uint64_t mask) {
+    int32_t list[64];
+    uint32_t n = 0;
+    for (int d = 0; d < 64; d++)
+        if (mask >> d & 1) list[n++] = d;
+    if (n == 0) ZK_FAIL(ZK_ERR_ARG, "zk_set_devices: empty mask");
+    return zk_set_device_list(list, n);
+}
+int zk_get_device_list(int32_t* devices, uint32_t capacity, uint32_t* count) {
+    if (count) *count = (uint32_t)ctx_count();
+    if (!devices) return ZK_OK;
+    if (capacity < (uint32_t)ctx_count()) ZK_FAIL(ZK_ERR_ARG, "zk_get_device_list: buffer too small");
+    for (int v = 0; v < ctx_count(); v++) devices[v] = ctx_at(v).device;
     return ZK_OK;
 }
 
 int zk_sync(void) {
-    Ctx& c = ctx();
-    if (!c.inited) return ZK_OK;
-    // every stream of the process: the context streams AND the per-slot streams of every key (proofs in flight run on
+    // every stream of the process on every device of the list: the context streams AND the per-slot streams of every key (proofs in flight run on
     // hipStreamNonBlocking slot streams; zk_profile_get reads events recorded there)
-    HIPCHK(hipDeviceSynchronize());
+    for (int v = 0; v < ctx_count(); v++) {
+        bool seen = false;
+        for (int u = 0; u < v; u++) seen = seen || ctx_at(u).device == ctx_at(v).device;
+        if (seen) continue;
+        DeviceScope ds(v);
+        HIPCHK(hipDeviceSynchronize());
+    }
     return ZK_OK;
 }
 
 int zk_profile_enable(int on) {
-    ctx().profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
+    const int level = on < 0 ? 0 : (on > 2 ? 2 : on);
+    ctx().profiling = level;
+    for (int v = 0; v < ctx_count(); v++) ctx_at(v).profiling = level;
     return ZK_OK;
 }
 int zk_profile_reset(void) {
-    Ctx& c = ctx();
-    for (auto& t : c.timers)
-        for (auto& sp : t.spans) {
-            c.event_pool.push_back(sp.first);
-            c.event_pool.push_back(sp.second);
-        }
-    c.timers.clear();
-    c.counters.clear();
+    for (int v = 0; v < ctx_count(); v++) {
+        Ctx& c = ctx_at(v);
+        for (auto& t : c.timers)
+            for (auto& sp : t.spans) {
+                c.event_pool.push_back(sp.first);
+                c.event_pool.push_back(sp.second);
+            }
+        c.timers.clear();
+        c.counters.clear();
+    }
     return ZK_OK;
 }
 int zk_profile_counter(const char* name, uint64_t* value) {
     if (!name || !value) ZK_FAIL(ZK_ERR_ARG, "zk_profile_counter: null");
     *value = 0;
-    for (auto& kv : ctx().counters)
-        if (kv.first == name) *value = kv.second;
+    for (int v = 0; v < ctx_count(); v++)
+        for (auto& kv : ctx_at(v).counters)
+            if (kv.first == name) *value += kv.second;
     return ZK_OK;
 }
 int zk_profile_get(const char* family, double* total_ms, uint64_t* launches) {
-    Ctx& c = ctx();
+    if (!family) ZK_FAIL(ZK_ERR_ARG, "zk_profile_get: null");
     ZKCHK(zk_sync());
     double tot = 0;
     uint64_t cnt = 0;
-    for (auto& t : c.timers) {
-        if (t.name != family) continue;
-        for (auto& sp : t.spans) {
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, sp.first, sp.second));
-            tot += ms;
-            cnt++;
+    for (int v = 0; v < ctx_count(); v++) {
+        DeviceScope ds(v);
+        for (auto& t : ctx_at(v).timers) {
+            if (t.name != family) continue;
+            for (auto& sp : t.spans) {
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, sp.first, sp.second));
+                tot += ms;
+                cnt++;
+            }
         }
     }
     if (total_ms) *total_ms = tot;
@@ -279,10 +413,12 @@ int zk_profile_get(const char* family, double* total_ms, uint64_t* launches) {
 }
 int zk_profile_names(char* buf, size_t buflen) {
     std::string s;
-    for (auto& t : ctx().timers) {
-        if (!s.empty()) s += ",";
-        s += t.name;
-    }
+    for (int v = 0; v < ctx_count(); v++)
+        for (auto& t : ctx_at(v).timers) {
+            if (("," + s + ",").find("," + t.name + ",") != std::string::npos) continue;
+            if (!s.empty()) s += ",";
+            s += t.name;
+        }
     if (!buf || buflen <= s.size()) ZK_FAIL(ZK_ERR_ARG, "zk_profile_names: buffer too small");
     memcpy(buf, s.c_str(), s.size() + 1);
     return ZK_OK;

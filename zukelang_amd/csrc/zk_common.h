@@ -17,9 +17,14 @@ struct KernelTimer {      // HIP-event timing of one named kernel family, live i
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
 };
 
+// One context per VIRTUAL device of the library's device list (zk_set_devices / zk_set_device_list; a process that never calls them has the
+// one-entry list zk_init made).  A virtual device is an index into that list; the list may name a HIP device more than once (several shards of a
+// multi-device key on one card: how a one-GPU box exercises the multi-device path).  Streams, twiddles, generator tables, event pools and timers are per
+// context; keys are bound to the context they were built under.
 struct Ctx {
     bool inited = false;
-    int device = -1;
+    int vdev = 0;                      // index into the device list
+    int device = -1;                   // HIP device of this context
     hipStream_t stream = nullptr;      // main stream (G1 work, Fr stage)
     hipStream_t stream2 = nullptr;     // G2 MSM
     hipStream_t stream3 = nullptr;     // second G1 MSM: the shallow single-wave tails of one product overlap the bulk of another
@@ -28,16 +33,30 @@ struct Ctx {
     void* tw_fwd = nullptr;
     void* tw_inv = nullptr;
     uint32_t tw_log = 0;
-    int profiling = 0;                 // 0 off, 1 = the dominant (accumulate) kernels only, 2 = every family
+    struct CtxBufs* bufs = nullptr;    // device tables owned by this context (ntt.hip twiddles, msm.hip generator tables): CtxBufs below
+    int profiling = 0;                 // 0 off, 1 = the dominant (accumulate) kernels only, 2 = every family (the same level on every context)
     std::vector<hipEvent_t> event_pool; // recycled events: hipEventCreate costs tens of microseconds
     std::vector<KernelTimer> timers;
     std::vector<std::pair<std::string, uint64_t>> counters;   // work counters collected with profiling level 2 (zk_profile_counter)
-    std::string last_error;
 };
-Ctx& ctx();
+Ctx& ctx();                              // the context of the calling thread's CURRENT virtual device (0 unless a DeviceScope is open)
+int ctx_count();                         // entries of the device list (0 before zk_init / zk_set_devices)
+Ctx& ctx_at(int vdev);
+// Makes virtual device `vdev` current for the calling thread (hipSetDevice + the library's own index) until the scope closes.
+struct DeviceScope {
+    int prev_vdev, prev_dev;
+    explicit DeviceScope(int vdev);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
 int ensure_init();
-std::vector<void (*)()>& cleanup_hooks();   // run by zk_shutdown before the streams die
+uint64_t live_key_handles();             // Groth16 + Pinocchio key handles alive (groth16.hip / pinocchio.hip): the device list may only change at 0
+std::vector<void (*)()>& cleanup_hooks();   // run by zk_shutdown once per context (that context current), before its streams die
 struct CleanupRegistrar { explicit CleanupRegistrar(void (*f)()) { cleanup_hooks().push_back(f); } };
+// device -> device copy between two virtual devices on `s` (a stream of the DESTINATION's context): hipMemcpyPeerAsync over xGMI when the HIP devices
+// differ, a plain device copy when both shards sit on one card
+int copy_between(void* dst, int dst_vdev, const void* src, int src_vdev, size_t bytes, hipStream_t s);
 
 #define HIPCHK(expr)                                                                      \
     do {                                                                                  \
@@ -68,6 +87,12 @@ struct DevBuf {
     }
     void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// per-context device tables (released by the owning translation unit's cleanup hook)
+struct CtxBufs {
+    DevBuf tw_fwd, tw_inv, inv_pow2;      // ntt.hip
+    DevBuf pow2[2];                       // msm.hip: 2^k * generator, both curves (fixed_base_mul)
 };
 
 // Scoped kernel-family timer (no-op unless profiling is on)
