@@ -27,20 +27,18 @@ namespace zk {
 static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
 template <class T> struct LaneCount { static constexpr uint32_t N = RawLayout<T>::LANES; };
 
-// ---- scalar (canonical Fr, 8 words in memory) times point, complete formulas (identity, equal operands).  Fixed 4-bit windows: the
-// multiples 1 P .. 15 P go to a per-lane table in device memory (7 doublings + 7 additions), then every window costs 4 doublings + ONE
-// addition of the looked-up multiple per sub-scalar (with per-lane scalars the conditional addition of a bitwise ladder would run in nearly
-// every step of a wave).  Round-2 history: bitwise 5 600 field products per multiplication, one 255-bit scalar in 64 windows 3 300
-// (4.2 s / 15.8 s / 77 s at 2^16 / 2^18 / 2^20 for a key's three sets), split through the endomorphisms 2 300 on G1 and 1 700 Fp2
-// products on G2 (2.7 s / 9.5 s / 45 s).
+// ---- scalar (canonical Fr, 8 words in memory) times point, complete formulas (identity, equal operands).
+// History of the per-multiplication cost (field products; a key's three sets at 2^16 / 2^18 / 2^20): bitwise ladder 5 600; one 255-bit scalar in 64
+// fixed 4-bit windows over a per-lane table of 1 P .. 15 P in device memory 3 300 (4.2 s / 15.8 s / 77 s); split through the endomorphisms 2 300 on G1,
+// 1 700 Fp2 products on G2 (2.7 s / 9.5 s / 45 s, round 2; 41 s at 2^20 in round 3); Jacobian accumulator + affine table + signed windows (round 4, below)
+// ~-16 % instructions: 34 s at 2^20, 160 s at 2^22.
 // The scalar is split through the curve's endomorphisms (Gallant-Lambert-Vanstone on G1, Galbraith-Lin-Scott on G2): the doublings are
-// what a 255-bit scalar costs (256 x 9 of 3 300 field products), and they are shared between the sub-scalars of
+// what a 255-bit scalar costs, and they are shared between the sub-scalars of
 //   G1:  k = q z^2 + t  =>  k P = (t + q) P + q phi(P),   phi(x, y) = (beta x, y) = [z^2 - 1] (x, y)          2 scalars of <= 129 bits
 //   G2:  k = sum_i k_i |z|^i  =>  k P = sum_i (-1)^i k_i psi^i(P),   psi(x, y) = (cx conj x, cy conj y) = [z] (x, y)      4 scalars of 64 bits
-// (z = -0xd201000000010000; r = z^4 - z^2 + 1, p = z mod r).  ONE table of the multiples 1 P .. 15 P as before; the image of an entry under
-// phi / psi^i costs one / two products by constants (scripts/gen_endo_consts.py derives and CHECKS them against first-principles
-// arithmetic).  132 doublings + ~62 additions on G1, 64 + ~60 on G2.  The split is a bitwise long division per lane (~600 steps of a few
-// integer instructions: the cost of a handful of field products).
+// (z = -0xd201000000010000; r = z^4 - z^2 + 1, p = z mod r).  ONE table of multiples of P; the image of an entry under phi / psi^i costs one / two
+// products by constants (scripts/gen_endo_consts.py derives and CHECKS them against first-principles arithmetic).  The split is a bitwise long
+// division per lane (~600 steps of a few integer instructions: the cost of a handful of field products).
 FF_INLINE void glv_split_g1(const uint32_t* __restrict__ k, uint32_t a[5], uint32_t b[4]) {
     const uint64_t d0 = (uint64_t)ENDO_Z2[0] | ((uint64_t)ENDO_Z2[1] << 32), d1 = (uint64_t)ENDO_Z2[2] | ((uint64_t)ENDO_Z2[3] << 32);
     uint64_t r0 = 0, r1 = 0;
@@ -108,96 +106,239 @@ FF_INLINE FpB<1> endo_limbs(const uint32_t* __restrict__ c) {
     for (int i = 0; i < FPL; i++) r.v[i] = c[i];
     return r;
 }
-// the table entry under phi
-FF_INLINE void endo_apply_g1(Xyzz<Fp>& q) { q.x = Fp(fe_mul(q.x, endo_limbs(ENDO_BETA))); }
-// the table entry under (-1)^i psi^i, i = 1..3 (lane pair: this lane holds component pair_comp() of every coordinate)
-FF_INLINE void endo_apply_g2(Xyzz<Fp2H>& q, int i) {
+// ---- round 4: the scalar multiplication itself.  Every butterfly of the transforms in the exponent is ONE of these, and the kernels already run at
+// ~90 % of the chip's field-multiplier rate (29 M G1 multiplications/s x 2 300 products): only fewer products per multiplication make the derivation
+// shorter.  Three changes, same group elements:
+//   * the accumulator is JACOBIAN (X, Y, Z) instead of XYZZ: a doubling is 3 M + 4 S (6.1 product-equivalents) instead of 4 M + 3 S + a fused
+//     double product (7.8) -- and doublings are what a 129-bit half-scalar is made of;
+//   * the window table is AFFINE: the multiples 1 P .. 8 P are built in Jacobian coordinates (4 doublings + 3 general additions), their Z are inverted
+//     together (Montgomery's trick: 21 products + ONE lockstep inversion, ~64 product-equivalents, fp_inv.cuh) and every window addition is a MIXED
+//     one -- 8 M + 3 S instead of the 12 M + 2 S of two projective points;
+//   * SIGNED 4-bit windows: k + 0x88..8 read nibble by nibble gives digits m - 8 in [-8, 7], so eight table entries serve sixteen digit values (the
+//     table costs half as much to build and to invert) and -P is a conditional negation of y.
+// Per G1 multiplication ~1 630 products instead of ~2 300; per G2 multiplication (lane pairs: a product 1.5, a square 1.0) ~1 800 instead of ~2 330.
+template <class T> struct Jac {
+    T x, y, z;          // z = 0: the identity (x, y arbitrary field elements)
+};
+// dbl-2009-l for a = 0 with 8 Y^4 taken as 2 (2 Y^2)^2 (keeps every bound inside the at-rest type for the lane-pair field too).  Complete: the
+// identity (Z = 0) and a point of order two (Y = 0) both give Z3 = 0.
+template <class T> FF_INLINE Jac<T> jac_dbl(const Jac<T>& p) {
+    const auto A = fe_sqr(p.x);
+    const auto B2 = fe_dbl(fe_sqr(p.y));                      // 2 Y^2
+    const auto C8 = fe_dbl(fe_sqr(B2));                       // 8 Y^4
+    const auto D = fe_dbl(fe_mul(p.x, B2));                   // 4 X Y^2
+    const auto E = fe_add(fe_dbl(A), A);                      // 3 X^2
+    const auto X3 = fe_sub(fe_sqr(E), fe_dbl(D));
+    const auto Y3 = fe_sub(fe_mul(E, fe_sub(D, X3)), C8);
+    const auto Z3 = fe_dbl(fe_mul(p.y, p.z));
+    return {T(X3), T(Y3), T(Z3)};
+}
+// acc += (qx, qy), an AFFINE point that is not the identity (madd-2004-hmv shape: 8 M + 3 S).  Complete: identity accumulator, equal and opposite points.
+template <class T, class QX, class QY> FF_INLINE void jac_madd(Jac<T>& acc, const QX& qx, const QY& qy) {
+    if (fe_is_zero(acc.z)) {
+        acc = {T(qx), T(qy), T(FieldOps<T>::one())};
+        return;
+    }
+    const auto Z2 = fe_sqr(acc.z);
+    const auto U2 = fe_mul(qx, Z2);
+    const auto S2 = fe_mul(fe_mul(qy, acc.z), Z2);
+    const auto H = fe_sub(U2, acc.x);
+    const auto R = fe_sub(S2, acc.y);
+    if (fe_is_zero(H)) {                                      // same x: the same point (double it) or its negative (identity)
+        if (fe_is_zero(R)) acc = jac_dbl(acc);
+        else acc.z = T(FieldOps<T>::zero());
+        return;
+    }
+    const auto HH = fe_sqr(H);
+    const auto HHH = fe_mul(H, HH);
+    const auto V = fe_mul(acc.x, HH);
+    const auto X3 = fe_sub_sub_dbl(fe_sqr(R), HHH, V);        // R^2 - H^3 - 2 V
+    const auto Y3 = fe_mul_sub(R, fe_sub(V, X3), acc.y, HHH);
+    acc.z = T(fe_mul(acc.z, H));
+    acc.x = T(X3);
+    acc.y = T(Y3);
+}
+// acc += q, both Jacobian (the three general additions of the table build: 12 M + 4 S).  Complete.
+template <class T> FF_INLINE void jac_add(Jac<T>& acc, const Jac<T>& q) {
+    if (fe_is_zero(q.z)) return;
+    if (fe_is_zero(acc.z)) {
+        acc = q;
+        return;
+    }
+    const auto Z1Z1 = fe_sqr(acc.z), Z2Z2 = fe_sqr(q.z);
+    const auto U1 = fe_mul(acc.x, Z2Z2), U2 = fe_mul(q.x, Z1Z1);
+    const auto S1 = fe_mul(fe_mul(acc.y, q.z), Z2Z2), S2 = fe_mul(fe_mul(q.y, acc.z), Z1Z1);
+    const auto H = fe_sub(U2, U1);
+    const auto R = fe_sub(S2, S1);
+    if (fe_is_zero(H)) {
+        if (fe_is_zero(R)) acc = jac_dbl(acc);
+        else acc.z = T(FieldOps<T>::zero());
+        return;
+    }
+    const auto HH = fe_sqr(H);
+    const auto HHH = fe_mul(H, HH);
+    const auto V = fe_mul(U1, HH);
+    const auto X3 = fe_sub_sub_dbl(fe_sqr(R), HHH, V);
+    const auto Y3 = fe_mul_sub(R, fe_sub(V, X3), S1, HHH);
+    acc.z = T(fe_mul(fe_mul(acc.z, q.z), H));
+    acc.x = T(X3);
+    acc.y = T(Y3);
+}
+// Per-multiplication scratch (one lane for G1, one lane PAIR for G2; 16 XYZZ points = 64 raw field elements were reserved per multiplication):
+//   [0, 16 E)   the affine table: entry d = 1..8 as x | y at (d - 1) * 2 E
+//   [16 E, 40 E) the Jacobian multiples d P as x | y | z at 16 E + (d - 1) * 3 E, while the table is being built
+//   [40 E, 48 E) the running products Z_1 .. Z_1 Z_2 .. Z_d of the shared inversion
+template <class T> struct TabLayout {
+    static constexpr int E = RawLayout<T>::ELEM;
+    static constexpr int AFF = 0, JAC = 16 * E, PRE = 40 * E;
+    static_assert(48 * E <= 16 * RawLayout<T>::XYZZ, "window-table scratch outgrew its reservation");
+};
+template <class T> FF_INLINE T ld_raw(const uint8_t* p) { return load_raw_f((const T*)nullptr, p); }
+// the multiples 1 P .. 8 P of a point that is NOT the identity, as affine points in the lane's scratch
+template <class T> FF_INLINE void window_table_affine(const Xyzz<T>& p, uint8_t* __restrict__ tab) {
+    using L = TabLayout<T>;
+    constexpr int E = L::E;
+    uint8_t* jac = tab + L::JAC;
+    uint8_t* pre = tab + L::PRE;
+    auto put = [&](uint32_t d, const Jac<T>& q) {
+        store_raw_f(jac + (d - 1) * 3 * E, q.x);
+        store_raw_f(jac + (d - 1) * 3 * E + E, q.y);
+        store_raw_f(jac + (d - 1) * 3 * E + 2 * E, q.z);
+    };
+    auto get = [&](uint32_t d) -> Jac<T> { return {ld_raw<T>(jac + (d - 1) * 3 * E), ld_raw<T>(jac + (d - 1) * 3 * E + E), ld_raw<T>(jac + (d - 1) * 3 * E + 2 * E)}; };
+    // (X, Y, ZZ, ZZZ) is the Jacobian point (X ZZ, Y ZZZ, ZZ): x = X ZZ / ZZ^2, y = Y ZZZ / ZZ^3 with ZZ^3 = ZZZ^2
+    const Jac<T> p1{T(fe_mul(p.x, p.zz)), T(fe_mul(p.y, p.zzz)), p.zz};
+    put(1, p1);
+#pragma unroll 1
+    for (uint32_t d = 2; d <= 8; d++) {
+        Jac<T> q;
+        if (d & 1) {
+            q = get(d - 1);
+            jac_add(q, p1);
+        } else {
+            q = jac_dbl(get(d >> 1));
+        }
+        put(d, q);
+    }
+    // running products of the Z, one inversion, back substitution: zi = 1 / Z_d
+    {
+        T run = ld_raw<T>(jac + 2 * E);
+        store_raw_f(pre, run);
+#pragma unroll 1
+        for (uint32_t d = 2; d <= 8; d++) {
+            run = T(fe_mul(run, ld_raw<T>(jac + (d - 1) * 3 * E + 2 * E)));
+            store_raw_f(pre + (d - 1) * E, run);
+        }
+        T inv = T(fe_inv_fast(run));
+#pragma unroll 1
+        for (uint32_t d = 8; d >= 1; d--) {
+            const T z = ld_raw<T>(jac + (d - 1) * 3 * E + 2 * E);
+            T zi = inv;
+            if (d > 1) {
+                zi = T(fe_mul(inv, ld_raw<T>(pre + (d - 2) * E)));
+                inv = T(fe_mul(inv, z));
+            }
+            const auto zi2 = fe_sqr(zi);
+            const auto x = fe_mul(ld_raw<T>(jac + (d - 1) * 3 * E), zi2);
+            const auto y = fe_mul(fe_mul(ld_raw<T>(jac + (d - 1) * 3 * E + E), zi), zi2);
+            store_raw_f(tab + L::AFF + (d - 1) * 2 * E, T(x));
+            store_raw_f(tab + L::AFF + (d - 1) * 2 * E + E, T(y));
+        }
+    }
+}
+// -P as a conditional negation of y (both branches in one type)
+FF_INLINE FpB<4> cond_neg(bool neg, const FpB<2>& y) { return fp_select(neg, FpB<4>(y), FpB<4>(fe_neg(y))); }
+FF_INLINE Fp2HB<4> cond_neg(bool neg, const Fp2HB<2>& y) { return {cond_neg(neg, y.v)}; }
+template <class T> FF_INLINE Xyzz<T> jac_to_xyzz(const Jac<T>& a) {
+    const auto zz = fe_sqr(a.z);
+    return {a.x, a.y, T(zz), T(fe_mul(a.z, zz))};
+}
+FF_INLINE Xyzz<Fp> xyzz_mul_scalar_endo(const Xyzz<Fp>& p, const uint32_t* __restrict__ k, uint8_t* __restrict__ tab) {
+    using L = TabLayout<Fp>;
+    constexpr int E = L::E;
+    if (xyzz_is_inf(p)) return xyzz_inf<Fp>();
+    window_table_affine<Fp>(p, tab);
+    uint32_t a[5], b[5];
+    glv_split_g1(k, a, b);
+    b[4] = 0;
+    {   // signed digits: nibble w of k + 0x8..8 (33 nibbles) minus 8
+        uint64_t ca = 0, cb = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint32_t add = i < 4 ? 0x88888888u : 0x8u;
+            ca += (uint64_t)a[i] + add;
+            a[i] = (uint32_t)ca;
+            ca >>= 32;
+            cb += (uint64_t)b[i] + add;
+            b[i] = (uint32_t)cb;
+            cb >>= 32;
+        }
+    }
+    Jac<Fp> acc;
+    acc.x = acc.y = acc.z = Fp(fp_zero());
+#pragma unroll 1
+    for (int w = 32; w >= 0; w--) {
+        if (w != 32) {
+#pragma unroll 1
+            for (int r = 0; r < 4; r++) acc = jac_dbl(acc);
+        }
+        const int da = (int)((a[w >> 3] >> ((w & 7) * 4)) & 15u) - 8, db = (int)((b[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
+        if (da) {
+            const uint8_t* e = tab + L::AFF + ((da < 0 ? -da : da) - 1) * 2 * E;
+            const FpB<2> x = fp_assume<2>(ld_raw<Fp>(e)), y = fp_assume<2>(ld_raw<Fp>(e + E));
+            jac_madd(acc, x, cond_neg(da < 0, y));
+        }
+        if (db) {                                             // the same entry under phi: (beta x, y)
+            const uint8_t* e = tab + L::AFF + ((db < 0 ? -db : db) - 1) * 2 * E;
+            const FpB<2> x = fe_mul(fp_assume<2>(ld_raw<Fp>(e)), endo_limbs(ENDO_BETA)), y = fp_assume<2>(ld_raw<Fp>(e + E));
+            jac_madd(acc, x, cond_neg(db < 0, y));
+        }
+    }
+    return jac_to_xyzz(acc);
+}
+// the affine table entry under (-1)^i psi^i, i = 1..3 (lane pair: this lane holds component pair_comp() of each coordinate)
+FF_INLINE void endo_apply_g2_aff(Fp2HB<2>& x, Fp2HB<2>& y, int i) {
     const uint32_t comp = pair_comp();
     const bool flip = (i & 1) && comp;                   // conj^i negates the c1 component for odd i
     const Fp2HB<1> cx{endo_limbs(ENDO_PSI_X[i - 1][comp])}, cy{endo_limbs(ENDO_PSI_Y[i - 1][comp])};
-    auto conj = [&](const Fp2H& a) -> Fp2HB<128> {
-        const FpB<128> n = fe_neg(a.v), p = a.v;
-        return {fp_select(flip, p, n)};
-    };
-    q.x = Fp2H(fe_mul(conj(q.x), cx));
-    q.y = Fp2H(fe_mul(conj(q.y), cy));
-    if (i & 1) {
-        q.zz = Fp2H(fp_canon(conj(q.zz).v));
-        q.zzz = Fp2H(fp_canon(conj(q.zzz).v));
-    }
-}
-template <class T> FF_INLINE void window_table(const Xyzz<T>& p, uint8_t* __restrict__ tab) {
-    constexpr int XB = RawLayout<T>::XYZZ;
-    xyzz_store_raw<T>(tab + XB * 1, p);
-    for (uint32_t d = 2; d < 16; d++) {
-        Xyzz<T> q;
-        if (d & 1) {
-            q = xyzz_load_raw<T>(tab + XB * (d - 1));
-            xyzz_add_impl(q, p);
-        } else {
-            q = xyzz_dbl_impl(xyzz_load_raw<T>(tab + XB * (d >> 1)));
-        }
-        xyzz_store_raw<T>(tab + XB * d, q);
-    }
-}
-FF_INLINE Xyzz<Fp> xyzz_mul_scalar_endo(const Xyzz<Fp>& p, const uint32_t* __restrict__ k, uint8_t* __restrict__ tab) {
-    constexpr int XB = RawLayout<Fp>::XYZZ;
-    window_table<Fp>(p, tab);
-    uint32_t a[5], b[4];
-    glv_split_g1(k, a, b);
-    Xyzz<Fp> acc = xyzz_inf<Fp>();
-    bool started = false;
-#pragma unroll 1
-    for (int w = 32; w >= 0; w--) {
-        const uint32_t da = (a[w >> 3] >> ((w & 7) * 4)) & 15u, db = w < 32 ? (b[w >> 3] >> ((w & 7) * 4)) & 15u : 0u;
-        if (!started) {
-            if (__ballot((da | db) != 0) == 0) continue;          // wave-uniform leading zero windows
-        } else {
-#pragma unroll 1
-            for (int r = 0; r < 4; r++) acc = xyzz_dbl_impl(acc);
-        }
-        started = true;
-        if (da) {
-            const Xyzz<Fp> q = xyzz_load_raw<Fp>(tab + XB * da);
-            xyzz_add_impl(acc, q);
-        }
-        if (db) {
-            Xyzz<Fp> q = xyzz_load_raw<Fp>(tab + XB * db);
-            endo_apply_g1(q);
-            xyzz_add_impl(acc, q);
-        }
-    }
-    return acc;
+    auto conj = [&](const Fp2HB<2>& a) -> Fp2HB<4> { return {fp_select(flip, FpB<4>(a.v), FpB<4>(fe_neg(a.v)))}; };
+    x = fe_mul(conj(x), cx);
+    y = fe_mul(conj(y), cy);
 }
 FF_INLINE Xyzz<Fp2H> xyzz_mul_scalar_endo(const Xyzz<Fp2H>& p, const uint32_t* __restrict__ k, uint8_t* __restrict__ tab) {
-    constexpr int XB = RawLayout<Fp2H>::XYZZ;
-    window_table<Fp2H>(p, tab);
+    using L = TabLayout<Fp2H>;
+    constexpr int E = L::E;
+    if (xyzz_is_inf(p)) return xyzz_inf<Fp2H>();
+    window_table_affine<Fp2H>(p, tab);
     uint64_t d[4];
     gls_split_g2(k, d);
-    Xyzz<Fp2H> acc = xyzz_inf<Fp2H>();
-    bool started = false;
-#pragma unroll 1
-    for (int w = 15; w >= 0; w--) {
-        uint32_t dg[4];
+    uint32_t top = 0;                                         // nibble 16 of d[i] + 0x8..8 (17 nibbles), 4 bits per sub-scalar
 #pragma unroll
-        for (int i = 0; i < 4; i++) dg[i] = (uint32_t)(d[i] >> (4 * w)) & 15u;
-        if (!started) {
-            if (__ballot((dg[0] | dg[1] | dg[2] | dg[3]) != 0) == 0) continue;
-        } else {
+    for (int i = 0; i < 4; i++) {
+        const uint64_t lo = d[i] + 0x8888888888888888ull;
+        top |= (8u + (lo < d[i] ? 1u : 0u)) << (4 * i);
+        d[i] = lo;
+    }
+    Jac<Fp2H> acc;
+    acc.x = acc.y = acc.z = Fp2H(fp_zero());
 #pragma unroll 1
-            for (int r = 0; r < 4; r++) acc = xyzz_dbl_impl(acc);
+    for (int w = 16; w >= 0; w--) {
+        if (w != 16) {
+#pragma unroll 1
+            for (int r = 0; r < 4; r++) acc = jac_dbl(acc);
         }
-        started = true;
 #pragma unroll 1
         for (int i = 0; i < 4; i++) {
-            if (dg[i]) {                                          // pair-uniform: both lanes of a pair hold the same scalar
-                Xyzz<Fp2H> q = xyzz_load_raw<Fp2H>(tab + XB * dg[i]);
-                if (i) endo_apply_g2(q, i);
-                xyzz_add_impl(acc, q);
+            const int dg = (int)(w == 16 ? (top >> (4 * i)) & 15u : (uint32_t)(d[i] >> (4 * w)) & 15u) - 8;
+            if (dg) {                                          // pair-uniform: both lanes of a pair hold the same scalar
+                const uint8_t* e = tab + L::AFF + ((dg < 0 ? -dg : dg) - 1) * 2 * E;
+                Fp2HB<2> x = fp_assume<2>(ld_raw<Fp2H>(e)), y = fp_assume<2>(ld_raw<Fp2H>(e + E));
+                if (i) endo_apply_g2_aff(x, y, i);
+                jac_madd(acc, x, cond_neg(dg < 0, y));
             }
         }
     }
-    return acc;
+    return jac_to_xyzz(acc);
 }
 FF_INLINE Fp neg_coord(const Fp& y) { return Fp(fp_canon(fe_neg(y))); }
 FF_INLINE Fp2H neg_coord(const Fp2H& y) { return Fp2H(fp_canon(fe_neg(y).v)); }
