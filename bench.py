@@ -36,6 +36,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # before torch / HIP initiali
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+T_START = time.perf_counter()
 PROFILE_ROUND = "r04"
 
 
@@ -129,7 +130,7 @@ def pmc_traffic():
     return None
 
 
-def cpu_baseline(budget_s=45.0):
+def cpu_baseline(budget_s=20.0):
     """The oracle's LITERAL restatement of groth16.ml:116-161 + QAP.ml:120-135 (per-variable apply_powers = m*n single double-and-add
     scalar multiplications, schoolbook mul / div_rem) on ONE host core, at the ladder of sizes BASELINE.md 3.2 names -- n = 16, 64, 256 (and
     1024 when the fitted model says it fits the budget) -- with the fitted cost model t(n) = a * m * n + b * n^2 and what that model says about
@@ -140,7 +141,7 @@ def cpu_baseline(budget_s=45.0):
     from zukelang_amd.groth16 import Groth16, PKey
     frs = lambda xs: bytes(RC.fr_bytes(xs))
     ladder, spent = [], 0.0
-    sizes = [16, 64, 256, 1024]
+    sizes = [16, 64, 128, 256, 1024]          # the default budget stops after n = 128 (~0.16 + 2.5 + 10 s of one core): "about 10-30 s of CPU work"
     for n in sizes:
         if ladder:          # predicted from the last point with the O(m n) law (m = n + 2): skip what does not fit
             n0, t0 = ladder[-1]["n"], ladder[-1]["seconds"]
@@ -420,6 +421,12 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     # the key as uploaded first, then derives (untimed, reported as derive_lagrange_s) and measures again: `value` is the second figure,
     # `tau_power_form` keeps the first.
     derive = derive_upto is not None and log_n <= derive_upto and world == 1 and not lagrange
+    if derive and not args.derived_only and args.time_budget > 0:
+        est = 36.0 * n / (1 << 20) * (1.08 if log_n > 20 else 1.0) + 12.0 * n / (1 << 22)          # derivation + the second measurement and its parity check
+        spent = time.perf_counter() - T_START
+        if spent + est > args.time_budget:
+            print("bench.py: %.0f s spent, the 2^%d derivation (~%.0f s) does not fit --time-budget %.0f: this workload reports the key as uploaded only" % (spent, log_n, est, args.time_budget), file=sys.stderr)
+            derive = False
     power_form = None
     if derive and args.derived_only:
         # profiling runs: only the path the headline runs (no tau-power pass whose kernels would mix into the kernel statistics)
@@ -651,7 +658,7 @@ def compact_line(full):
                      "constraints": cfg.get("constraints"), "key_form": key_form, "tau_power_value": tpf.get("value"),
                      "derive_lagrange_s": cfg.get("derive_lagrange_s"), "break_even_proofs": tpf.get("break_even_proofs"),
                      "proofs_in_flight": cfg.get("proofs_in_flight"), "proofs_per_step": cfg.get("proofs_per_step"),
-                     "sharding": (cfg.get("sharding") or "")[:160], "rehearsal_ranks_share_gpus": cfg.get("rehearsal_ranks_share_gpus"),
+                     "sharding": (cfg.get("sharding") or "")[:160], "rehearsal_ranks_share_gpus": cfg.get("rehearsal_ranks_share_gpus"), "device_list": cfg.get("device_list"),
                      "prove_algorithmic_bytes_per_constraint": cfg.get("prove_algorithmic_bytes_per_constraint"), "prove_hbm_frac": cfg.get("prove_hbm_frac")}
     out["ms_per_proof"] = full.get("ms_per_proof")
     out["single_proof_latency_ms"] = full.get("single_proof_latency_ms")
@@ -723,16 +730,19 @@ def main():
     ap.add_argument("--no-pinocchio", action="store_true", help="skip the Pinocchio 2^18 workload (config 5) of the default run")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs): same as --sizes '' --no-pinocchio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-budget", type=float, default=45.0, help="seconds of one host core the literal-algorithm ladder of cpu_baseline may take (n = 16, 64, 256, 1024 while the fitted O(m n) law says the next size fits)")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=20.0, help="seconds of one host core the literal-algorithm ladder of cpu_baseline may take (n = 16, 64, 128, 256, 1024 while the fitted O(m n) law says the next size fits; "
+                    "45 reaches n = 256 as rounds 2-3 did)")
     ap.add_argument("--cpu-fast-upto", type=int, default=20, help="workloads of at most 2^K constraints that hold Lagrange-form pools also run ONE proof on the multi-threaded CPU "
                     "prover of oracle/fast_cpu.c (context figure `cpu_fast_context`, BASELINE.md 3.3; ~0.5 s at 2^16, ~3 s at 2^18, ~12 s at 2^20 on 16 threads); -1 = never")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the oracle comparison of the last timed proof (profiling runs only)")
     ap.add_argument("--no-live-events", action="store_true", help="do not bracket the accumulate kernels with HIP events inside the timed region")
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
                     "not the reference's key format -- the default and the headline use the tau-power key)")
-    ap.add_argument("--derive-lagrange-upto", type=int, default=20, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
-                    "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.7 s at 2^16, 9.5 s at 2^18, 45 s at 2^20, 3.6 min at 2^22) and "
+    ap.add_argument("--derive-lagrange-upto", type=int, default=22, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
+                    "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.3 s at 2^16, 7.3 s at 2^18, 34 s at 2^20, 160 s at 2^22) and "
                     "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
+    ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock the whole run aims to stay within: a derivation whose estimate (34 s x n / 2^20) does not fit what is left "
+                    "is skipped and that workload reports its tau-power figure only (the default run is ~5 min with the 160 s derivation of the 2^22 key)")
     ap.add_argument("--host-witness", action="store_true", help="one GPU: hand the witness over as a host buffer with every proof (the PCIe-inclusive rate of DESIGN.md 8) instead of "
                     "proving from the copy made resident by zk_groth16_set_witness; never the headline")
     ap.add_argument("--derived-only", action="store_true", help="profiling runs: derive the key's Lagrange form right after the upload and measure only that path "
@@ -740,6 +750,9 @@ def main():
     ap.add_argument("--tau-power-key", action="store_true", help="N > 1: keep the key in tau-power form (sharded at upload) instead of deriving the Lagrange form on every rank")
     ap.add_argument("--replicated-fr", action="store_true", help="N > 1: every rank runs the Fr stage of every proof (one collective per proof: the all-gather of the 768-byte "
                     "partial sums) instead of the default, the owner's Fr stage + an all-to-all of scalar slices (GroupProver)")
+    ap.add_argument("--device-list", default="", help="ONE process, N devices behind one key handle (the path an OCaml host takes: zk_set_device_list, csrc/groth16_multi.hip): "
+                    "comma-separated HIP device indices, e.g. 0,1,2,3,4,5,6,7; an index may repeat (several shards on one card: a rehearsal, never faster).  "
+                    "Not the driver's --gpus N contract (that is one process per GPU over RCCL); n_gpus in the line = distinct devices of the list")
     ap.add_argument("--settle", type=float, default=4.0, help="max seconds of untimed load before timing so the clocks leave the idle state (0 = off)")
     ap.add_argument("--inflight", type=int, default=14, help="proofs kept in flight on one GPU, one stream each (1 = strictly serial)")
     args = ap.parse_args()
@@ -777,7 +790,13 @@ def main():
 
     from zukelang_amd import _lib
     L = _lib.lib()
-    _lib.check(L.zk_init(local_rank))
+    dev_list = [int(t) for t in args.device_list.split(",") if t.strip()]
+    if dev_list:
+        if world > 1:
+            raise SystemExit("--device-list is the ONE-process multi-device path; --gpus N starts one process per GPU")
+        _lib.set_device_list(dev_list)          # every key uploaded from here on is sharded over the list behind one handle
+    else:
+        _lib.check(L.zk_init(local_rank))
 
     head = bench_groth16(args, L, _lib, args.log_n, args.steps, args.warmup, args.inflight, args.settle, rank, world, dist,
                          lagrange=args.lagrange_key, replicated_fr=args.replicated_fr, events=not args.no_live_events,
@@ -788,26 +807,30 @@ def main():
     head_pub, roofs = summarize(head, world, peak.value, traffic, args.lagrange_key)
 
     others = []
-    if world == 1 and rank == 0 and not args.headline_only:
-        for tok in [t for t in args.sizes.split(",") if t.strip()]:
-            ln = int(tok)
-            if ln == args.log_n:
-                continue
-            per = {16: 320, 18: 80, 20: 24, 22: 8}.get(ln, max(8, int(0.6 / (2e-3 * (1 << max(0, ln - 16))))))       # proofs for >= 0.5 s at last round's rates
-            infl = args.inflight if ln <= 20 else 4
-            steps = max(1, (per + args.proofs_per_step - 1) // args.proofs_per_step)
-            r = bench_groth16(args, L, _lib, ln, steps, 1 if ln <= 18 else 0, infl, args.settle if ln <= 18 else min(args.settle, 2.0), 0, 1, None,
-                              lagrange=args.lagrange_key, events=not args.no_live_events,
-                              derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
-            pub, _ = summarize(r, 1, peak.value, traffic, args.lagrange_key)
-            pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {16: "2", 20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
-            others.append(pub)
-        if not args.no_pinocchio:
-            others.append(bench_pinocchio(args, L, _lib, 18, 48, 8, peak.value))
 
+    def other_size(ln):
+        per = {16: 320, 18: 80, 20: 24, 22: 8}.get(ln, max(8, int(0.6 / (2e-3 * (1 << max(0, ln - 16))))))       # proofs for >= 0.5 s at last round's rates
+        infl = args.inflight if ln <= 20 else 4
+        steps = max(1, (per + args.proofs_per_step - 1) // args.proofs_per_step)
+        r = bench_groth16(args, L, _lib, ln, steps, 1 if ln <= 18 else 0, infl, args.settle if ln <= 18 else min(args.settle, 2.0), 0, 1, None,
+                          lagrange=args.lagrange_key, events=not args.no_live_events,
+                          derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
+        pub, _ = summarize(r, 1, peak.value, traffic, args.lagrange_key)
+        pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {16: "2", 20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
+        others.append(pub)
+
+    # order: the short workloads, Pinocchio, the CPU ladder -- and the sizes above 2^20 LAST, so that the wall-clock guard of their (minutes-long)
+    # derivation sees everything else already spent (--time-budget)
+    sizes = [int(t) for t in args.sizes.split(",") if t.strip() and int(t) != args.log_n] if world == 1 and rank == 0 and not args.headline_only else []
+    for ln in [x for x in sizes if x <= 20]:
+        other_size(ln)
+    if world == 1 and rank == 0 and not args.headline_only and not args.no_pinocchio:
+        others.append(bench_pinocchio(args, L, _lib, 18, 48, 8, peak.value))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_baseline_budget)
+    for ln in [x for x in sizes if x > 20]:
+        other_size(ln)
 
     if rank == 0:
         # the dominant kernel = the accumulate family with the larger UN-OVERLAPPED time per proof (one proof in flight); N > 1: the
@@ -830,7 +853,7 @@ def main():
             "metric": "Groth16 constraints/sec on BLS12-381 at 1/2/4/8 MI355X; proof bit-exact",
             "value": head["value"],
             "unit": "constraints/s",
-            "n_gpus": world,
+            "n_gpus": len(set(dev_list)) if dev_list else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"],
@@ -851,11 +874,14 @@ def main():
                                     if head["group_batch"] is not None else
                                     ("MSM base points over ranks; every rank derived the key's Lagrange form (derive_lagrange_s) and runs the three-convolution Fr stage replicated; "
                                      "all-gather of 768 B partial sums + local EC reduce" if head.get("derive_lagrange_s") is not None else
-                                     "MSM base points over ranks, Fr stage replicated; all-gather of 768 B partial sums + local EC reduce")) if world > 1 else "single GPU",
+                                     "MSM base points over ranks, Fr stage replicated; all-gather of 768 B partial sums + local EC reduce")) if world > 1 else
+                                    ("ONE process, one key handle sharded over device list %s (zk_set_device_list): Fr stage on the slot's owner device, peer copies of the scalar slices, 768 B partial sums added on the first device" % dev_list
+                                     if len(dev_list) > 1 else "single GPU"),
                        "exchange": head.get("exchange"),
                        "derive_lagrange_s": head.get("derive_lagrange_s"),      # one-time, per key, outside the timed region
                        "tau_power_form": head.get("tau_power_form"),
-                       "rehearsal_ranks_share_gpus": rehearsal,
+                       "rehearsal_ranks_share_gpus": rehearsal or (len(dev_list) > len(set(dev_list))),
+                       "device_list": dev_list or None,          # one process, one key handle over these devices (zk_set_device_list)
                        "prove_algorithmic_bytes_per_constraint": 928,
                        "prove_hbm_frac": head_pub["prove_hbm_frac"]},
             "ms_per_proof": head["ms_per_proof"],

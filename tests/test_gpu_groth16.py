@@ -467,7 +467,8 @@ def test_every_form_of_the_bucket_reduction_gives_the_same_proof(c):
     e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
     pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
     expect = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
-    names = ("ZK_MSM_WINDOW", "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE")
+    names = ("ZK_MSM_WINDOW", "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_RED_WAVES",
+             "ZK_DS_WIDE_GROUP")
     old = {k: os.environ.get(k) for k in names}
     try:
         os.environ["ZK_MSM_WINDOW"] = str(c)              # read by the library when the key's base tables are built
@@ -478,6 +479,17 @@ def test_every_form_of_the_bucket_reduction_gives_the_same_proof(c):
                     os.environ["ZK_TAIL_SLOTS"], os.environ["ZK_TAIL_FIXUP_SLOTS"], os.environ["ZK_FIXUP_BY_CHUNK"] = sums, fix, chunk
                     proof = prover.prove_rs(w, r, s)
                     assert (proof.a, proof.b, proof.c) == expect, "window %d sums-on-slots %s fixup-on-slots %s by-chunk %s" % (c, sums, fix, chunk)
+        for k in names[1:]:
+            os.environ.pop(k, None)
+        # ... the one-lane-per-point sums kernels of msm_red.hip (round 4: products expanded in place) at one and two waves per SIMD, fix-up per bucket and
+        # per chunk border, and -- in the wide form of windows above 16 bits -- 16 / 32 / 64 points per digit value
+        os.environ["ZK_TAIL_SLOTS"] = "0"
+        for waves in ("1", "2"):
+            for grp in ("16", "32", "64"):
+                for chunk in ("0", "1"):
+                    os.environ["ZK_RED_WAVES"], os.environ["ZK_DS_WIDE_GROUP"], os.environ["ZK_FIXUP_BY_CHUNK"] = waves, grp, chunk
+                    proof = prover.prove_rs(w, r, s)
+                    assert (proof.a, proof.b, proof.c) == expect, "window %d waves %s points per digit value %s by-chunk %s" % (c, waves, grp, chunk)
         for k in names[1:]:
             os.environ.pop(k, None)
         # ... and the forms of the bucket ACCUMULATION the A/B switches select (msm_acc_g1.hip / msm_acc_g2.hip): register instead of LDS-DMA

@@ -178,9 +178,8 @@ template <class F> FF_INLINE void xyzz_add_impl(Xyzz<F>& acc, const Xyzz<F>& q) 
     const auto S2 = fe_mul(q.y, acc.zzz);
     const auto P = fe_sub(U2, U1);
     const auto R = fe_sub(S2, S1);
-    if (fe_is_zero(P)) {
-        if (fe_is_zero(R)) acc = xyzz_dbl_impl(acc);
-        else acc = xyzz_inf<F>();
+    if (fe_is_zero(P)) {                                          // P + P or P + (-P): out of line, on the accumulator (U1 = U2 and S1 = +-S2: acc holds the same point)
+        xyzz_madd_equal_x(acc, fe_is_zero(R));
         return;
     }
     const auto PP = fe_sqr(P);
@@ -301,6 +300,39 @@ template <class F> FF_INLINE void xyzz_store_raw(void* p, const Xyzz<F>& a) {
     store_raw_f(c + B, a.y);
     store_raw_f(c + 2 * B, a.zz);
     store_raw_f(c + 3 * B, a.zzz);
+}
+// add-2008-s with the second operand READ FROM MEMORY (raw layout) coordinate by coordinate, each right before its product, and ZZ / ZZZ read a
+// second time for the last two products: q never occupies 4 x 14 registers beside the accumulator and the temporaries of the formula.  The reduction
+// kernels that add bucket sums and chunk partials (msm.hip: k_msm_fixup, k_msm_digit_sums) spilled 25-39 registers with q loaded up front.
+template <class F> FF_INLINE void xyzz_add_raw_mem(Xyzz<F>& acc, const uint8_t* __restrict__ q) {
+    constexpr int B = RawLayout<F>::ELEM;
+    {
+        const F qzz = load_raw_f((const F*)nullptr, q + 2 * B);
+        if (fe_is_zero(qzz)) return;
+        if (xyzz_is_inf(acc)) {
+            acc = xyzz_load_raw<F>(q);
+            return;
+        }
+    }
+    const auto U1 = fe_mul(acc.x, load_raw_f((const F*)nullptr, q + 2 * B));
+    const auto U2 = fe_mul(load_raw_f((const F*)nullptr, q), acc.zz);
+    const auto S1 = fe_mul(acc.y, load_raw_f((const F*)nullptr, q + 3 * B));
+    const auto S2 = fe_mul(load_raw_f((const F*)nullptr, q + B), acc.zzz);
+    const auto P = fe_sub(U2, U1);
+    const auto R = fe_sub(S2, S1);
+    if (fe_is_zero(P)) {                                          // P + P or P + (-P): out of line, on the accumulator (U1 = U2 and S1 = +-S2: acc holds the same point)
+        xyzz_madd_equal_x(acc, fe_is_zero(R));
+        return;
+    }
+    const auto PP = fe_sqr(P);
+    const auto PPP = fe_mul(P, PP);
+    const auto Q = fe_mul(U1, PP);
+    const auto X3 = fe_sub_sub_dbl(fe_sqr(R), PPP, Q);          // R^2 - PPP - 2 Q, one carry pass
+    const auto Y3 = fe_mul_sub(R, fe_sub(Q, X3), S1, PPP);
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = fe_mul(fe_mul(acc.zz, load_raw_f((const F*)nullptr, q + 2 * B)), PP);
+    acc.zzz = fe_mul(fe_mul(acc.zzz, load_raw_f((const F*)nullptr, q + 3 * B)), PPP);
 }
 // ---- layout of the RESIDENT BASE TABLES (MsmBases::table): one 128-byte record per lane that reads the entry --
 //      x as its 14 register limbs | y as its 14 register limbs | 16 B of padding, canonical (< p, exact 29-bit limbs).

@@ -54,6 +54,10 @@ static inline size_t tail_wsum_points(const DigitPlan& p, uint32_t nwin) {
 //               lone 2^16 proof); above (windows of more than 16 bits) throughput-bound: the one-lane-per-point kernel of msm.hip
 //               (2^20 constraints, c = 20, a dozen proofs in flight: 54.5 against 52.5 M constraints/s with both sums steps on slots).
 //   weight:     S -> the product (block weights, combine, Horner over the windows): a few hundred points, always on slots.
+// msm_red.hip: the same two steps with one lane (or lane pair) per point.  workers = buckets, or chunk borders with by_chunk; wide_group = points per digit
+// value in the wide form (16 / 32 / 64; 0 = the default)
+int msm_red_fixup_launch(const TailJobs& jobs, uint32_t count, uint32_t n2, bool by_chunk, uint64_t workers, uint32_t max_nb, hipStream_t s);
+int msm_red_digit_sums_launch(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t nwin, const DigitPlan& dp, bool wide, uint32_t wide_group, hipStream_t s);
 int msm_tail_fixup_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t max_nb, hipStream_t s);
 int msm_tail_digit_sums_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t nwin, uint32_t c, hipStream_t s);
 int msm_tail_weight_slots(const TailJobs& jobs, uint32_t count, uint32_t n2, uint32_t nwin, uint32_t c, hipStream_t s);
