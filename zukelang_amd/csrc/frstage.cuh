@@ -1,6 +1,9 @@
 // Fr stage of the prover: QAP.eval (src/lib/zk/QAP.ml:120-135) for sparse R1CS on the GPU.
 #pragma once
+#include "rns_ntt.cuh"
 #include "zk_common.h"
+
+#include <vector>
 
 namespace zk {
 
@@ -23,10 +26,16 @@ struct FrStage {
     bool lagrange = false;
     DevBuf g_ntt;                     // NTT_S of g[e] = 1/e (g[0] = 0): kernel of the extrapolation convolution
     DevBuf zt;                        // Z(n + t) = (n+t)!/t!, t < n - 1
+    // round 4: the same fixed factors for the convolutions through the residue number system (rns_ntt.cuh), built when the transforms fit it (log_S <= 23)
+    bool rns_ok = false;
+    DevBuf e_rns, iz_rns, g_rns;      // counterparts of e_ntt, iz_ntt, g_ntt: 18 x S residues
+    std::vector<DevBuf> p_rns;        // p_rns[l]: the level-l table of the subproduct tree (nodes of 2^l points), 18 x n2 residues, for the levels above the fused ones
+    uint32_t rns_first_level = 0;     // lowest level with an RNS table
 };
 // per-proof scratch: one per proof in flight
 struct FrScratch {
     DevBuf wit, abc, d, tmp, bufA, h, flag;      // bufA: two convolution buffers of S elements back to back
+    RnsWork rns_a, rns_b;                        // residue arrays of the convolutions (allocated at first use)
 };
 
 int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, hipStream_t s);
@@ -42,7 +51,7 @@ int frstage_init_lagrange(FrStage& f, hipStream_t s);     // after frstage_init
 int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_witness_canonical, hipStream_t s);
 
 // subproduct-tree tables over the points offset .. offset + n2 - 1 (plain Montgomery form, see frstage.hip)
-int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pntt, DevBuf& q, hipStream_t s);
+int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pntt, DevBuf& q, hipStream_t s, std::vector<DevBuf>* p_rns = nullptr, uint32_t rns_first_level = 0);
 
 // a*b via NTT on device (Montgomery in/out); out must hold na+nb-1 elements
 int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, void* d_out, hipStream_t s);

@@ -176,6 +176,16 @@ __global__ void k_tree_pair(uint32_t* pntt_next, uint32_t* prod, const uint32_t*
     fe_store<FrParams>(pntt_next + 8 * i, fe_mul(l, fe_load<FrParams>(scale)));
     fe_store<FrParams>(prod + 8 * i, fe_mul(l, r));
 }
+// the LEFT children of a level, expanded like k_tree_expand: out[parent * 2 len + j] = j < len ? q[(2 parent) * len + j] : (j == len ? 1 : 0)
+__global__ void k_tree_expand_left(uint32_t* out, const uint32_t* q, uint32_t log_len, uint64_t total) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    uint64_t len = (uint64_t)1 << log_len, parent = i >> (log_len + 1), j = i & ((len << 1) - 1);
+    Fr x = fe_zero<FrParams>();
+    if (j < len) x = fe_load<FrParams>(q + 8 * ((2 * parent) * len + j));
+    else if (j == len) x = fe_one<FrParams>();
+    fe_store<FrParams>(out + 8 * i, x);
+}
 // cyclic wrap of the monic leading term: q[parent*len2 + 0] -= 1
 __global__ void k_tree_unwrap(uint32_t* q, uint32_t log_len2, uint64_t nodes) {
     uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,7 +283,11 @@ int dev_poly_mul(const void* d_a, uint64_t na, const void* d_b, uint64_t nb, voi
     hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(A), (const uint32_t*)d_a, (const uint32_t*)nullptr, na, S);
     hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(B), (const uint32_t*)d_b, (const uint32_t*)nullptr, nb, S);
     if (lg == 0) ZKCHK(fr_pointwise_mul(A.p, A.p, B.p, S, s));
-    else {
+    else if (lg <= RNS_MAX_LOG && rns_enabled()) {
+        RnsWork wa, wb;
+        ZKCHK(rns_conv_data(wa, wb, A.p, B.p, lg, A.p, 0, nout, s));
+        HIPCHK(hipStreamSynchronize(s));          // wa, wb die here
+    } else {
         ZKCHK(ntt_forward(B.p, S, lg, s));
         ZKCHK(ntt_mul_table(A.p, S, lg, B.p, S - 1, true, nullptr, nullptr, s, true));
     }
@@ -311,7 +325,7 @@ static int upload_csr(CsrDev& d, const zk_csr* h, uint32_t n, uint32_t m, hipStr
 }
 
 // Newton -> monomial for `batch` vectors of n2 coefficients stored back to back in d (in place).
-static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t levels, void* tmp, hipStream_t s) {
+static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t levels, void* tmp, hipStream_t s, RnsWork* rw = nullptr) {
     Ctx& c = ctx();
     const uint64_t total = (uint64_t)batch * f.n2;
     const uint32_t log_total = ceil_log2(total);
@@ -323,6 +337,11 @@ static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t leve
                        (const uint32_t*)c.tw_fwd, (const uint32_t*)c.tw_inv, fused, log_T, (uint64_t)f.n2);
     for (uint32_t l = fused + 1; l <= levels; l++) {
         const uint32_t* tab = FRP(f.pntt) + 8 * (uint64_t)(l - 1) * f.n2;
+        if (rw && f.rns_ok && l >= f.rns_first_level && l < f.p_rns.size() && f.p_rns[l].p) {
+            // the same node product as an integer convolution modulo 18 small primes (rns_ntt.cuh): upper halves in, sums with the lower halves out
+            ZKCHK(rns_conv_table(*rw, d, total, l, RNS_IN_TREE_HI, f.p_rns[l], (uint64_t)f.n2 - 1, d, RNS_OUT_TREE_ADD, 0, 0, 0, s));
+            continue;
+        }
         // upper halves (zero padded) -> NTT -> * P_left -> iNTT -> + lower halves, with the padding folded
         // into the first pass, the product into the middle kernel and the addition into the last pass
         ZKCHK(ntt_mul_table(tmp, total, l, tab, (uint64_t)f.n2 - 1, false, d, d, s));
@@ -335,7 +354,7 @@ static int tree_convert(const FrStage& f, void* d, uint32_t batch, uint32_t leve
 // points, NTT_{2^(l+1)} of the (monic, padded) subproduct of its LEFT half, times 2^-(l+1) -- plain Montgomery form, transform-domain
 // (bit-reversed) order, n2 entries per level at pntt + l * n2.  `q` returns the root product (low n2 coefficients, monic).
 // offset 0: the prover's basis conversion; offset n: the h bases of a derived Lagrange-form key (lagrange_derive.hip).
-int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pntt, DevBuf& q, hipStream_t s) {
+int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pntt, DevBuf& q, hipStream_t s, std::vector<DevBuf>* p_rns, uint32_t rns_first_level) {
     DevBuf N, prod, scale;
     ZKCHK(ntt_ensure_twiddles(log_n2 + 1));
     ZKCHK(q.alloc(32 * (size_t)n2));
@@ -345,6 +364,11 @@ int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pnt
     hipLaunchKernelGGL(k_tree_leaves, g1d(n2), dim3(256), 0, s, FRP(q), n2, offset);
     for (uint32_t l = 0; l < log_n2; l++) {
         // N = NTT_{2^(l+1)} of every level-l node (monic, padded): 2*n2 entries
+        if (p_rns && l + 1 >= rns_first_level) {
+            // the same table for the convolutions through the residue number system: the transform (there) of the left children's coefficient form
+            hipLaunchKernelGGL(k_tree_expand_left, g1d(n2), dim3(256), 0, s, FRP(prod), (const uint32_t*)FRP(q), l, (uint64_t)n2);
+            ZKCHK(rns_table_build((*p_rns)[l + 1], prod.p, n2, l + 1, s));
+        }
         hipLaunchKernelGGL(k_tree_expand, g1d(2 * (uint64_t)n2), dim3(256), 0, s, FRP(N), (const uint32_t*)FRP(q), l, 2 * (uint64_t)n2);
         ZKCHK(ntt_forward(N.p, 2 * (uint64_t)n2, l + 1, s));
         hipLaunchKernelGGL(k_inv_pow2_of, dim3(1), dim3(64), 0, s, FRP(scale), l + 1);
@@ -378,6 +402,14 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     }
     ZKCHK(ntt_ensure_twiddles(f.log_S));
     const uint32_t n2 = f.n2, S = f.S;
+    // round 4: convolutions through the residue number system where the transforms fit it (rns_ntt.cuh); the tables are always built so that the
+    // form switch ZK_FR_RNS can be flipped per proof (tests), the levels of the fused LDS kernel keep the Fr transform
+    f.rns_ok = f.log_S <= RNS_MAX_LOG;
+    f.rns_first_level = (f.log_n2 < (uint32_t)NTT_LOG_T ? f.log_n2 : (uint32_t)NTT_LOG_T) + 1;
+    if (f.rns_ok) {
+        f.p_rns.clear();
+        f.p_rns.resize(f.log_n2 + 1);
+    }
     ZKCHK(f.invfact.alloc(32 * (size_t)n2));
     ZKCHK(f.e_ntt.alloc(32 * (size_t)S));
     ZKCHK(f.pntt.alloc(32 * (size_t)n2 * (f.log_n2 ? f.log_n2 : 1)));
@@ -396,6 +428,7 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
         hipLaunchKernelGGL(k_fact_chunk_scan, dim3(1), dim3(64), 0, s, FRP(prod), nch);
         hipLaunchKernelGGL(k_invfact, g1d(nch, 64), dim3(64), 0, s, FRP(f.invfact), FRP(alt), (const uint32_t*)FRP(prod), n2);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.e_ntt), (const uint32_t*)FRP(alt), (const uint32_t*)nullptr, (uint64_t)n2, (uint64_t)S);
+        if (f.rns_ok) ZKCHK(rns_table_build(f.e_rns, f.e_ntt.p, S, f.log_S, s));          // from the coefficient form, before the Fr transform overwrites it
         ZKCHK(ntt_forward(f.e_ntt.p, S, f.log_S, s));
         ZKCHK(fr_to_factor(f.e_ntt.p, S, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -403,7 +436,7 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     // ---- subproduct tree, bottom-up.  q holds Q_{l,node} (low 2^l coefficients, monic), n2 entries per level.
     {
         DevBuf q;
-        ZKCHK(frstage_tree_tables(n2, f.log_n2, 0, f.pntt.p, q, s));
+        ZKCHK(frstage_tree_tables(n2, f.log_n2, 0, f.pntt.p, q, s, f.rns_ok ? &f.p_rns : nullptr, f.rns_first_level));
         ZKCHK(fr_to_factor(f.pntt.p, (uint64_t)n2 * f.log_n2, s));
         // ---- Z = prod_{i<n} (X - i)
         if (n == n2) {
@@ -441,6 +474,7 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
             prec = p2;
         }
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(f.iz_ntt), (const uint32_t*)FRP(g), (const uint32_t*)nullptr, need, (uint64_t)S);
+        if (f.rns_ok) ZKCHK(rns_table_build(f.iz_rns, f.iz_ntt.p, S, f.log_S, s));
         ZKCHK(ntt_forward(f.iz_ntt.p, S, f.log_S, s));
         ZKCHK(fr_to_factor(f.iz_ntt.p, S, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -463,6 +497,7 @@ int frstage_scratch_alloc(const FrStage& f, FrScratch& sc) {
 int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipStream_t s) {
     HIPCHK(hipGetLastError());           // a failed launch of an earlier call must not be blamed on this one
     const uint32_t n = f.n, n2 = f.n2, S = f.S;
+    const bool rns = f.rns_ok && n > 1 && rns_enabled();
     uint32_t* a = FRP(sc.abc);
     uint32_t* b = a + 8 * (uint64_t)n;
     uint32_t* cc = b + 8 * (uint64_t)n;
@@ -489,22 +524,29 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_wit_canon, hipSt
         // both vectors as two nodes of one batched convolution
         hipLaunchKernelGGL(k_scale_pad2, g1d(2 * (uint64_t)S), dim3(256), 0, s, FRP(sc.bufA), (const uint32_t*)a, (const uint32_t*)FRP(f.invfact), (uint64_t)n, (uint64_t)n,
                            (uint64_t)S, 2 * (uint64_t)S);
-        ZKCHK(ntt_mul_table(sc.bufA.p, 2 * (uint64_t)S, f.log_S, f.e_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
+        if (rns) ZKCHK(rns_conv_table(sc.rns_a, sc.bufA.p, 2 * (uint64_t)S, f.log_S, RNS_IN_PLAIN, f.e_rns, (uint64_t)S - 1, sc.bufA.p, RNS_OUT_RANGE, 0, n, (uint64_t)S, s));
+        else ZKCHK(ntt_mul_table(sc.bufA.p, 2 * (uint64_t)S, f.log_S, f.e_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
         hipLaunchKernelGGL(k_scale_pad2, g1d(2 * (uint64_t)n2), dim3(256), 0, s, FRP(sc.d), (const uint32_t*)FRP(sc.bufA), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S,
                            (uint64_t)n2, 2 * (uint64_t)n2);
     }
     // ---- Newton -> monomial
-    ZKCHK(tree_convert(f, sc.d.p, 2, f.log_n2, sc.tmp.p, s));
+    ZKCHK(tree_convert(f, sc.d.p, 2, f.log_n2, sc.tmp.p, s, rns ? &sc.rns_a : nullptr));
     // ---- h
     {
         ScopedTimer t("fr_quotient", s);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, FRP(sc.bufA), (const uint32_t*)FRP(sc.d), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
         hipLaunchKernelGGL(k_scale_pad, g1d(S), dim3(256), 0, s, (FRP(sc.bufA) + 8 * (uint64_t)S), (const uint32_t*)(FRP(sc.d) + 8 * (uint64_t)n2), (const uint32_t*)nullptr, (uint64_t)n, (uint64_t)S);
-        ZKCHK(ntt_forward((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, s));
-        ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), (uint64_t)S - 1, true, nullptr, nullptr, s, true));   // v*w, coefficients 0..2n-2
+        if (rns) {          // v w: the coefficients n-1 .. 2n-2 are all the quotient needs
+            ZKCHK(rns_conv_data(sc.rns_a, sc.rns_b, sc.bufA.p, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), f.log_S, (void*)(FRP(sc.bufA) + 8 * (uint64_t)(n - 1)), (uint64_t)n - 1, (uint64_t)n, s));
+        } else {
+            ZKCHK(ntt_forward((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, s));
+            ZKCHK(ntt_mul_table(sc.bufA.p, S, f.log_S, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), (uint64_t)S - 1, true, nullptr, nullptr, s, true));   // v*w, coefficients 0..2n-2
+        }
         // t[k] = (v w)[2n-2-k], k < n-1
         hipLaunchKernelGGL(k_reverse_pad, g1d(S), dim3(256), 0, s, (FRP(sc.bufA) + 8 * (uint64_t)S), (const uint32_t*)FRP(sc.bufA), (uint64_t)(2 * (uint64_t)n - 2), (uint64_t)n - 1, (uint64_t)S);
-        ZKCHK(ntt_mul_table((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, f.iz_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
+        if (rns) ZKCHK(rns_conv_table(sc.rns_a, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, RNS_IN_PLAIN, f.iz_rns, (uint64_t)S - 1, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), RNS_OUT_RANGE, 0,
+                                     (uint64_t)n - 1, 0, s));
+        else ZKCHK(ntt_mul_table((void*)(FRP(sc.bufA) + 8 * (uint64_t)S), S, f.log_S, f.iz_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
         // h[j] = hh[n-2-j], j < n-1
         hipLaunchKernelGGL(k_reverse_pad, g1d(n - 1), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)(FRP(sc.bufA) + 8 * (uint64_t)S), (uint64_t)n - 2, (uint64_t)n - 1, (uint64_t)n - 1);
     }
@@ -518,6 +560,7 @@ int frstage_init_lagrange(FrStage& f, hipStream_t s) {
     ZKCHK(f.g_ntt.alloc(32 * (size_t)S));
     ZKCHK(f.zt.alloc(32 * (size_t)(n > 1 ? n - 1 : 1)));
     hipLaunchKernelGGL(k_inv_range, g1d((S + FCH - 1) / FCH, 64), dim3(64), 0, s, FRP(f.g_ntt), S);
+    if (f.rns_ok) ZKCHK(rns_table_build(f.g_rns, f.g_ntt.p, S, f.log_S, s));
     ZKCHK(ntt_forward(f.g_ntt.p, S, f.log_S, s));
     ZKCHK(fr_to_factor(f.g_ntt.p, S, s));
     const uint32_t nch = (S + FCH - 1) / FCH;              // factorials up to 2 n <= S
@@ -555,7 +598,9 @@ int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_wit_can
         void* dst[3] = {sc.bufA.p, (void*)(FRP(sc.bufA) + 8 * (uint64_t)S), sc.tmp.p};
         for (int k = 0; k < 3; k++) {
             hipLaunchKernelGGL(k_lag_scale, g1d(S), dim3(256), 0, s, (uint32_t*)dst[k], src[k], (const uint32_t*)FRP(f.invfact), n, (uint64_t)S);
-            ZKCHK(ntt_mul_table(dst[k], S, f.log_S, f.g_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
+            if (f.rns_ok && f.g_rns.p && rns_enabled())          // only the values at n .. 2n-2 are read (k_lag_h)
+                ZKCHK(rns_conv_table(sc.rns_a, dst[k], S, f.log_S, RNS_IN_PLAIN, f.g_rns, (uint64_t)S - 1, (void*)((uint32_t*)dst[k] + 8 * (uint64_t)n), RNS_OUT_RANGE, (uint64_t)n, (uint64_t)n - 1, 0, s));
+            else ZKCHK(ntt_mul_table(dst[k], S, f.log_S, f.g_ntt.p, (uint64_t)S - 1, true, nullptr, nullptr, s));
         }
         hipLaunchKernelGGL(k_lag_h, g1d(n), dim3(256), 0, s, FRP(sc.h), (const uint32_t*)FRP(sc.bufA), (const uint32_t*)(FRP(sc.bufA) + 8 * (uint64_t)S),
                            (const uint32_t*)FRP(sc.tmp), (const uint32_t*)FRP(f.zt), n);
