@@ -47,7 +47,9 @@ def test_multi_device_key_gives_the_single_device_bytes(devices, devs, n):
     it = iter(toxic)
     pk, vk = Groth16.keygen(lambda: next(it), cs, lagrange=True)
     L, R_, Oo = csrs(cs)
-    rs = [(rng(), rng()) for _ in range(5)]
+    # proofs in flight: five on two or three list entries, fewer on longer lists -- every entry of the list is another set of streams on the ONE card of
+    # this box, and the card's scratch aperture is shared by all of its queues (on N real devices each has its own)
+    rs = [(rng(), rng()) for _ in range(5 if len(devs) <= 3 else (4 if len(devs) == 4 else 2))]
     exp = [O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s)) for r, s in rs]
     single = Groth16(cs, pk)
     ref0 = single.prove_rs(w, *rs[0])
@@ -98,7 +100,7 @@ def test_multi_device_key_gives_the_single_device_bytes(devices, devs, n):
     assert g2.shape == pk.lag_g2.shape and bool((g2 == pk.lag_g2).all())
     for slot, (r, s) in enumerate(rs[:3]):
         prover.prove_async(w, r, s, slot)
-    for slot in range(3):
+    for slot in range(len(rs[:3])):
         g = prover.prove_wait(slot)
         assert (g.a, g.b, g.c) == exp[slot], "derived key, slot %d" % slot
     io_vals = [w[k] for k in range(cs.m) if not cs.mid[k]]

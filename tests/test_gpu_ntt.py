@@ -116,3 +116,68 @@ def test_polynomial_mul_normalizes_like_the_reference():
     # polynomial.ml:135-139 KAT over Fr: (1 + x)(1 - x) = 1 - x^2
     p1, p2 = one + one, one + top
     assert bytes(FFT_Fr.polynomial_mul(p1, p2)) == one + zero + top
+
+
+def test_rns_convolution_engine_gives_the_same_field_elements():
+    """csrc/rns_ntt.hip (round 4, an OPTION: ZK_FR_RNS=1 when a key is uploaded): the products of the Fr stage as integer convolutions modulo 18 NTT-friendly
+    31-bit primes, carried back to Fr by the Chinese remainder theorem -- exact arithmetic, so Polynomial.mul (polynomial.ml:124-131), QAP.eval
+    (QAP.ml:120-135) and the proofs (groth16.ml:123-161) must come out byte for byte as through the Fr transforms: polynomial products incl. the extreme
+    values (r-1)^2 sums, tau-power keys below and above the fused tree levels (n = 4096: levels 11, 12 go through the residue system), a Lagrange-form
+    key, 2^16 constraints, Pinocchio."""
+    import os
+    from oracle import pyref as P
+    from zukelang_amd import pinocchio as PIN
+    from zukelang_amd.groth16 import Groth16
+    old = os.environ.get("ZK_FR_RNS")
+    os.environ["ZK_FR_RNS"] = "1"
+    try:
+        top = (RC.FR_MODULUS - 1).to_bytes(32, "little")
+        for na, nb in ((1, 7), (3, 5), (100, 29), (255, 257), (1024, 1024), (4096, 3000), (20000, 12000)):
+            a, b = _rand_fr(na, 7000 + na), _rand_fr(nb, 8000 + nb)
+            if na * nb <= 4096 * 4096:
+                assert bytes(FFT_Fr.polynomial_mul(a, b)) == O.poly_mul(a, b), (na, nb)
+            else:                                   # too long for the oracle's schoolbook product: against the Fr transforms
+                os.environ["ZK_FR_RNS"] = "0"
+                ref = bytes(FFT_Fr.polynomial_mul(a, b))
+                os.environ["ZK_FR_RNS"] = "1"
+                assert bytes(FFT_Fr.polynomial_mul(a, b)) == ref, (na, nb)
+        assert bytes(FFT_Fr.polynomial_mul(top * 1500, top * 1400)) == O.poly_mul(top * 1500, top * 1400)
+        frs = lambda xs: b"".join(P.fr_to_bytes(x) for x in xs)
+        for n in (2, 6, 300, 1000, 4096, 1 << 16):
+            cs, w = RC.iterated_cubic(n, 0x515 + n)
+            st = P.fr_stream(0x5EED0A00 + n)
+            toxic = [next(st) for _ in range(5)]
+            it = iter(toxic)
+            pk, _ = Groth16.keygen(lambda: next(it), cs, lagrange=True)
+            csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+            r, s = next(st), next(st)
+            exp = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+            for lag in (False, True):
+                prover = Groth16(cs, pk, lagrange=lag)          # the switch is read when the key is uploaded (tables) and per proof
+                got = prover.prove_rs(w, r, s)
+                assert (got.a, got.b, got.c) == exp, (n, lag)
+                if not lag and n <= 4096:
+                    os.environ["ZK_FR_RNS"] = "0"
+                    ref = [bytes(x) for x in prover.qap_eval(w)]          # the SAME key through the Fr transforms
+                    os.environ["ZK_FR_RNS"] = "1"
+                    assert [bytes(x) for x in prover.qap_eval(w)] == ref, n
+                w_bad = list(w)
+                w_bad[n // 2] = (w_bad[n // 2] + 1) % RC.FR_MODULUS
+                with pytest.raises(AssertionError):
+                    prover.prove_rs(w_bad, r, s)
+                prover.close()
+        cs, w = RC.iterated_cubic(1000, 11)
+        st = P.fr_stream(0x5EED0003)
+        tox = [next(st) for _ in range(11)]
+        it = iter(tox)
+        pk, _ = PIN.ZK.keygen(lambda: next(it), cs)
+        prover = PIN.ZK(cs, pk)
+        proof = prover.prove(lambda: next(it), w)
+        csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+        assert proof.to_bytes() == O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(tox[:8]), *(P.fr_to_bytes(x) for x in tox[8:]))
+        prover.close()
+    finally:
+        if old is None:
+            os.environ.pop("ZK_FR_RNS", None)
+        else:
+            os.environ["ZK_FR_RNS"] = old

@@ -402,9 +402,10 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     }
     ZKCHK(ntt_ensure_twiddles(f.log_S));
     const uint32_t n2 = f.n2, S = f.S;
-    // round 4: convolutions through the residue number system where the transforms fit it (rns_ntt.cuh); the tables are always built so that the
-    // form switch ZK_FR_RNS can be flipped per proof (tests), the levels of the fused LDS kernel keep the Fr transform
-    f.rns_ok = f.log_S <= RNS_MAX_LOG;
+    // round 4: convolutions through the residue number system where the transforms fit it (rns_ntt.cuh) -- an OPTION (ZK_FR_RNS=1 when the key is
+    // uploaded: the tables and the residue arrays of the slots cost 72 bytes per element; measured slower than the Fr transforms in its present form,
+    // DESIGN.md 9b), kept under parity by the GPU suite.  The levels of the fused LDS kernel keep the Fr transform.
+    f.rns_ok = f.log_S <= RNS_MAX_LOG && rns_enabled();
     f.rns_first_level = (f.log_n2 < (uint32_t)NTT_LOG_T ? f.log_n2 : (uint32_t)NTT_LOG_T) + 1;
     if (f.rns_ok) {
         f.p_rns.clear();
@@ -491,6 +492,10 @@ int frstage_scratch_alloc(const FrStage& f, FrScratch& sc) {
     ZKCHK(sc.bufA.alloc(32 * (size_t)2 * f.S));          // two convolution buffers back to back: A = [0, S), B = [S, 2S)
     ZKCHK(sc.h.alloc(32 * (size_t)f.n));
     ZKCHK(sc.flag.alloc(4));
+    if (f.rns_ok && f.n > 1) {          // residue arrays of the convolutions, allocated HERE: a proof may be enqueued under stream capture (ZK_GRAPH), where nothing can be allocated
+        ZKCHK(sc.rns_a.ensure(f.lagrange ? (uint64_t)f.S : 2 * (uint64_t)f.S));          // the Newton step of the tau-power path transforms both vectors in one batch
+        if (!f.lagrange) ZKCHK(sc.rns_b.ensure((uint64_t)f.S));
+    }
     return ZK_OK;
 }
 

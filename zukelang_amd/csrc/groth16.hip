@@ -120,7 +120,7 @@ int groth16_slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
         // proof in flight: the G2 product's latency-bound reduction chain then runs beside the G1 products instead of in front of
         // them (single-proof latency; with other proofs in flight it stays on one stream like every other slot).
         const char* ss = ZK_ENV("ZK_SLOT_STREAMS");
-        const bool want3 = ss ? atoi(ss) >= 3 : idx == 0;
+        const bool want3 = !k.one_stream_slots && (ss ? atoi(ss) >= 3 : idx == 0);
         if (ZK_ENV("ZK_SERIAL_STREAMS") || !want3) {
             sl->s1 = sl->s2 = sl->s0;
             sl->serial = true;
@@ -146,7 +146,7 @@ static uint32_t key_window(uint64_t g1_points) {
     return g1_points >= ((uint64_t)1 << 21) ? 20 : msm_auto_window(g1_points, true);
 }
 int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
-                      const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world, bool lagrange) {
+                      const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world, bool lagrange, bool shard_of_group) {
     if (!mid || !pk_g1 || !pk_g2 || !L || !R || !O) ZK_FAIL(ZK_ERR_ARG, "pk_upload: null argument");
     if (world == 0 || rank >= world) ZK_FAIL(ZK_ERR_ARG, "pk_upload: bad rank / world");
     ZKCHK(ensure_init());
@@ -154,6 +154,7 @@ int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, 
     auto key = std::make_unique<Groth16Key>();
     Groth16Key& k = *key;
     k.vdev = c.vdev;
+    k.one_stream_slots = shard_of_group;
     k.n = n; k.m = m; k.rank = rank; k.world = world;
     std::vector<uint32_t> mids;
     for (uint32_t i = 0; i < m; i++)

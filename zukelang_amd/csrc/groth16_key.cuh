@@ -50,13 +50,15 @@ struct Groth16Key {
     bool have_witness = false;
     bool lagrange = false;              // key holds [l_i(tau)] and the shifted-domain h bases instead of tau powers (row f4)
     std::unique_ptr<Slot> slots[MAX_SLOTS];
+    bool one_stream_slots = false;      // shard of a multi-device key: its products always run on the slot's one stream (no extra streams for slot 0)
     int vdev = 0;                       // virtual device (context) the key was built under; every call on it runs with that context current
 };
 
 
 // Builds a key (whole: rank 0 of world 1, or rank's shard) on the CURRENT virtual device; nothing is registered under a handle.
 int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
-                      const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world, bool lagrange);
+                      const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world, bool lagrange,
+                      bool shard_of_group = false);
 int groth16_slot_get(Groth16Key& k, uint32_t idx, Slot** out);
 // host half of a proof's inputs (witness handed over as a host buffer, r, s) into the slot's pinned staging memory; fails when the slot is busy
 int groth16_stage_inputs(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint8_t* r, const uint8_t* s);

@@ -19,7 +19,10 @@
 #include "groth16_key.cuh"
 
 #include <map>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -77,16 +80,37 @@ void group_release_all() {
 // runs f(v) for every virtual device of the key, one host thread each (the set-up paths synchronise their streams internally); the worst code wins
 template <class F> static int on_every_device(size_t count, F f) {
     std::vector<int> rc(count, ZK_OK);
-    if (count == 1) {
-        DeviceScope ds(0);
-        return f(0);
+    // One host thread per PHYSICAL device; list entries that share a card ("virtual devices") take their turns on that card's thread.  Besides being
+    // all the parallelism one card has to give, this bounds what the set-up kernels ask of the card at once: k_subgroup_check and the window-table
+    // builders carry 1-2 KiB of private memory per lane, i.e. > 1 GiB of scratch per QUEUE they run on, and a handful of them on different queues of ONE
+    // device exhaust its scratch aperture (HSA_STATUS_ERROR_OUT_OF_RESOURCES: the runtime aborts the process).
+    std::vector<std::vector<int>> groups;
+    for (size_t v = 0; v < count; v++) {
+        size_t gi = 0;
+        while (gi < groups.size() && ctx_at(groups[gi][0]).device != ctx_at((int)v).device) gi++;
+        if (gi == groups.size()) groups.emplace_back();
+        groups[gi].push_back((int)v);
     }
+    auto run_group = [&rc, &f](const std::vector<int>& vs) {
+        for (int v : vs) {
+            DeviceScope ds(v);
+            rc[v] = f(v);
+        }
+    };
+    // A host thread that cannot be started (the process is at its thread limit) must not take the process down: std::thread's constructor throws,
+    // and a joinable thread destroyed during the unwinding would call std::terminate.  Whatever could not be started runs on the calling thread.
     std::vector<std::thread> th;
-    for (size_t v = 0; v < count; v++)
-        th.emplace_back([&, v] {
-            DeviceScope ds((int)v);
-            rc[v] = f((int)v);
-        });
+    size_t started = 1;          // group 0 runs on the calling thread
+    for (size_t gi = 1; gi < groups.size(); gi++) {
+        try {
+            th.emplace_back(run_group, std::cref(groups[gi]));
+            started = gi + 1;
+        } catch (...) {
+            break;
+        }
+    }
+    run_group(groups[0]);
+    for (size_t gi = started; gi < groups.size(); gi++) run_group(groups[gi]);
     for (auto& t : th) t.join();
     int worst = ZK_OK;
     for (int r : rc)
@@ -94,6 +118,13 @@ template <class F> static int on_every_device(size_t count, F f) {
     return worst;
 }
 
+static void trace(const char* what) {
+    static const bool on = getenv("ZK_TRACE") != nullptr;
+    if (on) {
+        fprintf(stderr, "[zk multi] %s\n", what);
+        fflush(stderr);
+    }
+}
 static int sync_all(GroupKey& g) {
     for (size_t v = 0; v < g.sub.size(); v++) {
         DeviceScope ds((int)v);
@@ -117,7 +148,7 @@ int group_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const
     g.sub.resize(N);
     // every shard checks its own slice of the key points and builds the Fr-stage tables (any device may own a proof's Fr stage)
     const int rc = on_every_device(N, [&](int v) {
-        return groth16_key_build(g.sub[v], n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, (uint32_t)v, (uint32_t)N, lagrange);
+        return groth16_key_build(g.sub[v], n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, (uint32_t)v, (uint32_t)N, lagrange, true);
     });
     if (rc != ZK_OK) {
         group_destroy(g);
@@ -235,25 +266,28 @@ int group_prove_async(GroupKey& g, const uint8_t* sol, const uint8_t* r, const u
         };
         rc = body();
     }
-    {   // ---- first device: add the N blocks per product, convert, land the proof in pinned memory
+    {   // ---- first device: add the N blocks per product, convert, land the proof in pinned memory.  On ONE stream for all slots (the context's second
+        // stream): the Fp2 column sum carries 3 KiB of private memory per lane, i.e. 1.6 GiB of scratch for every QUEUE it is dispatched on -- on the
+        // slots' own streams a handful of proofs in flight exhausted the device's scratch aperture (HSA_STATUS_ERROR_OUT_OF_RESOURCES, the runtime aborts
+        // the process).  A combine is ~50 us of work behind its N events; the slots' combines queue up in the order the proofs were enqueued.
         DeviceScope ds(0);
-        Slot& s0 = *g.sub[0]->slots[slot];
+        hipStream_t cs = ctx().stream2;
         auto body = [&]() -> int {
-            for (int v = 1; v < N; v++) HIPCHK(hipStreamWaitEvent(s0.s0, gs.ev_part[v], 0));
+            for (int v = 0; v < N; v++) HIPCHK(hipStreamWaitEvent(cs, gs.ev_part[v], 0));
             if (rc != ZK_OK) return rc;
             const size_t g1b = xyzz_bytes(CURVE_G1), g2b = xyzz_bytes(CURVE_G2), blk = 2 * g1b + g2b;
-            HIPCHK(hipMemcpy2DAsync(gs.g1p.p, 2 * g1b, gs.parts.p, blk, 2 * g1b, N, hipMemcpyDeviceToDevice, s0.s0));                      // [device][A, C]
-            HIPCHK(hipMemcpy2DAsync(gs.g2p.p, g2b, gs.parts.as<char>() + 2 * g1b, blk, g2b, N, hipMemcpyDeviceToDevice, s0.s0));        // [device][B]
-            ZKCHK(xyzz_sum_columns(CURVE_G1, gs.sum.p, gs.g1p.p, N, 2, s0.s0));
-            ZKCHK(xyzz_sum_columns(CURVE_G2, gs.sum.as<char>() + 2 * g1b, gs.g2p.p, N, 1, s0.s0));
+            HIPCHK(hipMemcpy2DAsync(gs.g1p.p, 2 * g1b, gs.parts.p, blk, 2 * g1b, N, hipMemcpyDeviceToDevice, cs));                      // [device][A, C]
+            HIPCHK(hipMemcpy2DAsync(gs.g2p.p, g2b, gs.parts.as<char>() + 2 * g1b, blk, g2b, N, hipMemcpyDeviceToDevice, cs));        // [device][B]
+            ZKCHK(xyzz_sum_columns(CURVE_G1, gs.sum.p, gs.g1p.p, N, 2, cs));
+            ZKCHK(xyzz_sum_columns(CURVE_G2, gs.sum.as<char>() + 2 * g1b, gs.g2p.p, N, 1, cs));
             const uint32_t o1[2] = {0, 288}, o2[1] = {96};          // sums: A | C | B;  proof: a | b | c
-            ZKCHK(proof_points_to_bytes_dev(gs.sum.p, 2, o1, gs.sum.as<char>() + 2 * g1b, 1, o2, gs.out.p, s0.s0));
-            HIPCHK(hipMemcpyAsync(gs.host, gs.out.p, 384, hipMemcpyDeviceToHost, s0.s0));
+            ZKCHK(proof_points_to_bytes_dev(gs.sum.p, 2, o1, gs.sum.as<char>() + 2 * g1b, 1, o2, gs.out.p, cs));
+            HIPCHK(hipMemcpyAsync(gs.host, gs.out.p, 384, hipMemcpyDeviceToHost, cs));
             return ZK_OK;
         };
         const int rc0 = body();
         if (rc == ZK_OK) rc = rc0;
-        (void)hipEventRecord(gs.done, s0.s0);
+        (void)hipEventRecord(gs.done, cs);
     }
     if (rc != ZK_OK) {          // nothing of a half-enqueued proof may stay in flight behind the caller's back
         (void)sync_all(g);
@@ -316,7 +350,9 @@ int group_qap_eval(GroupKey& g, const uint8_t* sol, uint8_t* v_out, uint8_t* w_o
 int group_derive_lagrange(GroupKey& g) {
     if (g.lagrange) return ZK_OK;
     ZKCHK(check_idle(g, "zk_groth16_pk_derive_lagrange: a proof is in flight on this key"));
+    trace("derive: sync");
     ZKCHK(sync_all(g));
+    trace("derive: synced");
     const int N = (int)g.sub.size();
     const uint64_t n = g.n, p1o = g.p1, p2o = g.p2, p1n = 3 + n + (n - 1) + g.n_mid, p2n = 2 + n;
     int owner[3] = {0, N > 1 ? 1 : 0, N > 2 ? 2 : 0};
@@ -332,6 +368,7 @@ int group_derive_lagrange(GroupKey& g) {
             ZKCHK(in2[v].alloc(192 * p2o));
         }
     }
+    trace("derive: gather");
     // ---- gather: every shard's slice of the pools, dense affine, to every deriving device (window 0 of a shard's tables IS its slice in pool order)
     for (int v = 0; v < N; v++) {
         DeviceScope ds(v);
@@ -349,6 +386,7 @@ int group_derive_lagrange(GroupKey& g) {
         }
         HIPCHK(hipStreamSynchronize(c.stream));
     }
+    trace("derive: derive sets");
     // ---- derive: one host thread per deriving device (the derivation synchronises its stream between phases)
     int rc = on_every_device((size_t)N, [&](int v) -> int {
         if (!sets[v]) return ZK_OK;
@@ -358,6 +396,7 @@ int group_derive_lagrange(GroupKey& g) {
         return ZK_OK;
     });
     if (rc != ZK_OK) return rc;          // nothing of the key has changed yet
+    trace("derive: copy sets");
     // ---- every set (and the copied parts a | d1 | b1, ltd_mid, b2 | d2, which every derivation writes) to every other device
     struct Region { int src; int pool; uint64_t lo, hi; };
     const Region regions[6] = {{owner[0], 1, 3, 3 + n}, {owner[1], 2, 2, 2 + n}, {owner[2], 1, 3 + n, 3 + n + (n - 1)},
@@ -375,6 +414,7 @@ int group_derive_lagrange(GroupKey& g) {
         HIPCHK(hipStreamSynchronize(c.stream));
     }
     for (int v = 0; v < N; v++) { in1[v].release(); in2[v].release(); }
+    trace("derive: install");
     // ---- install: each device builds the window tables of ITS slice of the new pools and flips its Fr stage.  From the first commit on the key
     // is only consistent once every device has succeeded.
     for (auto& sl : g.slots) {          // group slots refer to the shards' slots, which the install replaces
@@ -386,6 +426,7 @@ int group_derive_lagrange(GroupKey& g) {
         g.broken = true;
         return rc;
     }
+    trace("derive: done");
     g.lagrange = true;
     g.p1 = p1n;
     g.p2 = p2n;

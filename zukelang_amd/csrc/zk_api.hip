@@ -3,7 +3,10 @@
 #include "fp_inv.cuh"
 #include "zk_common.h"
 
+#include <execinfo.h>
+#include <signal.h>
 #include <string.h>
+#include <unistd.h>
 #include <mutex>
 
 #include <stdlib.h>
@@ -13,7 +16,27 @@ namespace zk {
 // Runs when the shared object is loaded, i.e. before the first HIP call of a process that has
 // not touched the GPU yet: the pipelined prover keeps ~3 streams per proof in flight and the ROCm
 // default of 4 hardware queues serialises them (measured per 2^16 proof: 8.6 ms with 4, 7.0 ms with 16, 5.7-6.1 ms with 32).
-__attribute__((constructor)) static void zk_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
+// ZK_TRACE=1 (diagnostics): a native backtrace of the thread that raises SIGABRT / SIGSEGV -- the runtime's own threads abort without a word when a
+// queue dies, and Python's faulthandler only shows the main thread's Python frames.
+static void zk_fatal_signal(int sig) {
+    static const char msg[] = "[zk trace] fatal signal, native backtrace of the raising thread:\n";
+    signal(SIGABRT, SIG_DFL);
+    signal(SIGSEGV, SIG_DFL);
+    (void)!write(2, msg, sizeof msg - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    raise(sig);
+}
+__attribute__((constructor)) static void zk_request_hw_queues() {
+    setenv("GPU_MAX_HW_QUEUES", "32", 0);
+    if (getenv("ZK_TRACE")) {
+        void* warm[4];
+        (void)backtrace(warm, 4);          // loads the unwinder now: no allocation inside the handler
+        signal(SIGABRT, zk_fatal_signal);
+        signal(SIGSEGV, zk_fatal_signal);
+    }
+}
 
 // The device list and its contexts.  Contexts are heap-allocated and never destroyed (event / stream handles must not be touched at exit).
 static std::vector<Ctx*>& ctxs() {
