@@ -4,6 +4,7 @@ point patterns against the oracle's naive fold, Groth16 proofs of random sizes a
 (power-form and Lagrange-form keys).  Test infrastructure (it uses the oracle); not collected by pytest.
 Usage: python tests/soak_parity.py [seconds] [seed]"""
 import os, random, sys, time
+os.environ.setdefault("ZK_TEST_FORMS", "1")      # before the library loads: kernel-form switches (ZK_FR_RNS ...) are read per call, not cached (csrc/zk_common.h)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))      # ROOT = repo root (this file lives in tests/)
 import numpy as np
@@ -13,12 +14,14 @@ from zukelang_amd import r1cs as RC
 from zukelang_amd.curve import G1, G2
 from zukelang_amd.groth16 import Groth16
 from zukelang_amd import pinocchio as PIN
+from zukelang_amd import _lib
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 frb = P.fr_to_bytes
 t_end = time.time() + budget
-n_msm = n_g16 = n_pin = n_der = n_ba = 0
+n_msm = n_g16 = n_pin = n_der = n_ba = n_multi = n_rns = 0
+_lib.check(_lib.lib().zk_init(0))
 while time.time() < t_end:
     # ---- MSM with duplicates, negations, identity, tiny / huge / zero scalars
     G, naive, gen, mul = rnd.choice([(G1, O.g1_msm_naive, O.g1_generator, O.g1_mul), (G2, O.g2_msm_naive, O.g2_generator, O.g2_mul)])
@@ -78,6 +81,43 @@ while time.time() < t_end:
         assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch with batch-affine rounds", n)
         pr.close()
         n_ba += 1
+    if n_g16 % 4 == 1:
+        # round 4: the same key behind ONE handle over a device list (the card listed 2 .. 4 times: csrc/groth16_multi.hip), a few proofs in flight with
+        # the owner of the Fr stage rotating, then the multi-device derivation -- bytes as on one device
+        devs = [0] * rnd.choice([2, 3, 4])
+        _lib.set_device_list(devs)
+        try:
+            pr = Groth16(cs, pk)
+            pr.set_witness(w)
+            k = rnd.choice([1, 2, 3])
+            rss = [(r, s)] + [(rnd.randrange(P.R), rnd.randrange(P.R)) for _ in range(k - 1)]
+            for slot, (r_, s_) in enumerate(rss):
+                pr.prove_async(None, r_, s_, slot)
+            for slot, (r_, s_) in enumerate(rss):
+                p = pr.prove_wait(slot)
+                e_ = exp if slot == 0 else O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, b"".join(frb(x) for x in w), b"".join(frb(x) for x in toxic), frb(r_), frb(s_))
+                assert (p.a, p.b, p.c) == e_, ("multi-device Groth16 mismatch", n, devs, slot)
+            if n_multi % 2 == 0:
+                pr.derive_lagrange()
+                assert bytes(pr.pool_points(1)) == bytes(pk.lag_g1) and bytes(pr.pool_points(2)) == bytes(pk.lag_g2), ("multi-device derived pools differ", n, devs)
+                p = pr.prove_rs(w, r, s)
+                assert (p.a, p.b, p.c) == exp, ("multi-device Groth16 mismatch after the derivation", n, devs)
+            pr.close()
+        finally:
+            _lib.set_device_list([0])
+        n_multi += 1
+    if n_g16 % 4 == 3:
+        # round 4: the Fr stage's products through the residue number system (csrc/rns_ntt.hip, an option read at upload), both key forms
+        os.environ["ZK_FR_RNS"] = "1"
+        try:
+            for lag in (False, True):
+                pr = Groth16(cs, pk, lagrange=lag)
+                p = pr.prove_rs(w, r, s)
+                assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch through the residue number system", n, lag)
+                pr.close()
+        finally:
+            del os.environ["ZK_FR_RNS"]
+        n_rns += 1
     n_g16 += 1
     # ---- every fourth round: Pinocchio ZK prove at a random size against the trapdoor evaluation, then the product's verifier
     if n_g16 % 4 == 0:
@@ -100,5 +140,6 @@ while time.time() < t_end:
         prover.close()
         n_pin += 1
     if (n_msm % 10) == 0:
-        print("soak: %d MSM cases, %d Groth16 cases, %d Pinocchio cases ok" % (n_msm, n_g16, n_pin), flush=True)
-print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds) pinocchio=%d" % (n_msm, n_g16, n_der, n_ba, n_pin))
+        print("soak: %d MSM cases, %d Groth16 cases (%d multi-device, %d RNS), %d Pinocchio cases ok" % (n_msm, n_g16, n_multi, n_rns, n_pin), flush=True)
+print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds, %d behind a multi-device handle, %d through the residue number system) pinocchio=%d"
+      % (n_msm, n_g16, n_der, n_ba, n_multi, n_rns, n_pin))

@@ -178,8 +178,9 @@ template <class F> FF_INLINE void xyzz_add_impl(Xyzz<F>& acc, const Xyzz<F>& q) 
     const auto S2 = fe_mul(q.y, acc.zzz);
     const auto P = fe_sub(U2, U1);
     const auto R = fe_sub(S2, S1);
-    if (fe_is_zero(P)) {                                          // P + P or P + (-P): out of line, on the accumulator (U1 = U2 and S1 = +-S2: acc holds the same point)
-        xyzz_madd_equal_x(acc, fe_is_zero(R));
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R)) acc = xyzz_dbl_impl(acc);
+        else acc = xyzz_inf<F>();
         return;
     }
     const auto PP = fe_sqr(P);
@@ -320,8 +321,9 @@ template <class F> FF_INLINE void xyzz_add_raw_mem(Xyzz<F>& acc, const uint8_t* 
     const auto S2 = fe_mul(load_raw_f((const F*)nullptr, q + B), acc.zzz);
     const auto P = fe_sub(U2, U1);
     const auto R = fe_sub(S2, S1);
-    if (fe_is_zero(P)) {                                          // P + P or P + (-P): out of line, on the accumulator (U1 = U2 and S1 = +-S2: acc holds the same point)
-        xyzz_madd_equal_x(acc, fe_is_zero(R));
+    if (fe_is_zero(P)) {
+        if (fe_is_zero(R)) acc = xyzz_dbl_impl(acc);
+        else acc = xyzz_inf<F>();
         return;
     }
     const auto PP = fe_sqr(P);

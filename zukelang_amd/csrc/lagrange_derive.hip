@@ -25,6 +25,12 @@
 namespace zk {
 
 static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
+// Waves per SIMD of the lane-pair (G2) butterflies and table products.  Round 3 ran them at ONE wave (340-400 registers, no spill); with the Jacobian /
+// affine-table multiplication of round 4 the table product fits 256 registers with 20 spilled and the butterflies spill 146 / 227 -- outside the
+// multiplication's loop -- and TWO waves are faster: 7.39 -> 6.70 s at 2^18, 34.8 -> 31.2 s at 2^20 for a key's three sets (same box, alternating).
+#ifndef ZK_DERIVE_G2_WAVES
+#define ZK_DERIVE_G2_WAVES 2
+#endif
 template <class T> struct LaneCount { static constexpr uint32_t N = RawLayout<T>::LANES; };
 
 // ---- scalar (canonical Fr, 8 words in memory) times point, complete formulas (identity, equal operands).
@@ -361,10 +367,9 @@ template <class T> __global__ void k_raw_to_aff(uint8_t* __restrict__ dst, const
 
 // ---- one radix-2 stage over the whole array (independent blocks of 2h points): forward = DIF (natural -> bit-reversed),
 // inverse = DIT (bit-reversed -> natural, unscaled) -- the conventions of ntt.hip, so the Fr tables line up.  tw[h + j] = w_2h^(+-j).
-// Two waves per SIMD for G1 (256 registers: 16-122 spilled ones cost less than the second wave brings -- 2^20: 44.4 -> 41.6 s for a key's three
-// sets); the lane-pair G2 form needs 340-400 registers and spills hundreds at 256: one wave per SIMD there.
+// Two waves per SIMD for both curves (G1: 256 registers, 0 / 69 spilled; G2: see ZK_DERIVE_G2_WAVES above).
 template <class T, bool INVERSE>
-__global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : 1)) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t b0, uint64_t pairs, uint8_t* __restrict__ scratch) {
+__global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : ZK_DERIVE_G2_WAVES)) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t b0, uint64_t pairs, uint8_t* __restrict__ scratch) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, b = b0 + loc;      // a slab of butterflies per launch
     if (b >= pairs) return;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : 1)) void k_g
     }
 }
 // pts[i] <- tab[i] * pts[i]
-template <class T> __global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : 1)) void k_g_tabmul(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tab, uint64_t i0, uint64_t total, uint8_t* __restrict__ scratch) {
+template <class T> __global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : ZK_DERIVE_G2_WAVES)) void k_g_tabmul(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tab, uint64_t i0, uint64_t total, uint8_t* __restrict__ scratch) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, i = i0 + loc;
     if (i >= total) return;
