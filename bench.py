@@ -739,10 +739,10 @@ def main():
     ap.add_argument("--lagrange-key", action="store_true", help="one GPU: prove from the Lagrange-form EXTENSION of the key (scope row f4; "
                     "not the reference's key format -- the default and the headline use the tau-power key)")
     ap.add_argument("--derive-lagrange-upto", type=int, default=22, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
-                    "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.3 s at 2^16, 7.3 s at 2^18, 34 s at 2^20, 160 s at 2^22) and "
+                    "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.7 s at 2^16, 6.7 s at 2^18, 31 s at 2^20, 147 s at 2^22) and "
                     "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
     ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock the whole run aims to stay within: a derivation whose estimate (34 s x n / 2^20) does not fit what is left "
-                    "is skipped and that workload reports its tau-power figure only (the default run is ~5 min with the 160 s derivation of the 2^22 key)")
+                    "is skipped and that workload reports its tau-power figure only (the default run is ~5 min with the 147 s derivation of the 2^22 key)")
     ap.add_argument("--host-witness", action="store_true", help="one GPU: hand the witness over as a host buffer with every proof (the PCIe-inclusive rate of DESIGN.md 8) instead of "
                     "proving from the copy made resident by zk_groth16_set_witness; never the headline")
     ap.add_argument("--derived-only", action="store_true", help="profiling runs: derive the key's Lagrange form right after the upload and measure only that path "
