@@ -55,6 +55,13 @@ def test_fails_loudly_without_a_gpu():
     assert lib.zk_device_count() == 0
     assert lib.zk_init(0) == -5
     assert b"no HIP device" in lib.zk_last_error()
+    # the device-list entry points (multi-device keys) fail the same way and leave no list behind
+    assert lib.zk_set_devices(C.c_uint64(0b11)) == -5 and b"no HIP device" in lib.zk_last_error()
+    devs = (C.c_int32 * 2)(0, 0)
+    assert lib.zk_set_device_list(devs, C.c_uint32(2)) == -5
+    assert lib.zk_set_devices(C.c_uint64(0)) == -1 and lib.zk_set_device_list(None, C.c_uint32(0)) == -1          # argument errors come first
+    cnt = C.c_uint32(7)
+    assert lib.zk_get_device_list(None, C.c_uint32(0), C.byref(cnt)) == 0 and cnt.value == 0
     buf = (C.c_uint8 * 64)()
     assert lib.zk_fr_ntt(buf, 1, 0) == -5
     out = (C.c_uint8 * 96)()
