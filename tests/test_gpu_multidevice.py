@@ -143,3 +143,32 @@ def test_shards_of_a_multi_device_key_follow_the_equal_work_cuts(devices):
             lo, hi = C.c_uint64(), C.c_uint64()
             _lib.check(_lib.lib().zk_groth16_shard_range(C.c_uint64(size), C.c_uint64(heavy), C.c_uint32(g), C.c_uint32(world), C.byref(lo), C.byref(hi)))
             assert (lo.value, hi.value) == shard_bounds(size, g, world, heavy)
+
+
+def test_multi_device_key_error_paths(devices):
+    """More list entries than key points (the README circuit's G2 pool has 7), misuse of slots, and an unsatisfied witness on the synchronous call:
+    errors come back as codes / the reference's exceptions, nothing stays alive or busy."""
+    cs, w = RC.readme_circuit(3)
+    rng = seeded_rng(0x5EED0F99)
+    pk, _ = Groth16.keygen(rng, cs)
+    devices([0] * 8)
+    with pytest.raises(_lib.ZkError):
+        Groth16(cs, pk)                                         # a shard would be empty: ZK_ERR_ARG from every failing shard, the others are released
+    _lib.set_device_list([0, 0])                                # possible only because no handle stayed behind
+    prover = Groth16(cs, pk)
+    out = np.zeros(384, dtype=np.uint8)
+    p8 = out.ctypes.data_as(C.POINTER(C.c_uint8))
+    assert _lib.lib().zk_groth16_prove_wait(prover.handle, C.c_uint32(3), p8) == -1            # slot never used
+    r, s = rng(), rng()
+    prover.prove_async(w, r, s, 1)
+    with pytest.raises(_lib.ZkError):
+        prover.prove_async(w, r, s, 1)                          # still in flight
+    good = prover.prove_wait(1)
+    assert _lib.lib().zk_groth16_prove_wait(prover.handle, C.c_uint32(1), p8) == -1            # nothing in flight any more
+    w_bad = list(w)
+    w_bad[4] = (w_bad[4] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        prover.prove_rs(w_bad, r, s)                            # QAP.ml:134 through the synchronous call (owner = the first device)
+    again = prover.prove_rs(w, r, s)
+    assert (again.a, again.b, again.c) == (good.a, good.b, good.c)
+    prover.close()
