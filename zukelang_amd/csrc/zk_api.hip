@@ -264,7 +264,10 @@ static int contexts_create(const int32_t* devices, uint32_t count) {
     (void)hipGetDevice(&prev);
     std::vector<Ctx*> made;
     auto fail = [&](int rc) {
-        for (Ctx* c : made) delete c;          // streams of a half-built list leak with the process; the list itself stays empty
+        for (Ctx* c : made) {          // streams of a half-built list leak with the process; the list itself stays empty
+            delete c->bufs;
+            delete c;
+        }
         if (prev >= 0) (void)hipSetDevice(prev);
         return rc;
     };
