@@ -540,14 +540,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint3
 // digit sums of the bucket reduction (one lane, or lane pair, per point): msm_red.hip -- a translation unit of its own, with the field products
 // expanded in place
 static constexpr uint32_t BA_FINISH_CHUNK = 8;       // sorted entries per lane of the XYZZ accumulate that follows the batch-affine rounds
-template <class F> __global__ void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
-    constexpr int XB = FieldOps<F>::WORDS * 16;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npoints) return;
+// acc[i] = sum_j parts[j * npoints + i] on dense XYZZ points: the sum of the ranks' / devices' partial sums of a proof.  One lane per point in G1, a lane PAIR
+// in G2 (F = Fp2H), additions expanded in place on the lane's registers: round 3's form (a whole Fp2 point per lane through the out-of-line addition)
+// carried 3 KiB of private memory per lane -- 1.6 GiB of scratch reserved on every queue the kernel was dispatched on.
+template <class F> __global__ __launch_bounds__(64) void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
+    constexpr int XB = FieldOps<F>::WORDS * 16;          // dense XYZZ bytes of one point: 192 (G1) / 384 (G2: FieldOps<Fp2H> keeps Fp2's memory layout)
+    const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / RawLayout<F>::LANES;
+    if (i >= npoints) return;          // both lanes of a pair together
     Xyzz<F> acc = xyzz_inf<F>();
     for (uint32_t j = 0; j < count; j++) {
-        Xyzz<F> q = xyzz_load<F>(parts + (uint64_t)XB * ((uint64_t)j * npoints + i));
-        xyzz_add(acc, q);
+        const Xyzz<F> q = xyzz_load<F>(parts + (uint64_t)XB * ((uint64_t)j * npoints + i));
+        xyzz_add_impl(acc, q);
     }
     xyzz_store<F>(out + (uint64_t)XB * i, acc);
 }
@@ -1043,7 +1046,7 @@ int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_o
 }
 int xyzz_sum_columns(Curve curve, void* d_out, const void* d_parts, uint32_t count, uint32_t npoints, hipStream_t s) {
     if (curve == CURVE_G1) hipLaunchKernelGGL(k_xyzz_sum_columns<Fp>, grid_for(npoints, 64), dim3(64), 0, s, (uint8_t*)d_out, (const uint8_t*)d_parts, count, npoints);
-    else hipLaunchKernelGGL(k_xyzz_sum_columns<Fp2>, grid_for(npoints, 64), dim3(64), 0, s, (uint8_t*)d_out, (const uint8_t*)d_parts, count, npoints);
+    else hipLaunchKernelGGL(k_xyzz_sum_columns<Fp2H>, grid_for(2 * (uint64_t)npoints, 64), dim3(64), 0, s, (uint8_t*)d_out, (const uint8_t*)d_parts, count, npoints);
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
