@@ -101,3 +101,17 @@ def test_bench_line_of_a_real_one_gpu_run_is_compact_and_complete():
     assert d["parity"].startswith("passed") and [o["parity"] for o in d["other_workloads"]] == [True]
     detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
     assert detail["roofline_g1"] and detail["roofline_g2"] and detail["cpu_baseline"]["ladder"] and detail["proof_compressed_hex"]
+
+
+@pytest.mark.gpu
+def test_bench_device_list_runs_the_one_process_multi_device_path():
+    """`python bench.py --device-list 0,0`: ONE process, one key handle sharded over two entries of the device list (the path an OCaml host takes:
+    zk_set_device_list, csrc/groth16_multi.hip) -- both entries are the one card of the test box, so the line must call itself a rehearsal; the parity
+    gate compares the last timed proof with the oracle's trapdoor evaluation (groth16.ml:123-161: the bytes do not depend on how the sums are cut)."""
+    import json
+    res = _bench(["--device-list", "0,0", "--log-n", "12", "--steps", "2", "--warmup", "1", "--settle", "0", "--headline-only", "--no-cpu-baseline"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["config"]["device_list"] == [0, 0] and d["config"]["rehearsal_ranks_share_gpus"] is True
+    assert d["config"]["key_form"] == "tau_powers_uploaded_lagrange_derived_on_device" and d["config"]["tau_power_value"] > 0          # the multi-device derivation ran too
+    assert d["parity"].startswith("passed") and "device list [0, 0]" in d["config"]["sharding"]
