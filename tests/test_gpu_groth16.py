@@ -507,6 +507,50 @@ def test_every_form_of_the_bucket_reduction_gives_the_same_proof(c):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("c,witness", [(16, "random"), (20, "random"), (16, "bits"), (20, "bits")])
+def test_two_level_sort_plain_and_staged_scatter_give_the_same_proof(c, witness):
+    """The counting sort's second level (msm.hip: k_sort_fine, and k_sort_fine_staged which lays a tile of references out in LDS before storing them;
+    ZK_SORT_FINE_STAGED, read per call) forced on at a size the suite proves in a second (ZK_SORT_TWO_LEVEL_MIN, read when the key is built), with a
+    random-looking witness and with one whose values are mostly 0 / 1 (one fine bucket takes most of a tile): the trapdoor oracle's bytes
+    (groth16.ml:116-161)."""
+    n = 1 << 13
+    rng = seeded_rng(0x5EED0212)
+    if witness == "random":
+        cs, w = RC.iterated_cubic(n, next(P.fr_stream(0x5EED0211)))
+    else:
+        # gate i: v_i * v_i = v_i for nine variables in ten (bits), v_i * ONE = v_i for the tenth (any value)
+        free = [i % 10 == 9 for i in range(n)]
+        Lm = RC.Matrix.from_rows([{1 + i: 1} for i in range(n)])
+        Rm = RC.Matrix.from_rows([{0: 1} if free[i] else {1 + i: 1} for i in range(n)])
+        Om = RC.Matrix.from_rows([{1 + i: 1} for i in range(n)])
+        mid = np.ones(n + 1, dtype=np.uint8); mid[0] = 0; mid[n] = 0
+        cs = RC.R1CS(n, n + 1, Lm, Rm, Om, mid)
+        w = [1] + [rng() if free[i] else rng() & 1 for i in range(n)]
+    toxic = [rng() for _ in range(5)]
+    r, s = rng(), rng()
+    L, R_, Oo = csrs(cs)
+    e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
+    pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
+    expect = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
+    names = ("ZK_MSM_WINDOW", "ZK_SORT_TWO_LEVEL_MIN", "ZK_SORT_FINE_STAGED")
+    old = {k: os.environ.get(k) for k in names}
+    try:
+        os.environ["ZK_MSM_WINDOW"], os.environ["ZK_SORT_TWO_LEVEL_MIN"] = str(c), "10"
+        prover = Groth16(cs, pk)
+        for staged in ("0", "1"):
+            os.environ["ZK_SORT_FINE_STAGED"] = staged
+            for _ in range(2):                              # twice: the tile counters must be left clean
+                proof = prover.prove_rs(w, r, s)
+                assert (proof.a, proof.b, proof.c) == expect, "window %d staged %s witness %s" % (c, staged, witness)
+        prover.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 SWEEP_WINDOWS = (12, 14, 15, 17, 20)      # 17, 20: beyond the LDS histogram -- the two-level counting sort
 
 

@@ -478,6 +478,10 @@ __global__ __launch_bounds__(1024) void k_scan(SortJobs jobs, uint32_t nb) {
 // atomic, no separate scan launch), and scatters the references with LDS cursors.  A bin that swallowed a skewed share of the
 // digits (boolean-heavy witnesses) is simply a longer loop for its workgroup: the per-record work is a few instructions.
 static constexpr uint32_t SORT_MAX_FINE = 4096;
+// (scalar, window) pairs per coarse bin from which the second level stages its scatter through LDS (k_sort_fine_staged): measured on the pipelined
+// prover -- 2^16 constraints (2 k pairs per bin, a quarter of a tile) -1.3 %, 2^18 (8 k) -0.6 %, 2^20 (c = 20: 27 k) +0.1 % with the lone proof 0.4 ms shorter and
+// the sort's un-overlapped time 1.95 -> 1.50 ms, 2^22 (106 k) +1.1 % and 8.0 -> 6.0 ms
+static constexpr uint64_t SORT_FINE_STAGED_MIN = 16384;
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint32_t fine_bits, uint32_t nbins, uint32_t nb) {
     const uint2* __restrict__ rec = jobs.sorted2[blockIdx.y];
     const uint32_t* __restrict__ coff = jobs.cursor[blockIdx.y];          // coarse offsets (level 1 left them in its cursor array)
@@ -533,6 +537,134 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_fine(SortJobs jobs, uint3
         rn = in < hi ? rec[in] : make_uint2(0, 0);
         const uint32_t pos = wave_aggregated_add(cnt, ok, r.x & fm);
         if (ok) sorted[pos] = r.y;
+    }
+}
+
+// The same level-2 pass with its scatter STAGED through LDS (round 4; ZK_SORT_FINE_STAGED): the plain form stores every 4-byte reference on its own,
+// scattered over the bin's ~130 KB output range -- the counters see 1.53 GB written per 2^20 proof for 272 MB of references (lines leave the L2 half
+// written).  Here a workgroup takes its bin in tiles of 8 k records, ranks the tile's records per fine bucket (LDS atomics), scans the tile's counts,
+// lays the references out in bucket order in LDS and writes them from there: consecutive threads store the consecutive references of a bucket (runs of
+// ~8 = 32 bytes at 2^20 and 2^22, where c = 20 leaves 1024 fine buckets per bin, and the next tile continues every run).  Counters at 2^20: this kernel's writes 1.53 GB -> 0.51 GB per proof, all
+// kernels' 5.50 -> 4.47 GB (profiles/r04_sort_fine_staged.txt).  Counting pass, scan and offsets as in k_sort_fine.
+static constexpr uint32_t SORT_TILE_PER_THREAD = 8, SORT_TILE = SORT_THREADS * SORT_TILE_PER_THREAD;
+static inline size_t sort_fine_staged_lds(uint32_t fine_bits) { return 4 * ((size_t)2 << fine_bits); }          // cnt + tcnt
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_fine_staged(SortJobs jobs, uint32_t fine_bits, uint32_t nbins, uint32_t nb) {
+    const uint2* __restrict__ rec = jobs.sorted2[blockIdx.y];
+    const uint32_t* __restrict__ coff = jobs.cursor[blockIdx.y];
+    uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
+    uint32_t* __restrict__ sorted = jobs.sorted[blockIdx.y];
+    extern __shared__ uint32_t sort_dyn[];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x, nf = 1u << fine_bits, fm = nf - 1, lane = t & 63u, wv = t >> 6;
+    uint32_t* cnt = sort_dyn;                        // pass 1: counts; then every bucket's cursor in the output
+    uint32_t* tcnt = sort_dyn + nf;                  // per tile: counts, then (count << 16 | exclusive offset inside the tile)
+    __shared__ uint32_t part[SORT_THREADS];
+    __shared__ uint32_t st_val[SORT_TILE];           // the tile's references in bucket order ...
+    __shared__ uint16_t st_key[SORT_TILE];           // ... and the bucket of each
+    const uint32_t lo = coff[bin], hi = coff[bin + 1];
+    for (uint32_t f = t; f < nf; f += SORT_THREADS) { cnt[f] = 0; tcnt[f] = 0; }
+    __syncthreads();
+    uint32_t kn = lo + t < hi ? rec[lo + t].x : 0;
+    for (uint32_t base = lo; base < hi; base += SORT_THREADS) {
+        const uint32_t i = base + t;
+        const bool ok = i < hi;
+        const uint32_t key = kn & fm;
+        const uint32_t in = i + SORT_THREADS;
+        kn = in < hi ? rec[in].x : 0;
+        (void)wave_aggregated_add(cnt, ok, ok ? key : 0);
+    }
+    __syncthreads();
+    const uint32_t per = (nf + SORT_THREADS - 1) / SORT_THREADS;          // <= 4 (SORT_MAX_FINE)
+    {
+        uint32_t s = 0;
+        for (uint32_t k = 0; k < per; k++) { const uint32_t f = t * per + k; if (f < nf) s += cnt[f]; }
+        part[t] = s;
+        __syncthreads();
+        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+            const uint32_t v = t >= d ? part[t - d] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        uint32_t run = lo + part[t] - s;
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t f = t * per + k;
+            if (f < nf) {
+                const uint32_t c = cnt[f];
+                offsets[(uint64_t)bin * nf + f] = run;
+                cnt[f] = run;
+                run += c;
+            }
+        }
+        if (bin == nbins - 1 && t == 0) offsets[nb] = hi;
+    }
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += SORT_TILE) {
+        const uint32_t tile = hi - base < SORT_TILE ? hi - base : SORT_TILE;
+        uint32_t f[SORT_TILE_PER_THREAD], v[SORT_TILE_PER_THREAD], rk[SORT_TILE_PER_THREAD];
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_TILE_PER_THREAD; k++) {          // whole waves: the aggregated add ballots
+            const uint32_t j = k * SORT_THREADS + t;
+            const bool ok = j < tile;
+            const uint2 r = ok ? rec[base + j] : make_uint2(0, 0);
+            f[k] = r.x & fm;
+            v[k] = r.y;
+            rk[k] = wave_aggregated_add(tcnt, ok, ok ? f[k] : 0);
+        }
+        __syncthreads();
+        {   // exclusive scan of the tile's counts (each thread owns `per` consecutive buckets): wave shuffles + sixteen wave totals
+            uint32_t c[4], s = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t ff = t * per + k;
+                c[k] = k < per && ff < nf ? tcnt[ff] : 0;
+                s += c[k];
+            }
+            uint32_t incl = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= (uint32_t)d) incl += y;
+            }
+            if (lane == 63) part[wv] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < SORT_THREADS / 64; w++) before += w < wv ? part[w] : 0u;
+            uint32_t run = before + incl - s;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t ff = t * per + k;
+                if (k < per && ff < nf) {
+                    tcnt[ff] = run | (c[k] << 16);          // offset in the tile (< 8192: 13 bits) | the tile's count of this bucket (<= 8192: 14 bits)
+                    run += c[k];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_TILE_PER_THREAD; k++) {
+            const uint32_t j = k * SORT_THREADS + t;
+            if (j < tile) {
+                const uint32_t slot = (tcnt[f[k]] & 0xffffu) + rk[k];
+                st_val[slot] = v[k];
+                st_key[slot] = (uint16_t)f[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < SORT_TILE_PER_THREAD; k++) {          // slot j holds reference number (j - offset) of its bucket in this tile
+            const uint32_t j = k * SORT_THREADS + t;
+            if (j < tile) {
+                const uint32_t ff = st_key[j];
+                sorted[cnt[ff] + j - (tcnt[ff] & 0xffffu)] = st_val[j];
+            }
+        }
+        __syncthreads();
+        for (uint32_t ff = t; ff < nf; ff += SORT_THREADS) {
+            cnt[ff] += tcnt[ff] >> 16;
+            tcnt[ff] = 0;
+        }
+        __syncthreads();
     }
 }
 
@@ -905,7 +1037,10 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             hipLaunchKernelGGL(k_sort_scatter_lds<SORT_FEW_BINS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
             SortJobs l2 = sj;
             for (uint32_t i = 0; i < count; i++) l2.cursor[i] = l1.offsets[i];          // the coarse offsets (k_scan wrote offsets = cursor; the scatter advanced neither: it ranks in LDS)
-            hipLaunchKernelGGL(k_sort_fine, dim3(bins, count), dim3(SORT_THREADS), 0, s, l2, w.sort_fine_bits, bins, w.nbuckets);
+            const char* e_st = ZK_FORM_ENV("ZK_SORT_FINE_STAGED");          // a kernel-form switch (zk_common.h)
+            const bool staged = e_st ? atoi(e_st) != 0 : b.n * b.nw / bins >= SORT_FINE_STAGED_MIN;
+            if (staged) hipLaunchKernelGGL(k_sort_fine_staged, dim3(bins, count), dim3(SORT_THREADS), sort_fine_staged_lds(w.sort_fine_bits), s, l2, w.sort_fine_bits, bins, w.nbuckets);
+            else hipLaunchKernelGGL(k_sort_fine, dim3(bins, count), dim3(SORT_THREADS), 0, s, l2, w.sort_fine_bits, bins, w.nbuckets);
         } else if (w.sort_wgs) {
             const uint64_t total = sm ? b.n : b.n * b.nw, per_wg = (total + w.sort_wgs - 1) / w.sort_wgs;
             hipLaunchKernelGGL(k_sort_count_lds<SORT_MAX_BUCKETS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, sj, da, per_wg, w.nbuckets);
