@@ -509,8 +509,8 @@ def test_every_form_of_the_bucket_reduction_gives_the_same_proof(c):
 
 @pytest.mark.parametrize("c,witness", [(16, "random"), (20, "random"), (16, "bits"), (20, "bits")])
 def test_two_level_sort_plain_and_staged_scatter_give_the_same_proof(c, witness):
-    """The counting sort's second level (msm.hip: k_sort_fine, and k_sort_fine_staged which lays a tile of references out in LDS before storing them;
-    ZK_SORT_FINE_STAGED, read per call) forced on at a size the suite proves in a second (ZK_SORT_TWO_LEVEL_MIN, read when the key is built), with a
+    """The counting sort's two levels (msm.hip: k_sort_scatter_lds / k_sort_fine, and k_sort_scatter_staged / k_sort_fine_staged which lay a tile of
+    records out in LDS before storing them; ZK_SORT_COARSE_STAGED, ZK_SORT_FINE_STAGED, read per call) forced on at a size the suite proves in a second (ZK_SORT_TWO_LEVEL_MIN, read when the key is built), with a
     random-looking witness and with one whose values are mostly 0 / 1 (one fine bucket takes most of a tile): the trapdoor oracle's bytes
     (groth16.ml:116-161)."""
     n = 1 << 13
@@ -532,16 +532,16 @@ def test_two_level_sort_plain_and_staged_scatter_give_the_same_proof(c, witness)
     e1, e2, _ = O.groth16_setup_exponents(cs.n, cs.m, L, R_, Oo, cs.mid, frs(toxic))
     pk = PKey(G1.of_Fr(e1), G2.of_Fr(e2))
     expect = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
-    names = ("ZK_MSM_WINDOW", "ZK_SORT_TWO_LEVEL_MIN", "ZK_SORT_FINE_STAGED")
+    names = ("ZK_MSM_WINDOW", "ZK_SORT_TWO_LEVEL_MIN", "ZK_SORT_FINE_STAGED", "ZK_SORT_COARSE_STAGED")
     old = {k: os.environ.get(k) for k in names}
     try:
         os.environ["ZK_MSM_WINDOW"], os.environ["ZK_SORT_TWO_LEVEL_MIN"] = str(c), "10"
         prover = Groth16(cs, pk)
-        for staged in ("0", "1"):
-            os.environ["ZK_SORT_FINE_STAGED"] = staged
+        for coarse, staged in (("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")):
+            os.environ["ZK_SORT_COARSE_STAGED"], os.environ["ZK_SORT_FINE_STAGED"] = coarse, staged
             for _ in range(2):                              # twice: the tile counters must be left clean
                 proof = prover.prove_rs(w, r, s)
-                assert (proof.a, proof.b, proof.c) == expect, "window %d staged %s witness %s" % (c, staged, witness)
+                assert (proof.a, proof.b, proof.c) == expect, "window %d level 1 staged %s level 2 staged %s witness %s" % (c, coarse, staged, witness)
         prover.close()
     finally:
         for k, v in old.items():

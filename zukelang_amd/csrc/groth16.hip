@@ -314,7 +314,7 @@ static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint
         // cached); under ZK_TEST_FORMS=1 a slot's graphs are dropped whenever the switches differ from the ones they were captured under.
         if (forms_live()) {
             uint64_t h = 1469598103934665603ull;
-            for (const char* name : {"ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_RED_WAVES", "ZK_SORT_FINE_STAGED", "ZK_DS_WIDE_GROUP"}) {
+            for (const char* name : {"ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_RED_WAVES", "ZK_SORT_FINE_STAGED", "ZK_SORT_COARSE_STAGED", "ZK_DS_WIDE_GROUP"}) {
                 const char* v = getenv(name);
                 for (const char* q = v ? v : "\x01"; *q; q++) h = (h ^ (uint8_t)*q) * 1099511628211ull;
                 h = (h ^ 0xff) * 1099511628211ull;

@@ -307,6 +307,10 @@ static constexpr uint32_t SORT_MAX_BUCKETS = 32768;
 // other proofs in flight) or SORT_FEW_BINS for the 512 coarse bins of the two-level sort's first level (2 KiB: the sort of a 2^20 proof no longer
 // evicts the accumulate workgroups from the compute units it runs on)
 static constexpr uint32_t SORT_FEW_BINS = 512;
+// k_sort_scatter_staged (level 1 of the two-level sort with its records staged through LDS) -- measured at 2^20, same box: its writes 1.14 -> 0.74 GB per proof
+// (sort kernels 3.2 -> 2.8 GB as 2 FETCH + WRITE), but the launch is 2 % LONGER (the extra LDS pass and five barriers per tile cost more than the stores
+// save) and the pipelined prover loses 0.6-0.9 %: off unless ZK_SORT_COARSE_STAGED=1 (profiles/r04_sort_fine_staged.txt)
+static constexpr bool SORT_COARSE_STAGED_DEFAULT = false;
 template <uint32_t LDS_BINS>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_count_lds(SortJobs jobs, DigitArgs a, uint64_t per_wg, uint32_t nb) {
     const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
@@ -374,6 +378,77 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_lds(SortJobs jobs
         if (ok) {
             if (a.coarse_shift) jobs.sorted2[blockIdx.y][pos] = make_uint2(key, val);
             else sorted[pos] = val;
+        }
+    }
+}
+// Level 1 of the two-level sort with its 8-byte records STAGED through LDS (round 4; ZK_SORT_COARSE_STAGED): the plain scatter stores every record on its own
+// and the counters see 1.14 GB written per 2^20 proof for 545 MB of records.  Here the workgroup files the digits of COARSE_STAGE_WINDOWS windows of its 1024
+// scalars (<= 8 k records) per tile: rank per coarse bin with LDS atomics, scan the 512 tile counts, lay the records out in bin order in LDS and store them
+// from there -- consecutive lanes write the consecutive records of a bin (runs of ~16 = 128 bytes) and the next tile continues every run.  Scalar-major only.
+static constexpr uint32_t COARSE_STAGE_WINDOWS = 8, COARSE_STAGE_TILE = SORT_THREADS * COARSE_STAGE_WINDOWS;
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter_staged(SortJobs jobs, DigitArgs a, uint64_t per_wg, uint32_t nb) {
+    const uint32_t* __restrict__ scalars = jobs.scalars[blockIdx.y];
+    const uint32_t* __restrict__ base = jobs.wgcount[blockIdx.y];
+    const uint32_t* __restrict__ offsets = jobs.offsets[blockIdx.y];
+    uint2* __restrict__ out = jobs.sorted2[blockIdx.y];
+    __shared__ uint32_t cur[SORT_FEW_BINS];          // the workgroup's cursor in every coarse bin
+    __shared__ uint32_t tcnt[SORT_FEW_BINS];         // per tile: counts, then (count << 16 | exclusive offset inside the tile)
+    __shared__ uint32_t wtot[SORT_THREADS / 64];
+    __shared__ uint32_t tile_n;
+    __shared__ uint2 stage[COARSE_STAGE_TILE];
+    const uint32_t wg = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    for (uint32_t b = t; b < nb; b += SORT_THREADS) { cur[b] = offsets[b] + base[(uint64_t)wg * nb + b]; tcnt[b] = 0; }
+    __syncthreads();
+    const uint64_t lo = (uint64_t)wg * per_wg, hi = min(lo + per_wg, a.n);
+    for (uint64_t i0 = lo; i0 < hi; i0 += SORT_THREADS) {                           // whole waves: the aggregated add ballots
+        const uint64_t i = i0 + t;
+        uint32_t sk[9];
+        const bool live = i < hi && digits_prepare(scalars, i, a, sk);
+        for (uint32_t j0 = 0; j0 < a.nw; j0 += COARSE_STAGE_WINDOWS) {
+            uint32_t key[COARSE_STAGE_WINDOWS], val[COARSE_STAGE_WINDOWS], rk[COARSE_STAGE_WINDOWS];
+            uint32_t okm = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < COARSE_STAGE_WINDOWS; k++) {
+                key[k] = 0; val[k] = 0;
+                const bool ok = live && j0 + k < a.nw && digit_at(sk, i, j0 + k, a, key[k], val[k]);
+                rk[k] = wave_aggregated_add(tcnt, ok, key[k] >> a.coarse_shift);
+                okm |= (ok ? 1u : 0u) << k;
+            }
+            __syncthreads();
+            {   // exclusive scan of the tile's counts: one thread per bin (nb <= 512 <= SORT_THREADS)
+                const uint32_t c = t < nb ? tcnt[t] : 0;
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = (uint32_t)__shfl_up((int)incl, d);
+                    if (lane >= (uint32_t)d) incl += y;
+                }
+                if (lane == 63) wtot[wv] = incl;
+                __syncthreads();
+                uint32_t before = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < SORT_THREADS / 64; w++) before += w < wv ? wtot[w] : 0u;
+                if (t < nb) tcnt[t] = (before + incl - c) | (c << 16);          // offset < 8192 (13 bits) | count <= 8192 (14 bits)
+                if (t == SORT_THREADS - 1) tile_n = before + incl;
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < COARSE_STAGE_WINDOWS; k++)
+                if (okm >> k & 1u) stage[(tcnt[key[k] >> a.coarse_shift] & 0xffffu) + rk[k]] = make_uint2(key[k], val[k]);
+            __syncthreads();
+            const uint32_t tn = tile_n;
+#pragma unroll
+            for (uint32_t k = 0; k < COARSE_STAGE_WINDOWS; k++) {          // slot q holds record number (q - offset) of its bin in this tile
+                const uint32_t q = k * SORT_THREADS + t;
+                if (q < tn) {
+                    const uint2 r = stage[q];
+                    const uint32_t bin = r.x >> a.coarse_shift;
+                    out[cur[bin] + q - (tcnt[bin] & 0xffffu)] = r;
+                }
+            }
+            __syncthreads();
+            if (t < nb) { cur[t] += tcnt[t] >> 16; tcnt[t] = 0; }
+            __syncthreads();
         }
     }
 }
@@ -1034,7 +1109,10 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             gc.y = count;
             hipLaunchKernelGGL(k_sort_colscan, gc, dim3(256), 0, s, l1, bins, w.sort_wgs);
             hipLaunchKernelGGL(k_scan, dim3(count), dim3(1024), 0, s, l1, bins);
-            hipLaunchKernelGGL(k_sort_scatter_lds<SORT_FEW_BINS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
+            const char* e_cs = ZK_FORM_ENV("ZK_SORT_COARSE_STAGED");          // a kernel-form switch (zk_common.h)
+            const bool coarse_staged = sm && (e_cs ? atoi(e_cs) != 0 : SORT_COARSE_STAGED_DEFAULT);
+            if (coarse_staged) hipLaunchKernelGGL(k_sort_scatter_staged, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
+            else hipLaunchKernelGGL(k_sort_scatter_lds<SORT_FEW_BINS>, dim3(w.sort_wgs, count), dim3(SORT_THREADS), 0, s, l1, d1, per_wg, bins);
             SortJobs l2 = sj;
             for (uint32_t i = 0; i < count; i++) l2.cursor[i] = l1.offsets[i];          // the coarse offsets (k_scan wrote offsets = cursor; the scatter advanced neither: it ranks in LDS)
             const char* e_st = ZK_FORM_ENV("ZK_SORT_FINE_STAGED");          // a kernel-form switch (zk_common.h)

@@ -109,7 +109,7 @@ void profile_count(const char* name, uint64_t add);      // no-op unless profili
 // Environment knobs are read ONCE per process (tuning switches; a getenv per launch is a libc lock + string scan on the proof's hot path): a C++11
 // function-local static per call site, initialised thread-safely by the language.
 #define ZK_ENV(name) ([]() -> const char* { static const char* const v = getenv(name); return v; }())
-// The kernel-FORM switches of a proof (msm.hip msm_reduce_mixed: ZK_TAIL_SLOTS, ZK_TAIL_FIXUP_SLOTS, ZK_FIXUP_BY_CHUNK, ZK_DS_WIDE_GROUP; msm_sort_accumulate_many: ZK_SORT_FINE_STAGED; msm_red.hip: ZK_RED_WAVES; msm_acc_g1/g2.hip:
+// The kernel-FORM switches of a proof (msm.hip msm_reduce_mixed: ZK_TAIL_SLOTS, ZK_TAIL_FIXUP_SLOTS, ZK_FIXUP_BY_CHUNK, ZK_DS_WIDE_GROUP; msm_sort_accumulate_many: ZK_SORT_FINE_STAGED, ZK_SORT_COARSE_STAGED; msm_red.hip: ZK_RED_WAVES; msm_acc_g1/g2.hip:
 // ZK_ACC_G1_GLDS, ZK_ACC_G1_MMADD, ZK_ACC_G2_INLINE; groth16.hip: ZK_GRAPH) are cached like every other knob -- a proof costs no getenv at all --
 // unless the process was started with ZK_TEST_FORMS=1 (tests/conftest.py sets it): then they are read per call, so that the GPU suite can hold every
 // form to the oracle inside one process.  forms_live() is that one cached test-mode flag.
