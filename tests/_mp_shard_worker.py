@@ -4,6 +4,7 @@ mode "cpu": world_size ranks on the CPU with gloo.  The per-rank partial product
             the ORACLE over the rank's slice of the key pools (no GPU here), exchanged with the
             product's all_gather_bytes, summed, and compared with the single-rank oracle proof:
             covers the slicing rule, the scalar-vector layout, the exchange and its ordering.
+mode "gpu-rccl": mode "gpu" over backend nccl (RCCL), one rank per device -- a world of one on the one-GPU box.
 mode "gpu": the real path: every rank uploads its slice to the (shared) GPU, proves its partial
             sums with the HIP kernels, all-gathers 768 B per rank, combines on the GPU.
 """
@@ -30,7 +31,14 @@ def frs(xs):
 def main():
     mode = sys.argv[1]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-    dist.init_process_group("gloo")
+    if mode == "gpu-rccl":
+        # the RCCL branches of the collectives (device tensors, all_gather_into_tensor, all_to_all_single with splits, broadcast) on a REAL
+        # communicator: one rank per device, so on the one-GPU box that is a world of one -- self-collectives through the code N ranks run
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     cs, w = RC.iterated_cubic(n, 0xFEED)
     csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
@@ -208,6 +216,16 @@ def main():
             e2 = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(rr), P.fr_to_bytes(ss))
             assert (pr.a, pr.b, pr.c) == e2, "rank %d: proof after the failed round differs" % rank
         prover.close()
+        if mode == "gpu-rccl":
+            import torch
+            from zukelang_amd.groth16 import agree_on_status, exchange_slices
+            assert dist.get_backend() == "nccl"
+            blk = np.arange(768, dtype=np.uint8)
+            assert bytes(all_gather_bytes(blk, world)) == bytes(blk) * world
+            vec = torch.from_numpy(np.frombuffer(frs(list(range(1, 41))), dtype=np.uint8).copy()).cuda()
+            got = exchange_slices(vec, [(5, 29)], rank, world)
+            assert got.is_cuda and bytes(got.cpu().numpy()) == frs(list(range(6, 30)))
+            assert agree_on_status(-4) == -4
     dist.barrier()
     if rank == 0:
         print("MP-OK", mode, world, n)

@@ -38,6 +38,15 @@ def test_point_sharded_prove_gpu(world, n):
     _run("gpu", world, n)
 
 
+@pytest.mark.gpu
+def test_rccl_branches_of_the_collectives_on_a_real_communicator_world_of_one():
+    """Every `dist.get_backend() == "nccl"` branch of zukelang_amd/groth16.py (device-resident partial sums, all_gather_into_tensor,
+    all_to_all_single with per-destination splits, zk_groth16_combine_device) on a real RCCL communicator.  One rank per device is all
+    RCCL allows, so the one-GPU box runs a world of one: the collectives are self-exchanges, the code path is the one N ranks take, and the
+    proofs must be the trapdoor oracle's."""
+    _run("gpu-rccl", 1, 1000)
+
+
 def _bench(args, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     env.pop("WORLD_SIZE", None)
