@@ -20,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 frb = P.fr_to_bytes
 t_end = time.time() + budget
-n_msm = n_g16 = n_pin = n_der = n_ba = n_multi = n_rns = 0
+n_msm = n_g16 = n_pin = n_der = n_ba = n_multi = n_rns = n_sort = 0
 _lib.check(_lib.lib().zk_init(0))
 while time.time() < t_end:
     # ---- MSM with duplicates, negations, identity, tiny / huge / zero scalars
@@ -118,6 +118,25 @@ while time.time() < t_end:
         finally:
             del os.environ["ZK_FR_RNS"]
         n_rns += 1
+    if n_g16 % 4 == 2:
+        # round 4: the two-level counting sort forced on at this size (ZK_SORT_TWO_LEVEL_MIN, ZK_MSM_WINDOW: read when the key is built) with its two
+        # scatters plain or staged through LDS (ZK_SORT_COARSE_STAGED, ZK_SORT_FINE_STAGED: read per call), proofs in flight on several slots
+        os.environ["ZK_SORT_TWO_LEVEL_MIN"], os.environ["ZK_MSM_WINDOW"] = "8", str(rnd.choice([16, 20, 22]))
+        try:
+            pr = Groth16(cs, pk, lagrange=rnd.random() < 0.5)
+            pr.set_witness(w)
+            for _ in range(2):
+                os.environ["ZK_SORT_COARSE_STAGED"], os.environ["ZK_SORT_FINE_STAGED"] = rnd.choice("01"), rnd.choice("01")
+                for slot in range(3):
+                    pr.prove_async(None, r, s, slot)
+                for slot in range(3):
+                    p = pr.prove_wait(slot)
+                    assert (p.a, p.b, p.c) == exp, ("Groth16 mismatch with the two-level sort", n, dict((k, os.environ[k]) for k in os.environ if k.startswith("ZK_SORT") or k == "ZK_MSM_WINDOW"))
+            pr.close()
+        finally:
+            for k in ("ZK_SORT_TWO_LEVEL_MIN", "ZK_MSM_WINDOW", "ZK_SORT_COARSE_STAGED", "ZK_SORT_FINE_STAGED"):
+                os.environ.pop(k, None)
+        n_sort += 1
     n_g16 += 1
     # ---- every fourth round: Pinocchio ZK prove at a random size against the trapdoor evaluation, then the product's verifier
     if n_g16 % 4 == 0:
@@ -141,5 +160,5 @@ while time.time() < t_end:
         n_pin += 1
     if (n_msm % 10) == 0:
         print("soak: %d MSM cases, %d Groth16 cases (%d multi-device, %d RNS), %d Pinocchio cases ok" % (n_msm, n_g16, n_multi, n_rns, n_pin), flush=True)
-print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds, %d behind a multi-device handle, %d through the residue number system) pinocchio=%d"
-      % (n_msm, n_g16, n_der, n_ba, n_multi, n_rns, n_pin))
+print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds, %d behind a multi-device handle, %d through the residue number system, %d through the forced two-level sort in its plain / staged forms) pinocchio=%d"
+      % (n_msm, n_g16, n_der, n_ba, n_multi, n_rns, n_sort, n_pin))

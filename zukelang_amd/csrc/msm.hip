@@ -1002,7 +1002,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     if (b.precomp && w.nbuckets >= SORT_MAX_BUCKETS && w.nbuckets / COARSE_BINS <= SORT_MAX_FINE && maxN >= ((uint64_t)1 << two_level_min) && two_level != 0) {
         w.sort_fine_bits = ceil_log2(w.nbuckets / COARSE_BINS);
         uint64_t wgs = maxN / (4 * (uint64_t)COARSE_BINS);
-        w.sort_wgs = (uint32_t)(wgs > 256 ? 256 : wgs);
+        w.sort_wgs = (uint32_t)(wgs > 256 ? 256 : wgs < 1 ? 1 : wgs);          // < 1: only when ZK_SORT_TWO_LEVEL_MIN forces the two levels on a handful of pairs
         ZKCHK(w.wgcount.alloc(4 * (size_t)COARSE_BINS * w.sort_wgs));
         ZKCHK(w.sorted2.alloc(8 * (size_t)maxN));
         ZKCHK(w.coarse.alloc(4 * (size_t)3 * (COARSE_BINS + 1)));
