@@ -422,7 +422,7 @@ def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, w
     # `tau_power_form` keeps the first.
     derive = derive_upto is not None and log_n <= derive_upto and world == 1 and not lagrange
     if derive and not args.derived_only and args.time_budget > 0:
-        est = 36.0 * n / (1 << 20) * (1.08 if log_n > 20 else 1.0) + 12.0 * n / (1 << 22)          # derivation + the second measurement and its parity check
+        est = 31.0 * n / (1 << 20) * (1.08 if log_n > 20 else 1.0) + 12.0 * n / (1 << 22)          # derivation + the second measurement and its parity check
         spent = time.perf_counter() - T_START
         if spent + est > args.time_budget:
             print("bench.py: %.0f s spent, the 2^%d derivation (~%.0f s) does not fit --time-budget %.0f: this workload reports the key as uploaded only" % (spent, log_n, est, args.time_budget), file=sys.stderr)
@@ -741,7 +741,7 @@ def main():
     ap.add_argument("--derive-lagrange-upto", type=int, default=22, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
                     "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.7 s at 2^16, 6.7 s at 2^18, 31 s at 2^20, 147 s at 2^22) and "
                     "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
-    ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock the whole run aims to stay within: a derivation whose estimate (34 s x n / 2^20) does not fit what is left "
+    ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock the whole run aims to stay within: a derivation whose estimate (31 s x n / 2^20, 8 % more above 2^20) does not fit what is left "
                     "is skipped and that workload reports its tau-power figure only (the default run is ~5 min with the 147 s derivation of the 2^22 key)")
     ap.add_argument("--host-witness", action="store_true", help="one GPU: hand the witness over as a host buffer with every proof (the PCIe-inclusive rate of DESIGN.md 8) instead of "
                     "proving from the copy made resident by zk_groth16_set_witness; never the headline")

@@ -630,6 +630,13 @@ def test_lagrange_bases_derived_in_the_exponent(maker):
     with pytest.raises(AssertionError):
         prover.prove_rs(w_bad, r, s)
     prover.derive_lagrange()                                    # idempotent
+    # a derived key stored by one process and uploaded by the next (zk_groth16_pool_points -> zk_groth16_pk_upload_lagrange),
+    # with NOTHING taken from the keygen that knows tau: the same proof
+    stored = PKey(pk.g1, pk.g2, np.array(prover.pool_points(1), copy=True), np.array(prover.pool_points(2), copy=True))
+    again = Groth16(cs, stored, lagrange=True)
+    p2 = again.prove_rs(w, r, s)
+    again.close()
+    assert (p2.a, p2.b, p2.c) == exp
     # QAP.eval (coefficient vectors) stays available on the derived key
     if cs.n <= 100:
         q = O.QAP(cs.n, cs.m, *csrs(cs))

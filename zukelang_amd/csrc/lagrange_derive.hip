@@ -369,17 +369,20 @@ template <class T> __global__ void k_raw_to_aff(uint8_t* __restrict__ dst, const
 // inverse = DIT (bit-reversed -> natural, unscaled) -- the conventions of ntt.hip, so the Fr tables line up.  tw[h + j] = w_2h^(+-j).
 // Two waves per SIMD for both curves (G1: 256 registers, 0 / 69 spilled; G2: see ZK_DERIVE_G2_WAVES above).
 template <class T, bool INVERSE>
-__global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : ZK_DERIVE_G2_WAVES)) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t b0, uint64_t pairs, uint8_t* __restrict__ scratch) {
+__global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : ZK_DERIVE_G2_WAVES)) void k_gntt_stage(uint8_t* __restrict__ pts, const uint32_t* __restrict__ tw, uint32_t log_h, uint64_t b0, uint64_t pairs, uint32_t log_pairs, uint8_t* __restrict__ scratch) {
     constexpr int XB = RawLayout<T>::XYZZ;
     const uint64_t loc = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / LaneCount<T>::N, b = b0 + loc;      // a slab of butterflies per launch
     if (b >= pairs) return;
     uint8_t* tab = scratch + (uint64_t)16 * XB * loc;
-    const uint64_t h = (uint64_t)1 << log_h, j = b & (h - 1), e = ((b >> log_h) << (log_h + 1)) | j;
+    // butterfly b = (j, q) in j-MAJOR order (q = the block of 2h points, q < pairs / h): the butterflies with twiddle w^0 = 1 -- one in h, a tenth of a
+    // derivation's scalar multiplications over the levels of the tree -- then fill whole waves, which skip the multiplication (a wave-uniform test;
+    // in block-major order they sat in every h-th lane and saved nothing).  These kernels are bound by their arithmetic: the stride costs nothing.
+    const uint64_t h = (uint64_t)1 << log_h, nq = pairs >> log_h, q = b & (nq - 1), j = b >> (log_pairs - log_h), e = (q << (log_h + 1)) | j;
     const uint32_t* w = tw + 8 * (h + j);
     // nothing but the multiplicand stays live across the scalar multiplication (a second point in registers there costs hundreds of spills)
     if (INVERSE) {
         Xyzz<T> v = xyzz_load_raw<T>(pts + XB * (e + h));
-        if (log_h) v = xyzz_mul_scalar_endo(v, w, tab);      // span 2: the twiddle is 1 (wave-uniform test)
+        if (j) v = xyzz_mul_scalar_endo(v, w, tab);          // j = 0: the twiddle is 1
         Xyzz<T> u = xyzz_load_raw<T>(pts + XB * e);
         Xyzz<T> x = u;
         xyzz_add_impl(x, v);
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(128, (std::is_same<T, Fp>::value ? 2 : ZK_DERIVE_G2
         }
         v.y = neg_coord(v.y);
         xyzz_add_impl(u, v);                                // u - v
-        if (log_h) u = xyzz_mul_scalar_endo(u, w, tab);
+        if (j) u = xyzz_mul_scalar_endo(u, w, tab);
         xyzz_store_raw<T>(pts + XB * (e + h), u);
     }
 }
@@ -410,6 +413,7 @@ template <class T> __global__ __launch_bounds__(128, (std::is_same<T, Fp>::value
 }
 // scalar multiplications per launch: bounds the scratch of the window tables (16 multiples each) to 1 (G1) / 2 (G2) GiB
 static constexpr uint64_t DERIVE_SLAB = (uint64_t)1 << 18;
+static constexpr uint32_t DERIVE_SIDE_BY_SIDE_MAX_LOG = 22;          // measured: see groth16_derive_lagrange_pools
 template <class T> static int g_tabmul(uint8_t* pts, const uint32_t* tab, uint64_t total, uint8_t* scratch, hipStream_t s) {
     for (uint64_t i0 = 0; i0 < total; i0 += DERIVE_SLAB) {
         const uint64_t cnt = total - i0 < DERIVE_SLAB ? total - i0 : DERIVE_SLAB;
@@ -520,24 +524,32 @@ static int derive_tables_build(DeriveTables& t, const FrStage& f, uint32_t offse
 
 template <class T> static int gntt(uint8_t* pts, uint64_t total, uint32_t log_len, bool inverse, const DeriveTables& t, uint8_t* scratch, hipStream_t s) {
     const uint64_t pairs = total / 2;
+    if (log_len == 0) return ZK_OK;
+    if (pairs == 0 || (pairs & (pairs - 1))) ZK_FAIL(ZK_ERR_ARG, "derive: a transform array must hold a power of two of points");
+    uint32_t log_pairs = 0;
+    while (((uint64_t)1 << log_pairs) < pairs) log_pairs++;
     for (uint32_t st = 0; st < log_len; st++) {
         const uint32_t log_h = inverse ? st : log_len - 1 - st;
         for (uint64_t b0 = 0; b0 < pairs; b0 += DERIVE_SLAB) {
             const uint64_t cnt = pairs - b0 < DERIVE_SLAB ? pairs - b0 : DERIVE_SLAB;
             const dim3 g = g1d(cnt * LaneCount<T>::N, 128);
-            if (inverse) hipLaunchKernelGGL((k_gntt_stage<T, true>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_i.as<uint32_t>(), log_h, b0, pairs, scratch);
-            else hipLaunchKernelGGL((k_gntt_stage<T, false>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_f.as<uint32_t>(), log_h, b0, pairs, scratch);
+            if (inverse) hipLaunchKernelGGL((k_gntt_stage<T, true>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_i.as<uint32_t>(), log_h, b0, pairs, log_pairs, scratch);
+            else hipLaunchKernelGGL((k_gntt_stage<T, false>), g, dim3(128), 0, s, pts, (const uint32_t*)t.tw_f.as<uint32_t>(), log_h, b0, pairs, log_pairs, scratch);
         }
     }
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
 // src: n dense affine points [x^k], k < n (device);  dst: n dense affine points, the Lagrange-form bases of the tables' points
-template <class T> static int derive_set(const DeriveTables& t, const uint8_t* d_src, uint32_t n, uint8_t* d_dst, hipStream_t s) {
+// working arrays of one set: they outlive the enqueue (the sets of a key run side by side on their own streams)
+struct DeriveWork {
+    DevBuf A, W, scr;
+};
+template <class T> static int derive_set_enqueue(DeriveWork& wk, const DeriveTables& t, const uint8_t* d_src, uint32_t n, uint8_t* d_dst, hipStream_t s) {
     constexpr size_t XB = RawLayout<T>::XYZZ;
     constexpr uint32_t LP = LaneCount<T>::N;
     const uint32_t n2 = t.n2, S = 2 * n2;
-    DevBuf A, W, scr;
+    DevBuf &A = wk.A, &W = wk.W, &scr = wk.scr;
     ZKCHK(A.alloc(XB * S));
     ZKCHK(W.alloc(XB * (size_t)n2));
     ZKCHK(scr.alloc((size_t)16 * XB * (S < DERIVE_SLAB ? S : DERIVE_SLAB)));      // one table of 16 multiples per scalar multiplication of a launch
@@ -562,9 +574,23 @@ template <class T> static int derive_set(const DeriveTables& t, const uint8_t* d
     ZKCHK(g_tabmul<T>(A.as<uint8_t>(), (const uint32_t*)t.invfact.as<uint32_t>(), (uint64_t)n, sc, s));
     hipLaunchKernelGGL(k_raw_to_aff<T>, g1d((uint64_t)n * LP, 128), dim3(128), 0, s, d_dst, (const uint8_t*)A.as<uint8_t>(), (uint64_t)n);
     HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+template <class T> static int derive_set(const DeriveTables& t, const uint8_t* d_src, uint32_t n, uint8_t* d_dst, hipStream_t s) {
+    DeriveWork wk;
+    ZKCHK(derive_set_enqueue<T>(wk, t, d_src, n, d_dst, s));
     HIPCHK(hipStreamSynchronize(s));
     return ZK_OK;
 }
+// streams of the sets that run beside the caller's
+struct SideStreams {
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    ~SideStreams() {
+        for (hipStream_t x : st) if (x) { (void)hipStreamSynchronize(x); (void)hipStreamDestroy(x); }
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
 
 // Pools of a key in the reference's layout (device, dense affine)  g1 = a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid,  g2 = b2 | d2 | ti2[n+2]
 // -> the Lagrange-form pools  g1' = a | d1 | b1 | [l_i]_1 (n) | [lambda_t Z/delta]_1 (n-1) | ltd_mid,  g2' = b2 | d2 | [l_i]_2 (n)  (device, dense affine).
@@ -583,19 +609,45 @@ int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_
         HIPCHK(hipStreamSynchronize(s));
         return ZK_OK;
     }
-    if (sets & 3) {
-        ScopedTimer tm("lagrange_derive", s);
-        DeriveTables t0;
-        ZKCHK(derive_tables_build(t0, f, 0, s));
+    // The sets are independent, and a stage of one set is n2 / 2 scalar multiplications of ~2 ms (G1) / ~4 ms (G2) each: below 2^19 gates that is fewer
+    // waves than the chip has SIMDs (2^16: 512 of 1024 for a G1 set), and a stage takes one multiplication's latency however few waves it has.  Up to
+    // DERIVE_SIDE_BY_SIDE_MAX_LOG the selected sets therefore run side by side on their own streams (ZK_DERIVE_SIDE_BY_SIDE=0 / 1 overrides).
+    static const char* e_sbs = getenv("ZK_DERIVE_SIDE_BY_SIDE");
+    const bool several = (sets & (sets - 1)) != 0;
+    const bool side_by_side = several && (e_sbs ? atoi(e_sbs) != 0 : f.log_n2 <= DERIVE_SIDE_BY_SIDE_MAX_LOG);
+    ScopedTimer tm("lagrange_derive", s);
+    DeriveTables t0, tn;
+    if (sets & 3) ZKCHK(derive_tables_build(t0, f, 0, s));
+    if (sets & 4) ZKCHK(derive_tables_build(tn, f, n, s));          // the points n .. 2n-2 of the h values
+    if (!side_by_side) {
         if (sets & 1) ZKCHK(derive_set<Fp>(t0, d_g1 + 96 * o_ti, n, out_g1 + 96 * 3, s));
         if (sets & 2) ZKCHK(derive_set<Fp2H>(t0, d_g2 + 192 * 2, n, out_g2 + 192 * 2, s));
+        if (sets & 4) ZKCHK(derive_set<Fp>(tn, d_g1 + 96 * o_tz, n - 1, out_g1 + 96 * (3 + (uint64_t)n), s));
+        HIPCHK(hipStreamSynchronize(s));
+        return ZK_OK;
     }
-    if (sets & 4) {
-        DeriveTables tn;                       // the points n .. 2n-2 of the h values
-        ZKCHK(derive_tables_build(tn, f, n, s));
-        ZKCHK(derive_set<Fp>(tn, d_g1 + 96 * o_tz, n - 1, out_g1 + 96 * (3 + (uint64_t)n), s));
+    DeriveWork wk[3];                          // declared before the streams: the streams drain (SideStreams' destructor) before the arrays go
+    SideStreams side;
+    for (hipStream_t& x : side.st) HIPCHK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+    for (hipEvent_t& e : side.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(side.ev[0], s));     // tables built, copies enqueued: the side streams start from here
+    uint32_t used = 0;
+    int rc = ZK_OK;
+    auto stream_of = [&](uint32_t k) -> hipStream_t { return k == 0 ? s : side.st[k - 1]; };
+    auto start = [&](uint32_t k) -> int {
+        if (k) HIPCHK(hipStreamWaitEvent(side.st[k - 1], side.ev[0], 0));
+        return ZK_OK;
+    };
+    // the G2 set first: it is the longest
+    if (rc == ZK_OK && (sets & 2)) { rc = start(used); if (rc == ZK_OK) rc = derive_set_enqueue<Fp2H>(wk[used], t0, d_g2 + 192 * 2, n, out_g2 + 192 * 2, stream_of(used)); used++; }
+    if (rc == ZK_OK && (sets & 1)) { rc = start(used); if (rc == ZK_OK) rc = derive_set_enqueue<Fp>(wk[used], t0, d_g1 + 96 * o_ti, n, out_g1 + 96 * 3, stream_of(used)); used++; }
+    if (rc == ZK_OK && (sets & 4)) { rc = start(used); if (rc == ZK_OK) rc = derive_set_enqueue<Fp>(wk[used], tn, d_g1 + 96 * o_tz, n - 1, out_g1 + 96 * (3 + (uint64_t)n), stream_of(used)); used++; }
+    for (uint32_t k = 1; k < used; k++) {      // the caller's stream ends after every set (also on the way out of a failed enqueue)
+        if (hipEventRecord(side.ev[k], side.st[k - 1]) == hipSuccess) (void)hipStreamWaitEvent(s, side.ev[k], 0);
     }
-    HIPCHK(hipStreamSynchronize(s));
+    const hipError_t e_sync = hipStreamSynchronize(s);
+    if (rc != ZK_OK) return rc;
+    HIPCHK(e_sync);
     return ZK_OK;
 }
 
