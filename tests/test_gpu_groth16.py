@@ -554,6 +554,23 @@ def test_two_level_sort_plain_and_staged_scatter_give_the_same_proof(c, witness)
 SWEEP_WINDOWS = (12, 14, 15, 17, 20)      # 17, 20: beyond the LDS histogram -- the two-level counting sort
 
 
+@pytest.mark.parametrize("n", [6, 1000])
+def test_derivation_one_set_after_another_and_side_by_side_give_the_same_pools(n, monkeypatch):
+    """csrc/lagrange_derive.hip runs the three derived sets of a key on three streams (round 4); ZK_DERIVE_SIDE_BY_SIDE=0 runs them one after
+    another on the caller's.  Both orders must leave the pools of a keygen that knows tau, byte for byte."""
+    cs, w = RC.iterated_cubic(n, 12)
+    rng = seeded_rng(0x5EED0D11)
+    toxic = [rng() for _ in range(5)]
+    it = iter(toxic)
+    pk, vk = Groth16.keygen(lambda: next(it), cs, lagrange=True)
+    for order in ("0", "1"):
+        monkeypatch.setenv("ZK_DERIVE_SIDE_BY_SIDE", order)
+        prover = Groth16(cs, pk)
+        prover.derive_lagrange()
+        assert bytes(prover.pool_points(1)) == bytes(pk.lag_g1) and bytes(prover.pool_points(2)) == bytes(pk.lag_g2), "side by side = %s" % order
+        prover.close()
+
+
 def test_prove_from_the_interchange_files():
     """Scope row f3: the README circuit and its solution read from the binary .r1cs / .wit fixtures
     (zukelang_amd/r1cs_file.py; the CSR form of circuit.ml:73-75's gates) prove to the literal oracle's bytes."""
