@@ -8,7 +8,8 @@ TAG=$1; shift
 LN=${LOGN:-20}
 O=gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BARGS="--headline-only --derived-only --no-cpu-baseline --no-parity-gate --cpu-fast-upto -1 --log-n $LN"
+KEYFORM="--derived-only"; [ "${TAU_POWER:-0}" = 1 ] && KEYFORM="--derive-lagrange-upto -1"      # TAU_POWER=1: the key as uploaded (the basis-conversion Fr stage) instead of the derived form
+BARGS="--headline-only $KEYFORM --no-cpu-baseline --no-parity-gate --cpu-fast-upto -1 --log-n $LN"
 ONE="--inflight 1 --steps 1 --proofs-per-step 6 --warmup 0 --settle 0"
 for st in "$@"; do
   case $st in
