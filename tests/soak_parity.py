@@ -121,7 +121,7 @@ while time.time() < t_end:
     if n_g16 % 4 == 2:
         # round 4: the two-level counting sort forced on at this size (ZK_SORT_TWO_LEVEL_MIN, ZK_MSM_WINDOW: read when the key is built) with its two
         # scatters plain or staged through LDS (ZK_SORT_COARSE_STAGED, ZK_SORT_FINE_STAGED: read per call), proofs in flight on several slots
-        os.environ["ZK_SORT_TWO_LEVEL_MIN"], os.environ["ZK_MSM_WINDOW"] = "8", str(rnd.choice([16, 20, 22]))
+        os.environ["ZK_SORT_TWO_LEVEL_MIN"], os.environ["ZK_MSM_WINDOW"] = "8", str(rnd.choice([15, 16, 17, 20, 22]))          # 15, 17 divide 255: digits of min(s, r - s), one window fewer
         try:
             pr = Groth16(cs, pk, lagrange=rnd.random() < 0.5)
             pr.set_witness(w)

@@ -140,10 +140,15 @@ int groth16_slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
     return ZK_OK;
 }
 
-// The key's window width (see upload): one per key, 20 bits from 2^21 points in the G1 pool.
+// The key's window width (see upload): one per key, 20 bits from 2^21 points in the G1 pool; 17 bits from 2^20 points (2^19 gates on one GPU, the
+// shards of config 4's 2^22 key on eight): 17 divides 255, and with the digits taken from min(s, r - s) (msm.cuh: msm_windows) that is 15 windows
+// instead of 16 for twice the buckets -- measured +3.3 % at 2^19 (where 20 bits lose 2 %); at 2^18 +0.8 ... 1.8 % for 5 % more latency of a lone
+// proof, at 2^16 -6 %: both stay at 16 (profiles/r04_window_17_ab.txt).
 static uint32_t key_window(uint64_t g1_points) {
     if (getenv("ZK_MSM_WINDOW")) return 0;          // bases_setup reads it
-    return g1_points >= ((uint64_t)1 << 21) ? 20 : msm_auto_window(g1_points, true);
+    if (g1_points >= ((uint64_t)1 << 21)) return 20;
+    if (g1_points >= ((uint64_t)1 << 20)) return 17;
+    return msm_auto_window(g1_points, true);
 }
 int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
                       const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world, bool lagrange, bool shard_of_group) {
@@ -176,7 +181,7 @@ int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, 
     // ONE window width per key (both pools: their bucket reductions then go out as one chain of launches).  From 2^21 points
     // in this rank's G1 pool (n >= ~2^19.6 on one GPU) 20-bit windows: 13 instead of 16 digits per scalar pay for the 16x
     // bucket count and the two-level sort (measured, profiles/r02_window_sweep_*.json: +7.5 % at 2^20, +12 % at 2^22, -2 % at
-    // 2^19, -16 % at 2^18).  ZK_MSM_WINDOW overrides (config 3's sweep).
+    // 2^19, -16 % at 2^18); round 4: 17-bit windows, fifteen of them, from 2^20 points (key_window above).  ZK_MSM_WINDOW overrides (config 3's sweep).
     const uint32_t cw = key_window(k.hi1 - k.lo1);
     // key points are checked like the reference checks them on the way in (of_bytes_exn: encoding, curve, prime-order subgroup); ZK_KEY_SUBGROUP_CHECK=0
     // skips the subgroup part for keys that were checked before (it is [r] P = O per point: 0.3 s at 2^20 constraints, 1.4 s at 2^22)

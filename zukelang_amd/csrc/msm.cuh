@@ -11,7 +11,11 @@ static inline size_t xyzz_bytes(Curve c) { return c == CURVE_G1 ? 192 : 384; }
 
 // Signed-digit window layout: nw = floor(255 / c) + 1 windows of c bits (the top window absorbs
 // the last carry: scalars are < r < 2^255), digits in [-2^(c-1), 2^(c-1)], buckets 1..2^(c-1).
-static inline uint32_t msm_windows(uint32_t c) { return 255 / c + 1; }
+// fold: the digits are taken from min(s, r - s) < r / 2 < 0.4529 * 2^255 with the sign carried to every digit (resident keys: their points are in the
+// prime-order subgroup, (r - s) P = -s P).  The recoding constant K is < 2^(c nw - 1) (1 + 2^-(c-1)), so min(s, r - s) + K < 2^255 and a width that
+// DIVIDES 255 (c = 3, 5, 15, 17) needs no window for the last carry: 15 windows at c = 17 instead of 16.
+static inline bool msm_fold(uint32_t c, bool precomp) { return precomp && 255 % c == 0; }
+static inline uint32_t msm_windows(uint32_t c, bool fold = false) { return fold && 255 % c == 0 ? 255 / c : 255 / c + 1; }
 
 struct MsmBases {
     Curve curve = CURVE_G1;
@@ -19,6 +23,7 @@ struct MsmBases {
     uint32_t c = 0;          // window bits
     uint32_t nw = 0;         // windows
     bool precomp = false;    // table holds 2^(c*j) * P_i for j < nw at [j*n + i]; one bucket set
+    bool fold = false;       // digits of min(s, r - s): see msm_windows
     DevBuf table;            // affine Montgomery points in the 128-byte record layout of ec.cuh (TableLayout): canonical limbs, one cache line per lane and gather
     DevBuf ident;            // one byte per point, 1 = the base is the identity (the sort never files it into a bucket: table entries the accumulate loop meets are genuine points)
 };

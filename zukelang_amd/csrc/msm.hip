@@ -192,6 +192,7 @@ struct DigitArgs {
                             // not once per window: 13-16x less scalar traffic in the two passes); 0: a range of (scalar, window) pairs, window-major
     uint32_t alias_windows; // EXPERIMENT, compiled in only with -DZK_EXPERIMENTS (scripts/table_alias_ab.sh; results WRONG by design): every window
                             // reads window 0's table entries -- same additions and gathers, 1/16 of the table footprint.  Always 0 in the shipped library.
+    uint32_t fold;          // digits of min(s, r - s), sign carried to every digit (msm.cuh: msm_windows): bit 31 of the ninth word of a prepared scalar is the sign
 };
 // scalar i plus the recoding constant (9 words); false: the scalar is zero or its base is the identity -- no digit of it enters a bucket
 FF_INLINE bool digits_prepare(const uint32_t* __restrict__ scalars, uint64_t i, const DigitArgs& a, uint32_t s[9]) {
@@ -200,6 +201,27 @@ FF_INLINE bool digits_prepare(const uint32_t* __restrict__ scalars, uint64_t i, 
     s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w; s[8] = 0;
     if ((s[0] | s[1] | s[2] | s[3] | s[4] | s[5] | s[6] | s[7]) == 0) return false;
     if (a.ident && a.ident[i]) return false;
+    uint32_t flip = 0;
+    if (a.fold) {                                        // wave-uniform
+        uint32_t t[8];
+        int64_t bw = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            bw += (int64_t)FR_MOD[k] - (int64_t)s[k];
+            t[k] = (uint32_t)bw;
+            bw >>= 32;
+        }
+        bool less = false, decided = false;              // t < s, from the top word down (r is odd: t != s)
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            if (!decided && t[k] != s[k]) { less = t[k] < s[k]; decided = true; }
+        }
+        if (less) {
+            flip = 0x80000000u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = t[k];
+        }
+    }
     uint64_t cy = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -207,6 +229,7 @@ FF_INLINE bool digits_prepare(const uint32_t* __restrict__ scalars, uint64_t i, 
         s[k] = (uint32_t)cy;
         cy >>= 32;
     }
+    s[8] |= flip;                                        // c nw <= 276 bits: the ninth word uses 20 bits at most
     return true;
 }
 FF_INLINE bool digit_at(const uint32_t s[9], uint64_t i, uint32_t j, const DigitArgs& a, uint32_t& key, uint32_t& val);
@@ -220,14 +243,15 @@ FF_INLINE bool digit_at(const uint32_t s[9], uint64_t i, uint32_t j, const Digit
 #pragma unroll
     for (int k = 0; k < 9; k++) {        // static indexing keeps the scalar in registers
         if ((int)w == k) x0 = s[k];
-        if ((int)w + 1 == k) x1 = s[k];
+        if ((int)w + 1 == k) x1 = k == 8 ? s[k] & 0x7fffffffu : s[k];
     }
     const uint64_t x = ((uint64_t)x1 << 32) | x0;
     const uint32_t e = (uint32_t)(x >> b) & ((1u << a.c) - 1);
     const uint32_t bias = (1u << (a.c - 1)) - 1;
     if (e == bias) return false;                        // digit 0
-    const uint32_t neg = e < bias ? 1u : 0u;
-    const uint32_t d = neg ? bias - e : e - bias;
+    const uint32_t below = e < bias ? 1u : 0u;
+    const uint32_t d = below ? bias - e : e - bias;      // the digit's magnitude
+    const uint32_t neg = below ^ (s[8] >> 31);           // ... its sign, turned round for a folded scalar
     key = (a.precomp ? 0u : j * a.nb_per_window) + (d - 1);
 #ifdef ZK_EXPERIMENTS
     val = (uint32_t)(a.precomp && !a.alias_windows ? (uint64_t)j * a.n + i : i) | (neg << 31);
@@ -836,7 +860,7 @@ uint32_t msm_auto_window(uint64_t n, bool precomp) {
     // resident keys: at most 2^15 buckets, so the whole histogram of the counting sort fits in LDS
     const uint32_t cmax = precomp ? 16 : 20;
     for (uint32_t c = 6; c <= cmax; c++) {
-        double nw = msm_windows(c);
+        double nw = msm_windows(c, msm_fold(c, precomp));
         double buckets = (precomp ? 1.0 : nw) * (double)(1u << (c - 1));
         double cost = nw * (double)n + 3.0 * buckets;
         if (cost < best) { best = cost; bc = c; }
@@ -871,7 +895,7 @@ static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool pr
         c = e ? (uint32_t)atoi(e) : msm_auto_window(n, precomp);
     }
     if (c < 2 || c > 22) ZK_FAIL(ZK_ERR_ARG, "msm: window_bits must be in [2, 22]");
-    b.curve = curve; b.n = n; b.c = c; b.nw = msm_windows(c); b.precomp = precomp;
+    b.curve = curve; b.n = n; b.c = c; b.precomp = precomp; b.fold = msm_fold(c, precomp); b.nw = msm_windows(c, b.fold);
     if ((precomp ? (uint64_t)b.nw : 1) * n >= ((uint64_t)1 << 31)) ZK_FAIL(ZK_ERR_ARG, "msm: too many points for 31-bit references");
     return b.table.alloc(table_entry_bytes(curve) * n * (precomp ? b.nw : 1));
 }
@@ -998,7 +1022,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     // the sort runs on: two levels (2 KiB + 20 KiB of LDS) measure +1.6 % proofs/s at 2^16, +1.9 % at 2^18 with the same single-proof latency.
     // ZK_SORT_TWO_LEVEL=0: never (A/B; above 2^15 buckets that is the global-atomic sort); ZK_SORT_TWO_LEVEL_MIN: log2 of the pair threshold.
     const int two_level = getenv("ZK_SORT_TWO_LEVEL") ? atoi(getenv("ZK_SORT_TWO_LEVEL")) : 1;
-    const int two_level_min = getenv("ZK_SORT_TWO_LEVEL_MIN") ? atoi(getenv("ZK_SORT_TWO_LEVEL_MIN")) : (w.nbuckets > SORT_MAX_BUCKETS ? 22 : 20);
+    const int two_level_min = getenv("ZK_SORT_TWO_LEVEL_MIN") ? atoi(getenv("ZK_SORT_TWO_LEVEL_MIN")) : (w.nbuckets > 2 * SORT_MAX_BUCKETS ? 22 : 20);          // 2^16 buckets (c = 17) sort in two levels from 2^20 pairs like 2^15
     if (b.precomp && w.nbuckets >= SORT_MAX_BUCKETS && w.nbuckets / COARSE_BINS <= SORT_MAX_FINE && maxN >= ((uint64_t)1 << two_level_min) && two_level != 0) {
         w.sort_fine_bits = ceil_log2(w.nbuckets / COARSE_BINS);
         uint64_t wgs = maxN / (4 * (uint64_t)COARSE_BINS);
@@ -1076,7 +1100,7 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
     const uint32_t alias = 0u;
 #endif
     DigitArgs da{b.n, b.c, b.nw, b.precomp ? 1u : 0u, nbw, {0, 0, 0, 0, 0, 0, 0, 0, 0}, b.ident.as<uint8_t>(),
-                 0u, sm ? 1u : 0u, alias};
+                 0u, sm ? 1u : 0u, alias, b.fold ? 1u : 0u};
     for (uint32_t j = 0; j < b.nw; j++) {               // K += (2^(c-1) - 1) << (c*j)
         uint64_t v = ((uint64_t)1 << (b.c - 1)) - 1;
         uint32_t off = j * b.c, wd = off >> 5, sh = off & 31;
