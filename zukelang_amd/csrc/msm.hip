@@ -860,7 +860,7 @@ uint32_t msm_auto_window(uint64_t n, bool precomp) {
     // resident keys: at most 2^15 buckets, so the whole histogram of the counting sort fits in LDS
     const uint32_t cmax = precomp ? 16 : 20;
     for (uint32_t c = 6; c <= cmax; c++) {
-        double nw = msm_windows(c, msm_fold(c, precomp));
+        double nw = msm_windows(c);          // the plain count: the choice per size stays the measured one (a folded width then runs with one window fewer)
         double buckets = (precomp ? 1.0 : nw) * (double)(1u << (c - 1));
         double cost = nw * (double)n + 3.0 * buckets;
         if (cost < best) { best = cost; bc = c; }
