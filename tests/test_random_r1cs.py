@@ -1,0 +1,149 @@
+"""A general random R1CS family under parity (zukelang_amd/r1cs.py `random_r1cs`): multi-term l AND r rows, columns repeated across
+rows, variables that occur in no row (their key points are the identity: L_k = 0 in groth16.ml:59-68), witness values 0 / 1 / r-1
+mixed in, optionally no variable pinned to 1.  Semantics under test: QAP.build's reading of the gates (src/lib/zk/QAP.ml:25-52),
+QAP.eval (:120-135), `lhs = l * r` (src/lib/zk/circuit.ml:73-75), and both provers on top.
+
+CPU: the family is satisfied by construction and the oracle's literal restatement == its trapdoor form on it.
+GPU: HIP prover == literal oracle for n <= 64, == trapdoor oracle at 2^10 / 2^16 / 2^20, Groth16 (tau-power and derived key) and
+Pinocchio (ZK, NonZK, derived h bases)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from oracle import pyref as P
+from zukelang_amd import r1cs as RC
+
+frb = P.fr_to_bytes
+frs = lambda xs: bytes(RC.fr_bytes(xs))
+csrs = lambda cs: [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+INF1 = bytes([0x40]) + bytes(95)
+INF2 = bytes([0x40]) + bytes(191)
+
+SMALL = [(1, 4, (1, 2), True), (2, 6, (1, 3), False), (5, 12, (1, 4), False), (7, 30, (1, 1), True), (16, 24, (2, 9), True),
+         (33, 40, (1, 16), True), (64, 40, (1, 16), False)]
+
+
+@pytest.mark.parametrize("n,m,nnz,one", SMALL)
+def test_family_is_satisfied_and_the_oracle_forms_agree(n, m, nnz, one):
+    cs, w = RC.random_r1cs(n, m, 0xA11CE + n, nnz=nnz, one=one)
+    assert cs.check(w)
+    touched = set(cs.L.col) | set(cs.R.col) | set(cs.O.col)
+    assert len(touched) < m                                         # at least one variable occurs in no row
+    assert any(x == 0 for x in w) or any(x == P.R - 1 for x in w) or n < 4
+    st = P.fr_stream(0x5EED0A00 + n)
+    tox = [next(st) for _ in range(7)]
+    toxic, r, s = frs(tox[:5]), frb(tox[5]), frb(tox[6])
+    q = O.QAP(n, m, *csrs(cs))
+    pk1, pk2, vk1, vk2 = q.groth16_setup(toxic, cs.mid)
+    # a variable in no row (or only with explicit zero coefficients: a solved-for lhs entry of a gate whose product is 0) has L_k = 0:
+    # its point in ltd_mid (or ltgm_io) is the identity
+    touched = set()
+    for M in (cs.L, cs.R, cs.O):
+        vals = bytes(M.val)
+        touched |= {int(c) for e, c in enumerate(M.col) if any(vals[32 * e:32 * e + 32])}
+    mids = [k for k in range(m) if cs.mid[k]]
+    base = 96 * (3 + n + 2 + max(n - 1, 0))
+    for j, k in enumerate(mids):
+        assert (pk1[base + 96 * j:base + 96 * j + 96] == INF1) == (k not in touched)
+    rc, a, b, c = q.groth16_prove(pk1, pk2, cs.mid, frs(w), r, s, 1)
+    assert rc == 0 and (a, b, c) == O.groth16_prove_trapdoor(n, m, *csrs(cs), cs.mid, frs(w), toxic, r, s)
+    ptox = [next(st) for _ in range(11)]
+    ex = O.pinocchio_keygen_exponents(q, n, m, *csrs(cs), cs.mid, frs(ptox[:8]), True)
+    assert ex == O.pinocchio_keygen_exponents(None, n, m, *csrs(cs), cs.mid, frs(ptox[:8]), False)
+    if n <= 16:
+        ppk1, ppk2 = O.points_of_exponents_g1(ex[0]), O.points_of_exponents_g2(ex[1])
+        d = [frb(x) for x in ptox[8:]]
+        rc, pr = O.pinocchio_prove(q, ppk1, ppk2, cs.mid, frs(w), *d)
+        assert rc == 0 and pr == O.pinocchio_prove_trapdoor(n, m, *csrs(cs), cs.mid, frs(w), frs(ptox[:8]), *d)
+    bad = list(w)
+    k = int(cs.O.col[0])
+    bad[k] = (bad[k] + 1) % P.R
+    assert not cs.check(bad) and q.eval(frs(bad))[0] != 0
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+def _both_protocols(cs, w, seed, literal):
+    from zukelang_amd.groth16 import Groth16
+    from zukelang_amd import pinocchio as PIN
+    n, m = cs.n, cs.m
+    csr = csrs(cs)
+    st = P.fr_stream(seed)
+    tox = [next(st) for _ in range(5)]
+    rs = [(next(st), next(st)) for _ in range(2)]
+    it = iter(tox)
+    pk, vk = Groth16.keygen(lambda: next(it), cs)
+    sol = frs(w)
+    if literal:
+        q = O.QAP(n, m, *csr)
+        pk1, pk2, vk1, _ = q.groth16_setup(frs(tox), cs.mid)
+        assert bytes(pk.g1) == pk1 and bytes(pk.g2) == pk2 and bytes(vk.ltgm_io) == vk1[96:]
+    exp = [O.groth16_prove_trapdoor(n, m, *csr, cs.mid, sol, frs(tox), frb(r), frb(s)) for r, s in rs]
+    pr = Groth16(cs, pk)
+    for derived in (False, True):
+        if derived:
+            pr.derive_lagrange()
+        for (r, s), e in zip(rs, exp):
+            got = pr.prove_rs(w, r, s)
+            assert (got.a, got.b, got.c) == e, ("groth16", n, derived)
+        if literal:
+            rc, a, b, c = q.groth16_prove(pk1, pk2, cs.mid, sol, frb(rs[0][0]), frb(rs[0][1]), 1)
+            assert rc == 0 and (a, b, c) == exp[0]
+    io = [w[k] for k in range(m) if not cs.mid[k]]
+    assert Groth16.verify(io, vk, got)
+    assert not Groth16.verify([(io[0] + 1) % RC.FR_MODULUS] + io[1:], vk, got)
+    bad = list(w)
+    k = int(cs.O.col[0])
+    bad[k] = (bad[k] + 1) % RC.FR_MODULUS
+    with pytest.raises(AssertionError):
+        pr.prove_rs(bad, *rs[0])
+    pr.close()
+    ptox = [next(st) for _ in range(8)]
+    ds = [[next(st) for _ in range(3)] for _ in range(2)] + [[0, 0, 0]]
+    it = iter(ptox)
+    ppk, pvk = PIN.ZK.keygen(lambda: next(it), cs)
+    pexp = [O.pinocchio_prove_trapdoor(n, m, *csr, cs.mid, sol, frs(ptox), *(frb(x) for x in d)) for d in ds]
+    pp = PIN.ZK(cs, ppk)
+    for derived in (False, True):
+        if derived:
+            pp.derive_lagrange()
+        for d, e in zip(ds, pexp):
+            got = pp.prove_with(w, *d)
+            assert got.to_bytes() == e, ("pinocchio", n, derived)
+    if n <= (1 << 10):
+        assert PIN.ZK.verify(io, pvk, got)
+    pp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,nnz,one", SMALL)
+def test_gpu_small_random_circuits_match_the_literal_oracle(n, m, nnz, one):
+    cs, w = RC.random_r1cs(n, m, 0xA11CE + n, nnz=nnz, one=one)
+    _both_protocols(cs, w, 0x5EED0B00 + n, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n,nnz,one", [(10, (1, 16), True), (10, (3, 3), False), (16, (1, 12), True)])
+def test_gpu_random_circuits_match_the_trapdoor_oracle(log_n, nnz, one):
+    n = 1 << log_n
+    cs, w = RC.random_r1cs(n, n + n // 4, 0xBEEF00 + log_n, nnz=nnz, one=one)
+    _both_protocols(cs, w, 0x5EED0C00 + log_n, False)
+
+
+@pytest.mark.gpu
+def test_gpu_random_dense_rows_2_20():
+    """One case at BASELINE config 3's size: 2^20 constraints with 8 entries per row in all three matrices (the `dense_rows`
+    variant bench.py reports beside the headline), Groth16 only, derived key, against the trapdoor oracle."""
+    from zukelang_amd.groth16 import Groth16
+    n = 1 << 20
+    cs, w = RC.random_r1cs(n, n + 2, 0xD0D0, nnz=(8, 8))
+    st = P.fr_stream(0x5EED0D20)
+    tox = [next(st) for _ in range(5)]
+    r, s = next(st), next(st)
+    e1, e2, _ = O.groth16_setup_exponents(n, cs.m, *csrs(cs), cs.mid, frs(tox), want_io=False)
+    from zukelang_amd.curve import G1, G2
+    from zukelang_amd.groth16 import PKey
+    pr = Groth16(cs, PKey(G1.of_Fr(e1), G2.of_Fr(e2)))
+    exp = O.groth16_prove_trapdoor(n, cs.m, *csrs(cs), cs.mid, frs(w), frs(tox), frb(r), frb(s))
+    got = pr.prove_rs(w, r, s)
+    assert (got.a, got.b, got.c) == exp
+    pr.close()

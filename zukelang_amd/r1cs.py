@@ -175,3 +175,120 @@ def random_fr_bytes(count, seed):
     raw = rng.integers(0, 256, size=(count, 32), dtype=np.uint8)
     raw[:, 31] &= 0x3F     # < 2^254 < r : uniform on [0, 2^254), plenty for a workload generator
     return raw.reshape(-1)
+
+
+def random_r1cs(n, m, seed, nnz=(1, 16), one=True, unused=None, special=0.25):
+    """A general R1CS family for parity: nothing of the benchmark circuits' regular shape.
+
+      - every l, r and lhs row has between nnz[0] and nnz[1] entries (distinct, sorted columns) -- multi-term on BOTH operands
+        (Gate {lhs; l; r} with arbitrary Affine.t, src/lib/zk/circuit.ml:73-75; QAP.ml:30-52 reads each coefficient off);
+      - columns repeat freely across rows; `unused` variables (default max(1, m // 8)) occur in NO row, so their v_k, w_k, y_k are the
+        zero polynomial and their key points the identity (groth16.ml:59-68,74-79 with L_k = 0);
+      - coefficients: small integers, their negatives, and full-width field elements, mixed;
+      - witness values 0, 1 and r - 1 mixed into uniformly random ones (`special` = their share);
+      - one=False: no variable is pinned to 1 (the reference's `x * x` program has no $ONE, src/lib/test/test.ml:204-212);
+      - satisfied by construction: the last entry of every lhs row is solved for.
+    Variables 0..m-1 in Var.compare order as everywhere; roughly three quarters are mids, ONE (variable 0, when present) is public.
+    Returns (R1CS, witness ints).  Vectorised (numpy object arrays): 2^20 rows of 8 entries take seconds."""
+    P = FR_MODULUS
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lo, hi = nnz
+    unused = max(1, m // 8) if unused is None else unused
+    used = m - unused
+    assert n >= 1 and 1 <= lo <= hi and used >= max(2, hi + 1)
+    # which variables are in use: a random subset, ONE always
+    perm = rng.permutation(m - 1) + 1 if one else rng.permutation(m)
+    live = np.sort(np.concatenate(([0], perm[:used - 1])) if one else perm[:used]).astype(np.int64)
+    # witness
+    raw = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x3F
+    w = [int.from_bytes(bytes(raw[k]), "little") for k in range(m)]
+    kind = rng.random(m)
+    for k in range(m):
+        if kind[k] < special:
+            w[k] = (0, 1, P - 1)[int(kind[k] * 3 / special) % 3]
+    if one:
+        w[0] = 1
+    nz = [int(k) for k in live if w[k] != 0]
+    if len(nz) < 4:                                         # the solved-for entry needs a non-zero witness value
+        for k in live[:4]:
+            if w[k] == 0:
+                w[k] = 2 + int(k)
+        nz = [int(k) for k in live if w[k] != 0]
+    pivots = np.array(nz[:64], dtype=np.int64)
+    pivot_inv = np.array([pow(w[k], P - 2, P) for k in pivots], dtype=object)
+    wobj = np.array(w, dtype=object)
+
+    def rows(count_lo, count_hi, exclude=None):
+        cnt = rng.integers(count_lo, count_hi + 1, size=n)
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        ptr[1:] = np.cumsum(cnt)
+        tot = int(ptr[-1])
+        row = np.repeat(np.arange(n, dtype=np.int64), cnt)
+        first = ptr[:-1][row]
+        # distinct columns per row: a random start plus strictly increasing steps whose total stays below `span`
+        span = used if exclude is None else used - 1
+        step = rng.integers(1, max(2, (span - 1) // hi + 1), size=tot)
+        off = np.cumsum(step) - np.cumsum(step)[first] + step[first]
+        start = rng.integers(0, span, size=n)[row]
+        pos = (start + off) % span
+        if exclude is not None:                             # positions index the live variables without the row's pivot
+            pos = pos + (pos >= exclude[row])
+        col = live[pos]
+        order = np.lexsort((col, row))
+        col = col[order]
+        ck = rng.integers(0, 8, size=tot)
+        small = rng.integers(1, 1 << 31, size=tot).astype(object)
+        big = rng.integers(0, 256, size=(tot, 32), dtype=np.uint8)
+        big[:, 31] &= 0x3F
+        bigv = np.array([int.from_bytes(bytes(b), "little") for b in big[ck >= 6]], dtype=object) if (ck >= 6).any() else np.array([], dtype=object)
+        coef = small.copy()
+        coef[ck == 0] = 1
+        coef[ck == 1] = P - 1
+        neg = (ck == 2) | (ck == 3)
+        coef[neg] = P - small[neg]
+        coef[ck >= 6] = bigv
+        return ptr, row, col, coef
+
+    def dots(ptr, col, coef):
+        prod = coef * wobj[col]
+        return np.add.reduceat(prod, ptr[:-1]) % P
+
+    lp, _, lc, lv = rows(lo, hi)
+    rp, _, rc, rv = rows(lo, hi)
+    a, b = dots(lp, lc, lv), dots(rp, rc, rv)
+    want = a * b % P
+    piv_i = rng.integers(0, len(pivots), size=n)
+    piv = pivots[piv_i]
+    piv_pos = np.searchsorted(live, piv)
+    if hi > 1:
+        op, orow, oc, ov = rows(max(lo - 1, 0) if lo > 1 else 0, hi - 1, exclude=piv_pos)
+        part = np.zeros(n, dtype=object)
+        nonempty = op[1:] > op[:-1]
+        if nonempty.any():
+            red = np.add.reduceat(ov * wobj[oc], op[:-1][nonempty]) % P
+            part[nonempty] = red
+    else:
+        op, orow, oc, ov = np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=object)
+        part = np.zeros(n, dtype=object)
+    solved = (want - part) % P * pivot_inv[piv_i] % P
+    # merge the solved-for entry into each lhs row at its sorted place
+    cnt = (op[1:] - op[:-1]) + 1
+    optr = np.zeros(n + 1, dtype=np.int64)
+    optr[1:] = np.cumsum(cnt)
+    allrow = np.concatenate((orow, np.arange(n, dtype=np.int64)))
+    allcol = np.concatenate((oc, piv))
+    allval = np.concatenate((ov, solved))
+    order = np.lexsort((allcol, allrow))
+    ocol, oval = allcol[order], allval[order]
+
+    def matrix(ptr, col, coef):
+        vals = np.frombuffer(b"".join(int(c).to_bytes(32, "little") for c in coef), dtype=np.uint8).copy() if len(coef) else np.zeros(0, dtype=np.uint8)
+        return Matrix(ptr.astype(np.uint32), col.astype(np.uint32), vals)
+
+    mid = (rng.random(m) < 0.75).astype(np.uint8)
+    if one:
+        mid[0] = 0
+    if mid.all():
+        mid[m - 1] = 0
+    return R1CS(n, m, matrix(lp, lc, lv), matrix(rp, rc, rv), matrix(optr, ocol, oval), mid), w
