@@ -67,6 +67,14 @@ int zk_shutdown(void);
  *     device; the shard API (zk_groth16_pk_upload_sharded, _prove_partial*, _scalars_async ...) refuses multi-device handles with ZK_ERR_ARG.
  * The one-process-per-GPU path (torch.distributed / RCCL, bench.py --gpus N) does not use the device list: every rank keeps its one-entry list. */
 int zk_set_devices(uint64_t mask);
+/* Configuration by call instead of by environment.  The reference configures by functor application (no flags, no environment), and an
+ * OCaml host cannot change the process environment after the library was loaded in a way the C side is sure to see; the tuning knobs INTEGRATION.md 5
+ * lists as environment variables are therefore also settable here: name = the variable's name, with or without the "ZK_" prefix, in either case
+ * ("msm_window", "ZK_MSM_WINDOW"); value = the string the variable would hold; value == NULL hands the knob back to the environment.  An option set
+ * here wins over the environment.  Knobs are read when a key is uploaded or at the first proof and cached: set options BEFORE the first key upload.
+ * Unknown names -> ZK_ERR_ARG.  None changes a result (the one that changes a precondition, key_subgroup_check = 0, also switches off the folded
+ * windows that rely on it). */
+int zk_set_option(const char* name, const char* value);
 int zk_set_device_list(const int32_t* devices, uint32_t count);
 int zk_get_device_list(int32_t* devices /* may be NULL */, uint32_t capacity, uint32_t* count);
 

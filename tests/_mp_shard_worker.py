@@ -34,9 +34,11 @@ def main():
     if mode == "gpu-rccl":
         # the RCCL branches of the collectives (device tensors, all_gather_into_tensor, all_to_all_single with splits, broadcast) on a REAL
         # communicator: one rank per device, so on the one-GPU box that is a world of one -- self-collectives through the code N ranks run
+        # (tests/test_multiproc.py starts as many ranks as the box has cards, up to four: on an 8-GPU node RCCL runs BETWEEN devices with no edit)
         import torch
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        dev = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -139,7 +141,8 @@ def main():
     else:
         from zukelang_amd import _lib
         from zukelang_amd.groth16 import Groth16
-        _lib.check(_lib.lib().zk_init(0))
+        # one rank per card where the box has several (the ranks of the gloo rehearsal share the one card otherwise)
+        _lib.check(_lib.lib().zk_init(int(os.environ.get("LOCAL_RANK", "0")) % max(1, _lib.lib().zk_device_count())))
         it = iter(toxic)
         pk, _ = Groth16.keygen(lambda: next(it), cs)
         prover = Groth16(cs, pk, rank, world)

@@ -72,10 +72,19 @@ def main():
                 den = den * (xi - xj) % R
         lam.append(num * inv(den) % R)
     derived_h_pool = lam + [t, 1] + vk + wk
+    # verification key (pinocchio.ml:62-75) flattened as include/zkmi355x.h lays it out, and the NonZK proof (Compute.f, :210-248: no blinding)
+    ios = [k for k in range(m) if not mid[k]]
+    vx1 = [1, aw, gm * b % R] + [rv * vk[k] % R for k in ios] + [ry * yk[k] % R for k in ios]
+    vx2 = [1, av, ay, gm, gm * b % R, ry * t % R] + [rw * wk[k] % R for k in ios]
+    n_vv, n_ww, n_yy = rv * vm % R, rw * wm % R, ry * ym % R
+    proof0 = g1(n_vv) + g2(n_ww) + g1(n_yy) + g1(h) + g1(av * n_vv) + g2(aw * n_ww) + g1(ay * n_yy) + g1(b * (n_vv + n_ww + n_yy))
     out = {"how": "python tests/golden/make_readme_pinocchio.py (first-principles Python big integers, oracle/pyref.py)",
            "toxic": [hex(v) for v in (rv, rw, s, av, aw, ay, b, gm)], "deltas": [hex(v) for v in (dv, dw, dy)],
            "witness": [hex(v) for v in c], "mid": mid, "pk_g1": [g1(e) for e in ex1], "pk_g2": [g2(e) for e in ex2],
-           "derived_h_pool_g1": [g1(e) for e in derived_h_pool], "proof": proof}
+           "derived_h_pool_g1": [g1(e) for e in derived_h_pool], "proof": proof,
+           "pk_exponents_g1": [hex(e % R) for e in ex1], "pk_exponents_g2": [hex(e % R) for e in ex2],
+           "vk_exponents_g1": [hex(e % R) for e in vx1], "vk_exponents_g2": [hex(e % R) for e in vx2],
+           "vk_g1": [g1(e) for e in vx1], "vk_g2": [g2(e) for e in vx2], "io": [hex(c[k]) for k in ios], "proof_nonzk": proof0}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "readme_pinocchio_key.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote readme_pinocchio_key.json:", len(ex1), "+", len(ex2), "key points")

@@ -127,3 +127,13 @@ def test_a_plain_c99_host_binds_the_abi(tmp_path):
                            os.path.join(root, "examples", "c_host.c"), "-o", exe, "-L" + libdir, "-lzkmi355x", "-Wl,-rpath," + libdir])
     out = subprocess.check_output([exe])
     assert out.startswith(b"c-host ok")
+
+
+def test_set_option_accepts_the_public_knobs_and_nothing_else():
+    """zk_set_option needs no GPU: names with or without the ZK_ prefix, in either case; NULL hands the knob back to the environment."""
+    L = _lib.lib()
+    assert L.zk_set_option(b"no_such_knob", b"1") == -1 and L.zk_set_option(None, b"1") == -1 and L.zk_set_option(b"", b"1") == -1
+    assert L.zk_set_option(b"test_forms", b"1") == -1                  # test-only switches stay environment-only
+    for name in (b"msm_window", b"ZK_MSM_WINDOW", b"Msm_Window", b"key_subgroup_check", b"slot_streams", b"graph", b"derive_side_by_side"):
+        assert L.zk_set_option(name, b"16") == 0
+        assert L.zk_set_option(name, None) == 0

@@ -120,3 +120,34 @@ def test_a_plain_c_host_proves_the_fixture(tmp_path):
     for devs in (["0", "0"], ["0", "0", "0"]):
         out = subprocess.run([exe] + devs, capture_output=True, timeout=300)
         assert out.returncode == 0 and out.stdout.startswith(b"c-prove ok (%d device entries)" % len(devs)), (devs, out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_a_plain_c_host_runs_pinocchio_like_the_ocaml_shim(tmp_path):
+    """examples/c_pinocchio.c: the call sequence of ocaml/pinocchio_mi355x.ml (keygen through zk_g1/g2_of_fr, upload, ZK and NonZK prove, verify,
+    derive, pipelined prove) from C99, every byte against the first-principles fixture tests/golden/readme_pinocchio_key.json."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_pinocchio")
+    libdir = os.path.join(root, "zukelang_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "examples"),
+                           os.path.join(root, "examples", "c_pinocchio.c"), "-o", exe, "-L" + libdir, "-lzkmi355x", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith(b"c-pinocchio ok"), (out.returncode, out.stdout, out.stderr)
+
+
+def test_the_pinocchio_fixture_header_is_the_json():
+    """examples/readme_pinocchio_fixture.h is generated from the JSON fixture (tests/golden/make_readme_c_header.py): same bytes."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = open(os.path.join(root, "examples", "readme_pinocchio_fixture.h")).read()
+    arrays = {m.group(1): bytes(int(x) for x in m.group(2).split(",")) for m in re.finditer(r"static const uint8_t (\w+)\[\d+\] = \{([^}]*)\};", h)}
+    assert arrays["PFIX_PK_G1"] == PPK1 and arrays["PFIX_PK_G2"] == PPK2 and arrays["PFIX_PROOF"] == PPROOF and arrays["PFIX_DERIVED_H_POOL"] == PDER
+    assert arrays["PFIX_VK_G1"] == cat(PFIX["vk_g1"]) and arrays["PFIX_VK_G2"] == cat(PFIX["vk_g2"]) and arrays["PFIX_PROOF_NONZK"] == bytes.fromhex(PFIX["proof_nonzk"])
+    # and the new parts of the JSON against the oracle: verification key and NonZK proof
+    cs, csr = _circuit()
+    ex = O.pinocchio_keygen_exponents(None, cs.n, cs.m, *csr, cs.mid, frs(PTOX), False)
+    assert O.points_of_exponents_g1(ex[2]) == cat(PFIX["vk_g1"]) and O.points_of_exponents_g2(ex[3]) == cat(PFIX["vk_g2"])
+    z = frb(0)
+    assert O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(W), frs(PTOX), z, z, z) == bytes.fromhex(PFIX["proof_nonzk"])
+    assert O.pinocchio_verify(cat(PFIX["vk_g1"]), cat(PFIX["vk_g2"]), [int(x, 16) for x in PFIX["io"]], PPROOF)

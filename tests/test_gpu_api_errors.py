@@ -109,3 +109,104 @@ def test_key_points_outside_the_prime_order_subgroup_are_rejected_at_upload():
     g1p[96 * 2:96 * 3] = np.frombuffer(bad, dtype=np.uint8)
     with pytest.raises(_lib.ZkError):
         PIN.ZK(cs, type(pkp)(g1p, pkp.g2))
+
+
+def _set_option(name, value):
+    _lib.check(_lib.lib().zk_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def test_a_key_uploaded_without_the_subgroup_check_never_gets_folded_windows():
+    """Folded digits take min(s, r - s) -- one window fewer at the widths that divide 255 (c = 3, 5, 15, 17; 17 is the default from 2^20 pool points) --
+    and (r - s)(-P) = s P only for points of order r.  The width and the check used to be two unrelated environment knobs (ADVICE r4
+    medium): a key uploaded with the check skipped and one point outside the subgroup gave wrong proof bytes and ZK_OK.  Now a base set folds only
+    when the [r] P = O test ran on it.  Here: the check switched off through zk_set_option (the C-ABI's own configuration call), a key with a
+    point of the curve OUTSIDE the prime-order subgroup, every folding width -- the proof must be the literal fold of groth16.ml:116-161 over that
+    very key (the oracle's double-and-add does not care about a point's order).  With the check back on, the same key is refused."""
+    import oracle_lib as O
+    cs, w = RC.iterated_cubic(8, 3)
+    csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
+    rng = seeded(0xF01D)
+    tox = [rng() for _ in range(5)]
+    it = iter(tox)
+    pk, _ = Groth16.keygen(lambda: next(it), cs)
+    bad = np.frombuffer(P.g1_to_bytes(_point_outside_the_subgroup()), dtype=np.uint8)
+    g1 = np.array(pk.g1, dtype=np.uint8, copy=True)
+    for idx in (4, len(g1) // 96 - 2):                                    # tau^1 (serves A and C) and one of ltd_mid
+        g1[96 * idx:96 * idx + 96] = bad
+    key = type(pk)(g1, pk.g2)
+    frs = lambda xs: bytes(RC.fr_bytes(xs))
+    q = O.QAP(cs.n, cs.m, *csr)
+    r, s = rng(), rng()
+    rc, a, b, c = q.groth16_prove(bytes(g1), bytes(pk.g2), cs.mid, frs(w), frs([r]), frs([s]), 1)
+    assert rc == 0
+    try:
+        _set_option("key_subgroup_check", 0)
+        for width in (17, 15, 5, 3, 16):
+            _set_option("ZK_MSM_WINDOW", width)
+            pr = Groth16(cs, key)
+            got = pr.prove_rs(w, r, s)
+            assert (got.a, got.b, got.c) == (a, b, c), "window %d" % width
+            pr.derive_lagrange()                                          # the derived pools inherit "not checked"
+            got = pr.prove_rs(w, r, s)
+            assert (got.a, got.b, got.c) == (a, b, c), "window %d, derived key" % width
+            pr.close()
+    finally:
+        _set_option("msm_window", None)
+        _set_option("key_subgroup_check", None)
+    with pytest.raises(_lib.ZkError) as e:
+        Groth16(cs, key)
+    assert e.value.code == -2 and "subgroup" in str(e.value)
+    # ... and the honest key still folds (same bytes as the oracle at a folding width, check on)
+    exp = O.groth16_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, frs(w), frs(tox), frs([r]), frs([s]))
+    try:
+        _set_option("msm_window", 17)
+        pr = Groth16(cs, pk)
+        got = pr.prove_rs(w, r, s)
+        assert (got.a, got.b, got.c) == exp
+        pr.close()
+    finally:
+        _set_option("msm_window", None)
+
+
+def test_set_option_names():
+    L = _lib.lib()
+    assert L.zk_set_option(b"no_such_knob", b"1") == -1 and L.zk_set_option(None, b"1") == -1 and L.zk_set_option(b"", b"1") == -1
+    for name in (b"msm_window", b"ZK_MSM_WINDOW", b"Msm_Window", b"key_subgroup_check", b"slot_streams", b"graph", b"derive_side_by_side"):
+        assert L.zk_set_option(name, b"16" if b"indow" in name.lower() else b"1") == 0
+        assert L.zk_set_option(name, None) == 0
+
+
+def test_caller_owned_scalar_vectors_are_range_checked():
+    """zk_groth16_msm_partial_async takes device vectors nobody has looked at: a value >= r must come back as ZK_ERR_SCALAR_RANGE from the
+    matching wait, not as a wrong sum."""
+    cs, w = RC.iterated_cubic(64, 3)
+    rng = seeded(0xE48)
+    pk, _ = Groth16.keygen(rng, cs)
+    pr = Groth16(cs, pk)
+    L = _lib.lib()
+    p1, p2 = len(pk.g1) // 96, len(pk.g2) // 192
+    d = [C.c_void_p() for _ in range(3)]
+    for ptr, size in zip(d, (32 * p1, 32 * p1, 32 * p2)):
+        _lib.check(L.zk_device_malloc(C.c_size_t(size), C.byref(ptr)))
+    rb, sb, wb = fr_bytes([5]), fr_bytes([7]), fr_bytes(w)
+    _lib.check(L.zk_groth16_scalars_async(pr.handle, _p(wb), _p(rb), _p(sb), C.c_uint32(0), *d))
+    _lib.check(L.zk_groth16_scalars_wait(pr.handle, C.c_uint32(0)))
+    part = np.zeros(768, dtype=np.uint8)
+    _lib.check(L.zk_groth16_msm_partial_async(pr.handle, C.c_uint32(0), *d))
+    _lib.check(L.zk_groth16_prove_partial_wait(pr.handle, C.c_uint32(0), _p(part)))
+    good = bytes(part)
+    for which, count in ((0, p1), (1, p1), (2, p2)):
+        big = np.frombuffer((P.R + 3).to_bytes(32, "little"), dtype=np.uint8).copy()          # r + 3 < 2^255: a non-canonical encoding of 3
+        saved = np.zeros(32, dtype=np.uint8)
+        at = C.c_void_p(d[which].value + 32 * (count - 1))
+        _lib.check(L.zk_device_memcpy(saved.ctypes.data_as(C.c_void_p), at, C.c_size_t(32)))
+        _lib.check(L.zk_device_memcpy(at, big.ctypes.data_as(C.c_void_p), C.c_size_t(32)))
+        _lib.check(L.zk_groth16_msm_partial_async(pr.handle, C.c_uint32(0), *d))
+        assert L.zk_groth16_prove_partial_wait(pr.handle, C.c_uint32(0), _p(part)) == -3, which
+        _lib.check(L.zk_device_memcpy(at, saved.ctypes.data_as(C.c_void_p), C.c_size_t(32)))
+    _lib.check(L.zk_groth16_msm_partial_async(pr.handle, C.c_uint32(0), *d))
+    _lib.check(L.zk_groth16_prove_partial_wait(pr.handle, C.c_uint32(0), _p(part)))
+    assert bytes(part) == good
+    for ptr in d:
+        _lib.check(L.zk_device_free(ptr))
+    pr.close()

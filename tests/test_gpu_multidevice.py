@@ -1,6 +1,6 @@
 """N GPUs behind ONE handle of ONE process (round-3 verdict, missing 3; SURVEY 8b `zk_set_devices`): what an OCaml host reaches through the ctypes shim --
 `Groth16.Make(C).prove` (src/groth16/groth16.ml:235-237, src/lib/zk/protocol.mli:3-28) is one call on one key and knows nothing of ranks.
-The test box has ONE card, so the device list names it several times ("virtual devices": each entry its own context, streams, tables, slots and
+Device lists come from the box (`physical`): k distinct cards when it has them, otherwise -- the one-card test box -- the list names card 0 several times ("virtual devices": each entry its own context, streams, tables, slots and
 shard); every path but the physical peer copy is the one N real GPUs take.  Proof bytes = the single-device prover's = the trapdoor oracle's
 (groth16.ml:123-161: the sums do not depend on how they are cut)."""
 import ctypes as C
@@ -27,6 +27,13 @@ def csrs(cs):
 def seeded_rng(seed):
     st = P.fr_stream(seed)
     return lambda: next(st)
+
+
+def physical(devs):
+    """The device list a test asks for, on the cards the box HAS: k distinct HIP devices when at least k are visible (hipMemcpyPeerAsync over xGMI and
+    per-device contexts run for real -- an 8-GPU node exercises them with no edit), the one card listed k times otherwise (virtual devices)."""
+    k = len(devs)
+    return list(range(k)) if _lib.lib().zk_device_count() >= k else list(devs)
 
 
 @pytest.fixture
@@ -57,6 +64,7 @@ def test_multi_device_key_gives_the_single_device_bytes(devices, devs, n):
     single.close()
     assert (ref0.a, ref0.b, ref0.c) == exp[0]
 
+    devs = physical(devs)
     devices(devs)
     assert _lib.device_list() == devs
     prover = Groth16(cs, pk)                                   # the SAME call: zk_groth16_pk_upload shards over the list behind one handle
@@ -119,7 +127,7 @@ def test_multi_device_lagrange_extension_upload_and_mask_form(devices):
     L, R_, Oo = csrs(cs)
     r, s = rng(), rng()
     exp = O.groth16_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(toxic), P.fr_to_bytes(r), P.fr_to_bytes(s))
-    devices([0, 0, 0])
+    devices(physical([0, 0, 0]))
     prover = Groth16(cs, pk, lagrange=True)
     g = prover.prove_rs(w, r, s)
     assert (g.a, g.b, g.c) == exp
@@ -154,7 +162,7 @@ def test_multi_device_key_error_paths(devices):
     devices([0] * 8)
     with pytest.raises(_lib.ZkError):
         Groth16(cs, pk)                                         # a shard would be empty: ZK_ERR_ARG from every failing shard, the others are released
-    _lib.set_device_list([0, 0])                                # possible only because no handle stayed behind
+    _lib.set_device_list(physical([0, 0]))                      # possible only because no handle stayed behind
     prover = Groth16(cs, pk)
     out = np.zeros(384, dtype=np.uint8)
     p8 = out.ctypes.data_as(C.POINTER(C.c_uint8))

@@ -39,12 +39,14 @@ def test_point_sharded_prove_gpu(world, n):
 
 
 @pytest.mark.gpu
-def test_rccl_branches_of_the_collectives_on_a_real_communicator_world_of_one():
+def test_rccl_branches_of_the_collectives_on_a_real_communicator():
     """Every `dist.get_backend() == "nccl"` branch of zukelang_amd/groth16.py (device-resident partial sums, all_gather_into_tensor,
     all_to_all_single with per-destination splits, zk_groth16_combine_device) on a real RCCL communicator.  One rank per device is all
-    RCCL allows, so the one-GPU box runs a world of one: the collectives are self-exchanges, the code path is the one N ranks take, and the
+    RCCL allows: the world is the number of cards the box has (up to four -- the box's process guard allows six on the GPU), so the one-GPU
+    box runs a world of one (self-exchanges through the code N ranks run) and a multi-GPU node runs RCCL between devices with no edit.  The
     proofs must be the trapdoor oracle's."""
-    _run("gpu-rccl", 1, 1000)
+    import torch
+    _run("gpu-rccl", max(1, min(4, torch.cuda.device_count())), 1000)
 
 
 def _bench(args, timeout=900):

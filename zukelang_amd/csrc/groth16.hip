@@ -29,6 +29,15 @@ static CleanupRegistrar g_key_cleanup(handles_release);
 
 static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
 
+// Caller-owned scalar vectors (zk_groth16_msm_partial_async): bit 1 of *flag reports a value >= r.  The digits of a product are only right for
+// canonical scalars (the top window absorbs one carry of a value < 2^255; folded widths take r - s), and nothing upstream has looked at these.
+__global__ void k_check_canonical3(const uint32_t* __restrict__ a, const uint32_t* __restrict__ c, uint64_t n1, const uint32_t* __restrict__ b, uint64_t n2, int* flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i < n1) bad = !fe_is_canonical(fe_load<FrParams>(a + 8 * i)) || !fe_is_canonical(fe_load<FrParams>(c + 8 * i));
+    if (i < n2) bad = bad || !fe_is_canonical(fe_load<FrParams>(b + 8 * i));
+    if (bad) atomicOr(flag, 2);
+}
 // scalar vectors for the three MSMs (canonical form).  rs = r | s (canonical, device).
 __global__ void k_groth16_scalars(uint32_t* __restrict__ scalA, uint32_t* __restrict__ scalC, uint32_t* __restrict__ scalB,
                                   const uint32_t* __restrict__ v, const uint32_t* __restrict__ w, const uint32_t* __restrict__ h,
@@ -144,10 +153,11 @@ int groth16_slot_get(Groth16Key& k, uint32_t idx, Slot** out) {
 // shards of config 4's 2^22 key on eight): 17 divides 255, and with the digits taken from min(s, r - s) (msm.cuh: msm_windows) that is 15 windows
 // instead of 16 for twice the buckets -- measured +3.3 % at 2^19 (where 20 bits lose 2 %); at 2^18 +0.8 ... 1.8 % for 5 % more latency of a lone
 // proof, at 2^16 -6 %: both stay at 16 (profiles/r04_window_17_ab.txt).
-static uint32_t key_window(uint64_t g1_points) {
-    if (getenv("ZK_MSM_WINDOW")) return 0;          // bases_setup reads it
+// Without the subgroup check there are no folded digits (msm.cuh: msm_fold), and 17 bits without them are 16 windows over twice the buckets of 16 bits.
+static uint32_t key_window(uint64_t g1_points, bool in_subgroup) {
+    if (::zk::opt("ZK_MSM_WINDOW")) return 0;          // bases_setup reads it
     if (g1_points >= ((uint64_t)1 << 21)) return 20;
-    if (g1_points >= ((uint64_t)1 << 20)) return 17;
+    if (g1_points >= ((uint64_t)1 << 20)) return in_subgroup ? 17 : 16;
     return msm_auto_window(g1_points, true);
 }
 int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
@@ -182,10 +192,12 @@ int groth16_key_build(std::unique_ptr<Groth16Key>& out, uint32_t n, uint32_t m, 
     // in this rank's G1 pool (n >= ~2^19.6 on one GPU) 20-bit windows: 13 instead of 16 digits per scalar pay for the 16x
     // bucket count and the two-level sort (measured, profiles/r02_window_sweep_*.json: +7.5 % at 2^20, +12 % at 2^22, -2 % at
     // 2^19, -16 % at 2^18); round 4: 17-bit windows, fifteen of them, from 2^20 points (key_window above).  ZK_MSM_WINDOW overrides (config 3's sweep).
-    const uint32_t cw = key_window(k.hi1 - k.lo1);
     // key points are checked like the reference checks them on the way in (of_bytes_exn: encoding, curve, prime-order subgroup); ZK_KEY_SUBGROUP_CHECK=0
-    // skips the subgroup part for keys that were checked before (it is [r] P = O per point: 0.3 s at 2^20 constraints, 1.4 s at 2^22)
-    static const bool chk = !(getenv("ZK_KEY_SUBGROUP_CHECK") && atoi(getenv("ZK_KEY_SUBGROUP_CHECK")) == 0);
+    // (zk_set_option "key_subgroup_check") skips the subgroup part for keys that were checked before (it is [r] P = O per point: 0.3 s at 2^20
+    // constraints, 1.4 s at 2^22).  Read per key (set-up path).  A key uploaded without the check never gets folded windows: msm.cuh.
+    const char* e_chk = ::zk::opt("ZK_KEY_SUBGROUP_CHECK");
+    const bool chk = !(e_chk && atoi(e_chk) == 0);
+    const uint32_t cw = key_window(k.hi1 - k.lo1, chk);
     ZKCHK(msm_bases_from_bytes(k.g1, CURVE_G1, pk_g1 + 96 * k.lo1, k.hi1 - k.lo1, cw, true, c.stream, chk));
     ZKCHK(msm_bases_from_bytes(k.g2, CURVE_G2, pk_g2 + 192 * k.lo2, k.hi2 - k.lo2, cw, true, c.stream, chk));
     ZKCHK(k.mid_idx.alloc(4 * (size_t)(k.n_mid ? k.n_mid : 1)));
@@ -319,8 +331,8 @@ static int prove_enqueue(Groth16Key& k, Slot& sl, const uint8_t* sol, const uint
         // cached); under ZK_TEST_FORMS=1 a slot's graphs are dropped whenever the switches differ from the ones they were captured under.
         if (forms_live()) {
             uint64_t h = 1469598103934665603ull;
-            for (const char* name : {"ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_RED_WAVES", "ZK_SORT_FINE_STAGED", "ZK_SORT_COARSE_STAGED", "ZK_DS_WIDE_GROUP"}) {
-                const char* v = getenv(name);
+            for (const char* name : {"ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_RED_WAVES", "ZK_SORT_FINE_STAGED", "ZK_SORT_COARSE_STAGED", "ZK_DS_WIDE_GROUP", "ZK_FR_RNS"}) {
+                const char* v = ::zk::opt(name);
                 for (const char* q = v ? v : "\x01"; *q; q++) h = (h ^ (uint8_t)*q) * 1099511628211ull;
                 h = (h ^ 0xff) * 1099511628211ull;
             }
@@ -368,7 +380,7 @@ int groth16_prove_finish(Slot& sl) {
     sl.busy = false;
     int hf;
     memcpy(&hf, sl.host + 384, 4);
-    if (hf & 2) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "witness value >= r");
+    if (hf & 2) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "an Fr input (witness value, or a scalar of a caller-owned vector) is >= r");
     if (hf & 1) ZK_FAIL(ZK_ERR_REMAINDER, "p mod Z != 0");
     return ZK_OK;
 }
@@ -448,9 +460,10 @@ int groth16_install_lagrange(Groth16Key& k, const void* d_g1, const void* d_g2, 
     groth16_shard_range(p1n, p2n + 1, rank, world, &lo1, &hi1);        // p2n + 1 = 3 + the n Lagrange points: the A prefix counts twice
     groth16_shard_range(p2n, 0, rank, world, &lo2, &hi2);
     if (hi1 == lo1 || hi2 == lo2) ZK_FAIL(ZK_ERR_ARG, "install_lagrange: more ranks than key points");
-    const uint32_t cw = key_window(hi1 - lo1);
-    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, (const uint8_t*)d_g1 + 96 * lo1, hi1 - lo1, cw, true, c.stream));
-    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, (const uint8_t*)d_g2 + 192 * lo2, hi2 - lo2, cw, true, c.stream));
+    // the derived pools are linear combinations of the key's own points: in the subgroup exactly when those were checked (msm.cuh: msm_fold)
+    const uint32_t cw = key_window(hi1 - lo1, k.g1.in_subgroup);
+    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, (const uint8_t*)d_g1 + 96 * lo1, hi1 - lo1, cw, true, c.stream, k.g1.in_subgroup));
+    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, (const uint8_t*)d_g2 + 192 * lo2, hi2 - lo2, cw, true, c.stream, k.g2.in_subgroup));
     ZKCHK(frstage_init_lagrange(k.fr, c.stream));        // ADDS the Lagrange tables to the Fr stage; the tau-power path keeps working until `lagrange` flips
     HIPCHK(hipStreamSynchronize(c.stream));              // the caller's pools have been read
     HIPCHK(hipGetLastError());
@@ -497,14 +510,14 @@ int zk_groth16_pk_shard(uint64_t handle, uint32_t rank, uint32_t world) {
     for (uint32_t i = 0; i < MAX_SLOTS; i++) k.slots[i].reset();
     // window 0 of the resident tables is the pool in order: the rank keeps its contiguous slice and builds its own window tables
     MsmBases g1, g2;
-    const uint32_t cw = key_window(hi1 - lo1);
+    const uint32_t cw = key_window(hi1 - lo1, k.g1.in_subgroup);
     DevBuf d1, d2;
     ZKCHK(d1.alloc(96 * (hi1 - lo1)));
     ZKCHK(d2.alloc(192 * (hi2 - lo2)));
     ZKCHK(msm_bases_dense(k.g1, lo1, hi1 - lo1, d1.p, c.stream));
     ZKCHK(msm_bases_dense(k.g2, lo2, hi2 - lo2, d2.p, c.stream));
-    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, d1.p, hi1 - lo1, cw, true, c.stream));
-    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, d2.p, hi2 - lo2, cw, true, c.stream));
+    ZKCHK(msm_bases_from_device_affine(g1, CURVE_G1, d1.p, hi1 - lo1, cw, true, c.stream, k.g1.in_subgroup));      // a slice of checked points is checked
+    ZKCHK(msm_bases_from_device_affine(g2, CURVE_G2, d2.p, hi2 - lo2, cw, true, c.stream, k.g2.in_subgroup));
     HIPCHK(hipStreamSynchronize(c.stream));
     k.g1 = std::move(g1);
     k.g2 = std::move(g2);
@@ -696,7 +709,17 @@ int zk_groth16_msm_partial_async(uint64_t handle, uint32_t slot, const void* d_s
     Slot* sl;
     ZKCHK(groth16_slot_get(*k, slot, &sl));
     if (sl->busy) ZK_FAIL(ZK_ERR_ARG, "slot still has work in flight: call the matching _wait first");
-    memset(sl->host + 384, 0, 4);      // the remainder / range flags belong to the Fr stage, which ran elsewhere (zk_groth16_scalars_wait)
+    // the remainder flag belongs to the Fr stage, which ran elsewhere (zk_groth16_scalars_wait); the RANGE of these vectors is checked here: they are
+    // caller-owned device memory nobody has looked at (ZK_ERR_SCALAR_RANGE from the matching _wait)
+    memset(sl->host + 384, 0, 4);
+    {
+        const uint64_t n1 = k->hi1 - k->lo1, n2 = k->hi2 - k->lo2;
+        HIPCHK(hipMemsetAsync(sl->fs.flag.p, 0, 4, sl->s0));
+        hipLaunchKernelGGL(k_check_canonical3, g1d(n1 > n2 ? n1 : n2), dim3(256), 0, sl->s0, (const uint32_t*)d_scal_a_slice, (const uint32_t*)d_scal_c_slice, n1,
+                           (const uint32_t*)d_scal_b_slice, n2, sl->fs.flag.as<int>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(sl->host + 384, sl->fs.flag.p, 4, hipMemcpyDeviceToHost, sl->s0));
+    }
     ZKCHK(groth16_msms_enqueue(*k, *sl, d_scal_a_slice, d_scal_c_slice, d_scal_b_slice, true));
     HIPCHK(hipMemcpyAsync(sl->host_partial, sl->results.p, ZK_GROTH16_PARTIAL_BYTES, hipMemcpyDeviceToHost, sl->s0));
     HIPCHK(hipEventRecord(sl->done, sl->s0));

@@ -91,10 +91,20 @@ template <class F> static int on_every_device(size_t count, F f) {
         if (gi == groups.size()) groups.emplace_back();
         groups[gi].push_back((int)v);
     }
+    // f allocates (std::vector, make_unique, device buffers): an exception that left a thread function would be std::terminate for the host process --
+    // it becomes a return code like every other failure
     auto run_group = [&rc, &f](const std::vector<int>& vs) {
         for (int v : vs) {
             DeviceScope ds(v);
-            rc[v] = f(v);
+            try {
+                rc[v] = f(v);
+            } catch (const std::bad_alloc&) {
+                rc[v] = set_error(ZK_ERR_HIP, "out of host memory while setting a device of the key up", __FILE__, __LINE__);
+            } catch (const std::exception& e) {
+                rc[v] = set_error(ZK_ERR_HIP, e.what(), __FILE__, __LINE__);
+            } catch (...) {
+                rc[v] = set_error(ZK_ERR_HIP, "exception while setting a device of the key up", __FILE__, __LINE__);
+            }
         }
     };
     // A host thread that cannot be started (the process is at its thread limit) must not take the process down: std::thread's constructor throws,
@@ -119,7 +129,7 @@ template <class F> static int on_every_device(size_t count, F f) {
 }
 
 static void trace(const char* what) {
-    static const bool on = getenv("ZK_TRACE") != nullptr;
+    static const bool on = getenv("ZK_TRACE") != nullptr;          // diagnostics: environment only
     if (on) {
         fprintf(stderr, "[zk multi] %s\n", what);
         fflush(stderr);

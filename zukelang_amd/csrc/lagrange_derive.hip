@@ -612,7 +612,7 @@ int groth16_derive_lagrange_pools(const FrStage& f, const uint8_t* d_g1, uint64_
     // The sets are independent, and a stage of one set is n2 / 2 scalar multiplications of ~2 ms (G1) / ~4 ms (G2) each: below 2^19 gates that is fewer
     // waves than the chip has SIMDs (2^16: 512 of 1024 for a G1 set), and a stage takes one multiplication's latency however few waves it has.  Up to
     // DERIVE_SIDE_BY_SIDE_MAX_LOG the selected sets therefore run side by side on their own streams (ZK_DERIVE_SIDE_BY_SIDE=0 / 1 overrides).
-    const char* e_sbs = getenv("ZK_DERIVE_SIDE_BY_SIDE");          // per derivation, not per proof: read every time (tests run both orders in one process)
+    const char* e_sbs = ::zk::opt("ZK_DERIVE_SIDE_BY_SIDE");          // per derivation, not per proof: read every time (tests run both orders in one process)
     const bool several = (sets & (sets - 1)) != 0;
     const bool side_by_side = several && (e_sbs ? atoi(e_sbs) != 0 : f.log_n2 <= DERIVE_SIDE_BY_SIDE_MAX_LOG);
     ScopedTimer tm("lagrange_derive", s);

@@ -14,7 +14,11 @@ static inline size_t xyzz_bytes(Curve c) { return c == CURVE_G1 ? 192 : 384; }
 // fold: the digits are taken from min(s, r - s) < r / 2 < 0.4529 * 2^255 with the sign carried to every digit (resident keys: their points are in the
 // prime-order subgroup, (r - s) P = -s P).  The recoding constant K is < 2^(c nw - 1) (1 + 2^-(c-1)), so min(s, r - s) + K < 2^255 and a width that
 // DIVIDES 255 (c = 3, 5, 15, 17) needs no window for the last carry: 15 windows at c = 17 instead of 16.
-static inline bool msm_fold(uint32_t c, bool precomp) { return precomp && 255 % c == 0; }
+// Two preconditions, both enforced where the bases are built / the scalars enter: (1) the points have order r -- MsmBases::in_subgroup, set only when
+// the [r] P = O test ran on them or they were derived on the device from points it ran on; a base set without it never folds, whatever its width;
+// (2) the scalars are canonical (< r) -- every entry point that takes scalars checks it (the Fr stage for a witness, zk_groth16_msm_partial_async
+// for caller-owned device vectors).
+static inline bool msm_fold(uint32_t c, bool precomp, bool in_subgroup) { return precomp && in_subgroup && 255 % c == 0; }
 static inline uint32_t msm_windows(uint32_t c, bool fold = false) { return fold && 255 % c == 0 ? 255 / c : 255 / c + 1; }
 
 struct MsmBases {
@@ -24,6 +28,7 @@ struct MsmBases {
     uint32_t nw = 0;         // windows
     bool precomp = false;    // table holds 2^(c*j) * P_i for j < nw at [j*n + i]; one bucket set
     bool fold = false;       // digits of min(s, r - s): see msm_windows
+    bool in_subgroup = false; // every point is known to have order r (checked at upload, or derived on the device from checked points)
     DevBuf table;            // affine Montgomery points in the 128-byte record layout of ec.cuh (TableLayout): canonical limbs, one cache line per lane and gather
     DevBuf ident;            // one byte per point, 1 = the base is the identity (the sort never files it into a bucket: table entries the accumulate loop meets are genuine points)
 };
@@ -60,7 +65,8 @@ uint32_t msm_auto_window(uint64_t n, bool precomp);
 // check_subgroup: also require [r] P = O of every point (proving keys: the reference's of_bytes_exn raises otherwise, curve.ml:199-212)
 int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s, bool check_subgroup = false);
 // d_affine: n DENSE affine points (96 / 192 B each); it must stay valid until the stream has run the table build
-int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s);
+// in_subgroup: the caller vouches that the points have order r (they were derived on the device from a base set whose in_subgroup is set)
+int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s, bool in_subgroup = false);
 // base points [lo, lo + count) of the set (window 0 of the table) back in the dense affine format, exact
 int msm_bases_dense(const MsmBases& b, uint64_t lo, uint64_t count, void* d_dense, hipStream_t s);
 // max_nonzero: upper bound of the non-zero scalars this workspace's products ever carry (0 = all of b.n): sizes the batch-affine buffers

@@ -888,14 +888,14 @@ int msm_bases_dense(const MsmBases& b, uint64_t lo, uint64_t count, void* d_dens
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
-static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool precomp) {
+static int bases_setup(MsmBases& b, Curve curve, uint64_t n, uint32_t c, bool precomp, bool in_subgroup) {
     if (n == 0) ZK_FAIL(ZK_ERR_ARG, "msm: empty base set");
     if (c == 0) {
-        const char* e = getenv("ZK_MSM_WINDOW");         // window-size sweeps (BASELINE config 3); key set-up, not a per-proof path
+        const char* e = ::zk::opt("ZK_MSM_WINDOW");         // window-size sweeps (BASELINE config 3); key set-up, not a per-proof path
         c = e ? (uint32_t)atoi(e) : msm_auto_window(n, precomp);
     }
     if (c < 2 || c > 22) ZK_FAIL(ZK_ERR_ARG, "msm: window_bits must be in [2, 22]");
-    b.curve = curve; b.n = n; b.c = c; b.precomp = precomp; b.fold = msm_fold(c, precomp); b.nw = msm_windows(c, b.fold);
+    b.curve = curve; b.n = n; b.c = c; b.precomp = precomp; b.in_subgroup = in_subgroup; b.fold = msm_fold(c, precomp, in_subgroup); b.nw = msm_windows(c, b.fold);
     if ((precomp ? (uint64_t)b.nw : 1) * n >= ((uint64_t)1 << 31)) ZK_FAIL(ZK_ERR_ARG, "msm: too many points for 31-bit references");
     return b.table.alloc(table_entry_bytes(curve) * n * (precomp ? b.nw : 1));
 }
@@ -937,12 +937,12 @@ int points_xyzz_to_bytes(Curve curve, const void* d_xyzz, uint64_t count, uint8_
     HIPCHK(hipStreamSynchronize(s));
     return ZK_OK;
 }
-int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s) {
-    ZKCHK(bases_setup(b, curve, n, c, precomp));
+int msm_bases_from_device_affine(MsmBases& b, Curve curve, const void* d_affine, uint64_t n, uint32_t c, bool precomp, hipStream_t s, bool in_subgroup) {
+    ZKCHK(bases_setup(b, curve, n, c, precomp, in_subgroup));
     return curve == CURVE_G1 ? bases_finish<Fp>(b, d_affine, s) : bases_finish<Fp2>(b, d_affine, s);
 }
 int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s, bool check_subgroup) {
-    ZKCHK(bases_setup(b, curve, n, c, precomp));
+    ZKCHK(bases_setup(b, curve, n, c, precomp, check_subgroup));      // folded digits only for points the [r] P = O test below has passed
     DevBuf raw, dense, flag;
     ZKCHK(raw.alloc(aff_bytes(curve) * n));
     ZKCHK(dense.alloc(aff_bytes(curve) * n));
@@ -974,10 +974,10 @@ static uint32_t ba_rounds_for(const MsmBases& b, uint32_t nbuckets) {
     // (bit 0: G1, bit 1: G2).  Default: none -- measured on MI355X: the rounds re-read what they add from HBM, ~1 KB
     // per G1 addition in round 0 (two random 128-byte-line gathers of each table entry), and lose to the register-resident XYZZ
     // accumulate for G1; for G2 they break even.  Read per workspace, not cached: tests switch it.
-    const int forced = getenv("ZK_MSM_BA_ROUNDS") ? atoi(getenv("ZK_MSM_BA_ROUNDS")) : -1;
+    const int forced = ::zk::opt("ZK_MSM_BA_ROUNDS") ? atoi(::zk::opt("ZK_MSM_BA_ROUNDS")) : -1;
     if (forced == 0) return 0;
     if (forced > 0) return forced > 24 ? 24 : (uint32_t)forced;
-    const int curves = getenv("ZK_MSM_BA_CURVES") ? atoi(getenv("ZK_MSM_BA_CURVES")) : 0;
+    const int curves = ::zk::opt("ZK_MSM_BA_CURVES") ? atoi(::zk::opt("ZK_MSM_BA_CURVES")) : 0;
     if (!(curves & (b.curve == CURVE_G1 ? 1 : 2))) return 0;
     const uint64_t mean = b.n * b.nw / nbuckets;
     uint32_t r = 0;
@@ -992,9 +992,9 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     // >= 2 waves per SIMD when there is enough work; chunks of at least 16 entries (with a dozen proofs in flight the
     // chip is full anyway, and every chunk boundary costs a partial sum to store and to fix up: 8 -> 16 is +2.5 % proofs/s
     // at 2^16, 16..24 measure the same, 32 and up lose to the tail of the longest chunk)
-    static const uint64_t target_threads = getenv("ZK_MSM_TARGET_THREADS") ? (uint64_t)atoll(getenv("ZK_MSM_TARGET_THREADS")) : 256 * 1024;   // tuning knob
+    static const uint64_t target_threads = ::zk::opt("ZK_MSM_TARGET_THREADS") ? (uint64_t)atoll(::zk::opt("ZK_MSM_TARGET_THREADS")) : 256 * 1024;   // tuning knob
     uint32_t chunk = (uint32_t)((maxN + target_threads - 1) / target_threads);
-    static const uint32_t chunk_min = getenv("ZK_MSM_CHUNK_MIN") ? (uint32_t)atoi(getenv("ZK_MSM_CHUNK_MIN")) : 16;   // tuning knob
+    static const uint32_t chunk_min = ::zk::opt("ZK_MSM_CHUNK_MIN") ? (uint32_t)atoi(::zk::opt("ZK_MSM_CHUNK_MIN")) : 16;   // tuning knob
     if (launch_entries && chunk >= 64) {            // short chunks (small keys) already fill whole rounds: at 2^16, 2 rounds of 16-entry chunks beat 1 round of 32; 48 instead of 64 (the G2 product of a 2^20 key: one round of 208 instead of four of 52) measures the same
         // The caller knows how many sorted entries ONE accumulate launch carries (several products over these bases, e.g. Groth16's A and C):
         // cut it into a WHOLE number of rounds of the chip's resident lanes (256 CUs x 4 SIMDs x ACC_WAVES_G1 = ACC_WAVES_G2 = 2 waves x 64 lanes, half as many
@@ -1021,8 +1021,8 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
     // single-level sort below), but its 128 KiB per workgroup evict the accumulate workgroups of the other proofs in flight from every compute unit
     // the sort runs on: two levels (2 KiB + 20 KiB of LDS) measure +1.6 % proofs/s at 2^16, +1.9 % at 2^18 with the same single-proof latency.
     // ZK_SORT_TWO_LEVEL=0: never (A/B; above 2^15 buckets that is the global-atomic sort); ZK_SORT_TWO_LEVEL_MIN: log2 of the pair threshold.
-    const int two_level = getenv("ZK_SORT_TWO_LEVEL") ? atoi(getenv("ZK_SORT_TWO_LEVEL")) : 1;
-    const int two_level_min = getenv("ZK_SORT_TWO_LEVEL_MIN") ? atoi(getenv("ZK_SORT_TWO_LEVEL_MIN")) : (w.nbuckets > 2 * SORT_MAX_BUCKETS ? 22 : 20);          // 2^16 buckets (c = 17) sort in two levels from 2^20 pairs like 2^15
+    const int two_level = ::zk::opt("ZK_SORT_TWO_LEVEL") ? atoi(::zk::opt("ZK_SORT_TWO_LEVEL")) : 1;
+    const int two_level_min = ::zk::opt("ZK_SORT_TWO_LEVEL_MIN") ? atoi(::zk::opt("ZK_SORT_TWO_LEVEL_MIN")) : (w.nbuckets > 2 * SORT_MAX_BUCKETS ? 22 : 20);          // 2^16 buckets (c = 17) sort in two levels from 2^20 pairs like 2^15
     if (b.precomp && w.nbuckets >= SORT_MAX_BUCKETS && w.nbuckets / COARSE_BINS <= SORT_MAX_FINE && maxN >= ((uint64_t)1 << two_level_min) && two_level != 0) {
         w.sort_fine_bits = ceil_log2(w.nbuckets / COARSE_BINS);
         uint64_t wgs = maxN / (4 * (uint64_t)COARSE_BINS);
@@ -1037,7 +1037,7 @@ int msm_workspace_alloc(MsmWorkspace& w, const MsmBases& b, uint64_t max_nonzero
         // tuning knob.  With scalar-major passes 8 workgroups already beat the global atomics (2^16: 37.3 -> 38.7-39.4 M constraints/s, the
         // sort 0.61 -> 0.45 ms per proof; below 8 -- pools of 2^14 constraints -- the global path wins: 23.6 M against 22.3-22.6); it was 64
         // with window-major passes
-        static const uint64_t min_wgs = getenv("ZK_SORT_MIN_WGS") ? (uint64_t)atoll(getenv("ZK_SORT_MIN_WGS")) : 8;
+        static const uint64_t min_wgs = ::zk::opt("ZK_SORT_MIN_WGS") ? (uint64_t)atoll(::zk::opt("ZK_SORT_MIN_WGS")) : 8;
         if (wgs >= min_wgs) {                               // below that too few workgroups: the global-atomic path is cheaper
             w.sort_wgs = (uint32_t)wgs;
             ZKCHK(w.wgcount.alloc(4 * (size_t)w.nbuckets * wgs));
@@ -1092,10 +1092,10 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
     const uint32_t nbw = 1u << (b.c - 1);
     // scalar-major LDS sorts need ONE bucket set (resident keys: every window files into the same 2^(c-1) buckets); ZK_SORT_SCALAR_MAJOR=0 restores
     // the window-major ranges
-    static const bool want_sm = !(getenv("ZK_SORT_SCALAR_MAJOR") && atoi(getenv("ZK_SORT_SCALAR_MAJOR")) == 0);
+    static const bool want_sm = !(::zk::opt("ZK_SORT_SCALAR_MAJOR") && atoi(::zk::opt("ZK_SORT_SCALAR_MAJOR")) == 0);
     const bool sm = want_sm && b.precomp && w.sort_wgs != 0;
 #ifdef ZK_EXPERIMENTS
-    static const uint32_t alias = (getenv("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(getenv("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u;
+    static const uint32_t alias = (::zk::opt("ZK_EXPERIMENT_TABLE_ALIAS") && atoi(::zk::opt("ZK_EXPERIMENT_TABLE_ALIAS"))) ? 1u : 0u;
 #else
     const uint32_t alias = 0u;
 #endif
@@ -1140,7 +1140,19 @@ int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const v
             SortJobs l2 = sj;
             for (uint32_t i = 0; i < count; i++) l2.cursor[i] = l1.offsets[i];          // the coarse offsets (k_scan wrote offsets = cursor; the scatter advanced neither: it ranks in LDS)
             const char* e_st = ZK_FORM_ENV("ZK_SORT_FINE_STAGED");          // a kernel-form switch (zk_common.h)
-            const bool staged = e_st ? atoi(e_st) != 0 : b.n * b.nw / bins >= SORT_FINE_STAGED_MIN;
+            bool staged = e_st ? atoi(e_st) != 0 : b.n * b.nw / bins >= SORT_FINE_STAGED_MIN;
+            // its static LDS (part + the two staging tiles) plus 8 bytes per fine bucket must fit the device's per-workgroup limit (84 KB at c = 22; the
+            // MI355X allows 160 KB): asked once per device, the plain form serves wherever it does not fit
+            if (staged) {
+                static int lds_limit[64] = {0};
+                const int dev = ctx().device >= 0 && ctx().device < 64 ? ctx().device : 0;
+                if (!lds_limit[dev]) {
+                    int v = 0;
+                    lds_limit[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx().device) == hipSuccess && v > 0 ? v : 65536;
+                }
+                const size_t need = sort_fine_staged_lds(w.sort_fine_bits) + 4 * (size_t)SORT_THREADS + 8 * (size_t)SORT_TILE;
+                if (need > (size_t)lds_limit[dev]) staged = false;
+            }
             if (staged) hipLaunchKernelGGL(k_sort_fine_staged, dim3(bins, count), dim3(SORT_THREADS), sort_fine_staged_lds(w.sort_fine_bits), s, l2, w.sort_fine_bits, bins, w.nbuckets);
             else hipLaunchKernelGGL(k_sort_fine, dim3(bins, count), dim3(SORT_THREADS), 0, s, l2, w.sort_fine_bits, bins, w.nbuckets);
         } else if (w.sort_wgs) {
@@ -1341,7 +1353,7 @@ static int msm_api(Curve curve, const uint8_t* bases, size_t nbases, const uint8
     MsmWorkspace w;
     // ZK_MSM_API_PRECOMP=1 runs this entry point through the resident-key machinery (window tables, one bucket set, batch-affine
     // rounds): how the tests reach those kernels with adversarial base sets (duplicates, negations, the identity)
-    const bool precomp = getenv("ZK_MSM_API_PRECOMP") && atoi(getenv("ZK_MSM_API_PRECOMP")) != 0;
+    const bool precomp = ::zk::opt("ZK_MSM_API_PRECOMP") && atoi(::zk::opt("ZK_MSM_API_PRECOMP")) != 0;
     ZKCHK(msm_bases_from_bytes(b, curve, bases, nscalars, window_bits, precomp, c.stream));
     ZKCHK(msm_workspace_alloc(w, b));
     DevBuf sc, res, flag;

@@ -6,7 +6,7 @@
 namespace zk {
 
 static uint64_t env_u64(const char* name, uint64_t dflt) {
-    const char* e = getenv(name);
+    const char* e = ::zk::opt(name);
     return e ? (uint64_t)atoll(e) : dflt;
 }
 

@@ -50,9 +50,9 @@ struct PinSlot {
 static constexpr uint32_t PIN_MAX_SLOTS = 15;
 // key points are checked like the reference checks them on the way in (of_bytes_exn, curve.ml:199-212: encoding, curve, prime-order subgroup);
 // ZK_KEY_SUBGROUP_CHECK=0 skips the subgroup part (see groth16.hip)
-static bool key_subgroup_check() {
-    static const bool chk = !(getenv("ZK_KEY_SUBGROUP_CHECK") && atoi(getenv("ZK_KEY_SUBGROUP_CHECK")) == 0);
-    return chk;
+static bool key_subgroup_check() {          // read per key (set-up path); without the check a pool never gets folded windows (msm.cuh)
+    const char* e = ::zk::opt("ZK_KEY_SUBGROUP_CHECK");
+    return !(e && atoi(e) == 0);
 }
 struct PinKey {
     uint32_t n = 0, m = 0, n_mid = 0;
@@ -222,7 +222,7 @@ int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
     HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * (uint64_t)n, si, 96, hipMemcpyDeviceToDevice, c.stream));                                       // [1] = si[0]
     HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * ((uint64_t)n + 1), si + 96 * ((uint64_t)n + 1), 96 * 2 * (uint64_t)k.m, hipMemcpyDeviceToDevice, c.stream));   // v_all | w_all
     MsmBases nb;
-    ZKCHK(msm_bases_from_device_affine(nb, CURVE_G1, pool.p, ph, old.c, true, c.stream));
+    ZKCHK(msm_bases_from_device_affine(nb, CURVE_G1, pool.p, ph, old.c, true, c.stream, old.in_subgroup));      // derived from the old pool's points: msm.cuh, msm_fold
     ZKCHK(frstage_init_lagrange(k.fr, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     k.g1[5] = std::move(nb);
@@ -267,7 +267,7 @@ static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
         ZKCHK(sl->out_dev.alloc(960));
         HIPCHK(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
-        if (idx == 0 && !getenv("ZK_SERIAL_STREAMS")) {
+        if (idx == 0 && !::zk::opt("ZK_SERIAL_STREAMS")) {
             // the slot of the synchronous zk_pinocchio_prove: two more streams, used only while no other proof is in flight (groth16.hip, slot 0)
             HIPCHK(hipStreamCreateWithFlags(&sl->s1, hipStreamNonBlocking));
             HIPCHK(hipStreamCreateWithFlags(&sl->s2, hipStreamNonBlocking));

@@ -38,6 +38,62 @@ __attribute__((constructor)) static void zk_request_hw_queues() {
     }
 }
 
+// ---- options: zk_set_option(name, value) first, the environment second (zk_common.h: opt)
+// The public knobs -- the ones that are not test-only.  A name is accepted with or without its "ZK_" prefix, in either case.
+static const char* const PUBLIC_OPTIONS[] = {
+    "ZK_MSM_WINDOW",            // Pippenger window bits of keys uploaded afterwards (default: per key size, msm_auto_window / groth16.hip)
+    "ZK_KEY_SUBGROUP_CHECK",    // 0: skip the [r] P = O test of key points at upload (keys checked before); folded 17-bit windows are then not used
+    "ZK_SLOT_STREAMS",          // 3: three streams for every proof slot, 1: one
+    "ZK_SERIAL_STREAMS",        // 1: a lone proof stays on one stream
+    "ZK_GRAPH",                 // 1: capture each slot's proof into a hipGraph and replay it
+    "ZK_MSM_CHUNK_MIN", "ZK_MSM_TARGET_THREADS",      // accumulate chunking
+    "ZK_SORT_TWO_LEVEL", "ZK_SORT_TWO_LEVEL_MIN", "ZK_SORT_MIN_WGS", "ZK_SORT_SCALAR_MAJOR", "ZK_SORT_FINE_STAGED", "ZK_SORT_COARSE_STAGED",
+    "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_DS_WIDE_GROUP", "ZK_RED_WAVES",
+    "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_MSM_BA_CURVES", "ZK_MSM_BA_ROUNDS", "ZK_MSM_API_PRECOMP",
+    "ZK_DERIVE_SIDE_BY_SIDE", "ZK_FR_RNS", "ZK_LONE_SPLIT",
+};
+struct OptionTable {
+    std::mutex mu;
+    std::vector<std::pair<std::string, const char*>> set;      // name -> value (nullptr: explicitly unset, i.e. back to the environment)
+    std::vector<std::string*> arena;                           // values live for ever: ZK_ENV call sites keep the pointer
+};
+static OptionTable& options() {
+    static OptionTable* t = new OptionTable;
+    return *t;
+}
+const char* opt(const char* name) {
+    OptionTable& t = options();
+    {
+        std::lock_guard<std::mutex> g(t.mu);
+        for (auto& kv : t.set)
+            if (kv.first == name) {
+                if (kv.second) return kv.second;
+                break;
+            }
+    }
+    return getenv(name);
+}
+static int option_set(const char* name, const char* value) {
+    if (!name || !*name) ZK_FAIL(ZK_ERR_ARG, "zk_set_option: no name");
+    std::string up;
+    for (const char* q = name; *q; q++) up.push_back((char)((*q >= 'a' && *q <= 'z') ? *q - 32 : *q));
+    if (up.compare(0, 3, "ZK_") != 0) up = "ZK_" + up;
+    bool known = false;
+    for (const char* k : PUBLIC_OPTIONS) known = known || up == k;
+    if (!known) ZK_FAIL(ZK_ERR_ARG, "zk_set_option: unknown option name");
+    OptionTable& t = options();
+    std::lock_guard<std::mutex> g(t.mu);
+    const char* stored = nullptr;
+    if (value) {
+        t.arena.push_back(new std::string(value));
+        stored = t.arena.back()->c_str();
+    }
+    for (auto& kv : t.set)
+        if (kv.first == up) { kv.second = stored; return ZK_OK; }
+    t.set.emplace_back(up, stored);
+    return ZK_OK;
+}
+
 // The device list and its contexts.  Contexts are heap-allocated and never destroyed (event / stream handles must not be touched at exit).
 static std::vector<Ctx*>& ctxs() {
     static std::vector<Ctx*>* v = new std::vector<Ctx*>;
@@ -264,7 +320,15 @@ static int contexts_create(const int32_t* devices, uint32_t count) {
     (void)hipGetDevice(&prev);
     std::vector<Ctx*> made;
     auto fail = [&](int rc) {
-        for (Ctx* c : made) {          // streams of a half-built list leak with the process; the list itself stays empty
+        for (Ctx* c : made) {          // nothing of a half-built list survives: its streams and events go with it
+            if (c->device >= 0 && hipSetDevice(c->device) == hipSuccess) {
+                if (c->stream) (void)hipStreamDestroy(c->stream);
+                if (c->stream2) (void)hipStreamDestroy(c->stream2);
+                if (c->stream3) (void)hipStreamDestroy(c->stream3);
+                if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+                if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+                if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+            }
             delete c->bufs;
             delete c;
         }
@@ -357,8 +421,18 @@ int zk_set_device_list(const int32_t* devices, uint32_t count) {
     if (count > 64) ZK_FAIL(ZK_ERR_ARG, "device list: 1 .. 64 entries");
     for (uint32_t i = 0; i < count; i++)
         if (devices[i] < 0 || devices[i] >= n) ZK_FAIL(ZK_ERR_ARG, "device index out of range");
+    // The contexts own per-device tables the cleanup hooks release (twiddles, generator tables), so the old list has to go before the new one is
+    // built; should building it fail all the same (a HIP error in hipSetDevice or a stream creation), the previous list is put back -- a later call
+    // must not find the library unbound and silently bind device 0.
+    std::vector<int32_t> before;
+    for (int v = 0; v < ctx_count(); v++) before.push_back(ctx_at(v).device);
     ZKCHK(zk_shutdown());
-    return contexts_create(devices, count);
+    const int rc = contexts_create(devices, count);
+    if (rc != ZK_OK && !before.empty()) {
+        const std::string why = zk_last_error();
+        if (contexts_create(before.data(), (uint32_t)before.size()) == ZK_OK) return set_error(rc, ("the new device list could not be built; the previous one is back in place: " + why).c_str(), __FILE__, __LINE__);
+    }
+    return rc;
 }
 int zk_set_devices(uint64_t mask) {
     int32_t list[64];
@@ -376,6 +450,7 @@ int zk_get_device_list(int32_t* devices, uint32_t capacity, uint32_t* count) {
     return ZK_OK;
 }
 
+int zk_set_option(const char* name, const char* value) { return option_set(name, value); }
 int zk_sync(void) {
     // every stream of the process on every device of the list: the context streams AND the per-slot streams of every key (proofs in flight run on
     // hipStreamNonBlocking slot streams; zk_profile_get reads events recorded there)

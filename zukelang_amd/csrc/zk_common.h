@@ -54,8 +54,9 @@ int ensure_init();
 uint64_t live_key_handles();             // Groth16 + Pinocchio key handles alive (groth16.hip / pinocchio.hip): the device list may only change at 0
 std::vector<void (*)()>& cleanup_hooks();   // run by zk_shutdown once per context (that context current), before its streams die
 struct CleanupRegistrar { explicit CleanupRegistrar(void (*f)()) { cleanup_hooks().push_back(f); } };
-// device -> device copy between two virtual devices on `s` (a stream of the DESTINATION's context): hipMemcpyPeerAsync over xGMI when the HIP devices
-// differ, a plain device copy when both shards sit on one card
+// device -> device copy between two virtual devices on `s` -- a stream of the CALLING thread's current device, which may be the source's or the
+// destination's (HIP takes a stream of either side for a peer copy; groth16_multi.hip pushes partial sums on the source shard's stream and pulls
+// scalar slices on the destination's): hipMemcpyPeerAsync over xGMI when the HIP devices differ, a plain device copy when both shards sit on one card
 int copy_between(void* dst, int dst_vdev, const void* src, int src_vdev, size_t bytes, hipStream_t s);
 
 #define HIPCHK(expr)                                                                      \
@@ -106,9 +107,14 @@ struct ScopedTimer {
 
 void profile_count(const char* name, uint64_t add);      // no-op unless profiling level 2 is on
 
-// Environment knobs are read ONCE per process (tuning switches; a getenv per launch is a libc lock + string scan on the proof's hot path): a C++11
-// function-local static per call site, initialised thread-safely by the language.
-#define ZK_ENV(name) ([]() -> const char* { static const char* const v = getenv(name); return v; }())
+// A tuning knob by its name ("ZK_MSM_WINDOW"): the value given through zk_set_option (the C-ABI's own configuration call: a host that cannot
+// set the process environment reliably after dlopen -- an OCaml program -- uses that), else the environment variable of the same name, else nullptr.
+// The returned pointer stays valid for the life of the process (option values are never freed or overwritten in place).  zk_api.hip.
+const char* opt(const char* name);
+// Knobs are read ONCE per process (tuning switches; a lookup per launch is a lock + string scan on the proof's hot path): a C++11
+// function-local static per call site, initialised thread-safely by the language.  zk_set_option therefore acts on what has not run yet: set
+// options before the first key is uploaded.
+#define ZK_ENV(name) ([]() -> const char* { static const char* const v = ::zk::opt(name); return v; }())
 // The kernel-FORM switches of a proof (msm.hip msm_reduce_mixed: ZK_TAIL_SLOTS, ZK_TAIL_FIXUP_SLOTS, ZK_FIXUP_BY_CHUNK, ZK_DS_WIDE_GROUP; msm_sort_accumulate_many: ZK_SORT_FINE_STAGED, ZK_SORT_COARSE_STAGED; msm_red.hip: ZK_RED_WAVES; msm_acc_g1/g2.hip:
 // ZK_ACC_G1_GLDS, ZK_ACC_G1_MMADD, ZK_ACC_G2_INLINE; groth16.hip: ZK_GRAPH) are cached like every other knob -- a proof costs no getenv at all --
 // unless the process was started with ZK_TEST_FORMS=1 (tests/conftest.py sets it): then they are read per call, so that the GPU suite can hold every
@@ -117,7 +123,7 @@ static inline bool forms_live() {
     static const bool live = [] { const char* e = getenv("ZK_TEST_FORMS"); return e && atoi(e) != 0; }();
     return live;
 }
-#define ZK_FORM_ENV(name) (::zk::forms_live() ? (const char*)getenv(name) : ZK_ENV(name))
+#define ZK_FORM_ENV(name) (::zk::forms_live() ? ::zk::opt(name) : ZK_ENV(name))
 
 static inline uint32_t ceil_log2(uint64_t x) {
     uint32_t l = 0;
