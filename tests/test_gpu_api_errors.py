@@ -118,10 +118,12 @@ def _set_option(name, value):
 def test_a_key_uploaded_without_the_subgroup_check_never_gets_folded_windows():
     """Folded digits take min(s, r - s) -- one window fewer at the widths that divide 255 (c = 3, 5, 15, 17; 17 is the default from 2^20 pool points) --
     and (r - s)(-P) = s P only for points of order r.  The width and the check used to be two unrelated environment knobs (ADVICE r4
-    medium): a key uploaded with the check skipped and one point outside the subgroup gave wrong proof bytes and ZK_OK.  Now a base set folds only
-    when the [r] P = O test ran on it.  Here: the check switched off through zk_set_option (the C-ABI's own configuration call), a key with a
-    point of the curve OUTSIDE the prime-order subgroup, every folding width -- the proof must be the literal fold of groth16.ml:116-161 over that
-    very key (the oracle's double-and-add does not care about a point's order).  With the check back on, the same key is refused."""
+    medium): a key uploaded with the check skipped and one point outside the subgroup gave a wrong sum and ZK_OK.  Now a base set folds only
+    when the [r] P = O test ran on it.  Here: the check switched off through zk_set_option (the C-ABI's own configuration call), a key with two
+    points of the curve OUTSIDE the prime-order subgroup, every folding width.  For such points the only well-defined answer is the plain sum
+    sum_i s_i P_i over the canonical scalars s_i in [0, r) (the reference's nested folds, groth16.ml:116-121, agree with it only on the subgroup), so
+    that is the expectation: the three scalar vectors read back from the device, the pools read back from the key, the oracle's double-and-add.
+    With the check back on, the same key is refused."""
     import oracle_lib as O
     cs, w = RC.iterated_cubic(8, 3)
     csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
@@ -135,20 +137,36 @@ def test_a_key_uploaded_without_the_subgroup_check_never_gets_folded_windows():
         g1[96 * idx:96 * idx + 96] = bad
     key = type(pk)(g1, pk.g2)
     frs = lambda xs: bytes(RC.fr_bytes(xs))
-    q = O.QAP(cs.n, cs.m, *csr)
+    L = _lib.lib()
     r, s = rng(), rng()
-    rc, a, b, c = q.groth16_prove(bytes(g1), bytes(pk.g2), cs.mid, frs(w), frs([r]), frs([s]), 1)
-    assert rc == 0
+
+    def plain_sums(pr):
+        p1, p2 = bytes(pr.pool_points(1)), bytes(pr.pool_points(2))
+        n1, n2 = len(p1) // 96, len(p2) // 192
+        d = [C.c_void_p() for _ in range(3)]
+        host = [np.zeros(32 * k, dtype=np.uint8) for k in (n1, n1, n2)]
+        for ptr, h in zip(d, host):
+            _lib.check(L.zk_device_malloc(C.c_size_t(len(h)), C.byref(ptr)))
+        _lib.check(L.zk_groth16_scalars_async(pr.handle, _p(fr_bytes(w)), _p(fr_bytes([r])), _p(fr_bytes([s])), C.c_uint32(1), *d))
+        _lib.check(L.zk_groth16_scalars_wait(pr.handle, C.c_uint32(1)))
+        for ptr, h in zip(d, host):
+            _lib.check(L.zk_device_memcpy(h.ctypes.data_as(C.c_void_p), ptr, C.c_size_t(len(h))))
+            _lib.check(L.zk_device_free(ptr))
+        (rc1, a), (rc2, c), (rc3, b) = O.g1_msm_naive(p1, bytes(host[0])), O.g1_msm_naive(p1, bytes(host[1])), O.g2_msm_naive(p2, bytes(host[2]))
+        assert rc1 == rc2 == rc3 == 0
+        return a, b, c
+
     try:
         _set_option("key_subgroup_check", 0)
         for width in (17, 15, 5, 3, 16):
             _set_option("ZK_MSM_WINDOW", width)
             pr = Groth16(cs, key)
+            assert bytes(pr.pool_points(1)) == bytes(g1)
             got = pr.prove_rs(w, r, s)
-            assert (got.a, got.b, got.c) == (a, b, c), "window %d" % width
+            assert (got.a, got.b, got.c) == plain_sums(pr), "window %d" % width
             pr.derive_lagrange()                                          # the derived pools inherit "not checked"
             got = pr.prove_rs(w, r, s)
-            assert (got.a, got.b, got.c) == (a, b, c), "window %d, derived key" % width
+            assert (got.a, got.b, got.c) == plain_sums(pr), "window %d, derived key" % width
             pr.close()
     finally:
         _set_option("msm_window", None)
@@ -162,7 +180,7 @@ def test_a_key_uploaded_without_the_subgroup_check_never_gets_folded_windows():
         _set_option("msm_window", 17)
         pr = Groth16(cs, pk)
         got = pr.prove_rs(w, r, s)
-        assert (got.a, got.b, got.c) == exp
+        assert (got.a, got.b, got.c) == exp and (got.a, got.b, got.c) == plain_sums(pr)
         pr.close()
     finally:
         _set_option("msm_window", None)
@@ -194,7 +212,14 @@ def test_caller_owned_scalar_vectors_are_range_checked():
     part = np.zeros(768, dtype=np.uint8)
     _lib.check(L.zk_groth16_msm_partial_async(pr.handle, C.c_uint32(0), *d))
     _lib.check(L.zk_groth16_prove_partial_wait(pr.handle, C.c_uint32(0), _p(part)))
-    good = bytes(part)
+
+    def combined():          # the partial sums are raw projective limbs (not canonical: bucket order may differ run to run); the proof they combine to is
+        out = np.zeros(384, dtype=np.uint8)
+        _lib.check(L.zk_groth16_combine(_p(part), C.c_uint32(1), _p(out)))
+        return bytes(out)
+    good = combined()
+    ref = pr.prove_rs(w, 5, 7)
+    assert good == ref.a + ref.b + ref.c
     for which, count in ((0, p1), (1, p1), (2, p2)):
         big = np.frombuffer((P.R + 3).to_bytes(32, "little"), dtype=np.uint8).copy()          # r + 3 < 2^255: a non-canonical encoding of 3
         saved = np.zeros(32, dtype=np.uint8)
@@ -206,7 +231,7 @@ def test_caller_owned_scalar_vectors_are_range_checked():
         _lib.check(L.zk_device_memcpy(at, saved.ctypes.data_as(C.c_void_p), C.c_size_t(32)))
     _lib.check(L.zk_groth16_msm_partial_async(pr.handle, C.c_uint32(0), *d))
     _lib.check(L.zk_groth16_prove_partial_wait(pr.handle, C.c_uint32(0), _p(part)))
-    assert bytes(part) == good
+    assert combined() == good
     for ptr in d:
         _lib.check(L.zk_device_free(ptr))
     pr.close()

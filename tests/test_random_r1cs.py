@@ -89,8 +89,17 @@ def _both_protocols(cs, w, seed, literal):
             rc, a, b, c = q.groth16_prove(pk1, pk2, cs.mid, sol, frb(rs[0][0]), frb(rs[0][1]), 1)
             assert rc == 0 and (a, b, c) == exp[0]
     io = [w[k] for k in range(m) if not cs.mid[k]]
+    assert len(io) <= 65
     assert Groth16.verify(io, vk, got)
-    assert not Groth16.verify([(io[0] + 1) % RC.FR_MODULUS] + io[1:], vk, got)
+    # a wrong public input is rejected -- unless its variable occurs in no gate: then [L_k(tau)/gamma]_1 is the identity and its value cannot matter
+    # (the reference's verifier, groth16.ml:163-173, accepts just the same)
+    lt = bytes(vk.ltgm_io)
+    live = [j for j in range(len(io)) if lt[96 * j:96 * j + 96] != INF1]
+    dead = [j for j in range(len(io)) if j not in live]
+    for j in live[:2] + live[-1:] + dead[:1]:
+        wrong = list(io)
+        wrong[j] = (wrong[j] + 1) % RC.FR_MODULUS
+        assert Groth16.verify(wrong, vk, got) == (j not in live)
     bad = list(w)
     k = int(cs.O.col[0])
     bad[k] = (bad[k] + 1) % RC.FR_MODULUS

@@ -188,7 +188,7 @@ def random_r1cs(n, m, seed, nnz=(1, 16), one=True, unused=None, special=0.25):
       - witness values 0, 1 and r - 1 mixed into uniformly random ones (`special` = their share);
       - one=False: no variable is pinned to 1 (the reference's `x * x` program has no $ONE, src/lib/test/test.ml:204-212);
       - satisfied by construction: the last entry of every lhs row is solved for.
-    Variables 0..m-1 in Var.compare order as everywhere; roughly three quarters are mids, ONE (variable 0, when present) is public.
+    Variables 0..m-1 in Var.compare order as everywhere; roughly three quarters are mids (all but 64 from 256 variables up), ONE (variable 0, when present) is public.
     Returns (R1CS, witness ints).  Vectorised (numpy object arrays): 2^20 rows of 8 entries take seconds."""
     P = FR_MODULUS
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -287,6 +287,9 @@ def random_r1cs(n, m, seed, nnz=(1, 16), one=True, unused=None, special=0.25):
         return Matrix(ptr.astype(np.uint32), col.astype(np.uint32), vals)
 
     mid = (rng.random(m) < 0.75).astype(np.uint8)
+    if m > 256:                                             # a statement has a handful of public values, not a quarter of its variables: at most 64
+        pub = np.flatnonzero(mid == 0)
+        mid[pub[64:]] = 1
     if one:
         mid[0] = 0
     if mid.all():
