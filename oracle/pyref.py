@@ -347,6 +347,31 @@ def interpolate_int_domain(ys):
     return total + [0] * (n - len(total))
 
 
+def lagrange_basis(xs):
+    """polynomial.ml:212-226 for ARBITRARY distinct points: l_j = prod_{i != j} (x - x_i) / (x_j - x_i), the factors multiplied in the reference's
+    order (the points before x_j in reverse, then the ones after it: `List.rev_append sx xs`) -- the product is the same polynomial in any order."""
+    out = []
+    for j, xj in enumerate(xs):
+        others = list(reversed(xs[:j])) + list(xs[j + 1:])
+        acc = [1]
+        for xi in others:
+            d = (xj - xi) % R
+            assert d != 0                                   # polynomial.ml:220
+            dinv = fr_inv(d)
+            acc = poly_mul(acc, [(-xi) * dinv % R, dinv])
+        out.append(acc)
+    return out
+
+
+def interpolate(xys):
+    """polynomial.ml:228-230: sum_j y_j l_j."""
+    ls = lagrange_basis([x % R for x, _ in xys])
+    total = []
+    for (_, y), l in zip(xys, ls):
+        total = poly_add(total, [c * (y % R) % R for c in l])
+    return total
+
+
 def z_poly(n):
     z = [1]
     for i in range(n):

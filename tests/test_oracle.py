@@ -163,6 +163,34 @@ def test_polynomial_ml_kats():
         assert P.poly_normalize(qi) == pq and ri == pr
 
 
+def test_polynomial_ml_interpolation_kats():
+    """polynomial.ml:232-243 `test_interpolate`: the reference's three point sets -- two of them NOT contiguous integers -- over Fr instead of Q:
+    the interpolant passes through every point (the reference's own assertion) and has the coefficients the rationals give."""
+    third, half = P.fr_inv(3), P.fr_inv(2)
+    for xys, coeffs in (([(0, 1), (1, 2)], [1, 1]),
+                        ([(0, 10), (3, 9)], [10, (-third) % P.R]),
+                        ([(1, 3), (2, 2), (3, 4)], [7, (-11 * half) % P.R, 3 * half % P.R])):
+        f = P.interpolate(xys)
+        assert all(P.poly_eval(f, x) == y % P.R for x, y in xys)
+        assert P.poly_normalize(f) == coeffs
+        basis = P.lagrange_basis([x for x, _ in xys])
+        for j, (xj, _) in enumerate(xys):
+            assert [P.poly_eval(basis[j], x) for x, _ in xys] == [1 if i == j else 0 for i in range(len(xys))]
+    # on the QAP's domain 0..n-1 (QAP.ml:81-86) the general form is the integer-domain form the C oracle's QAP.build uses
+    ys = [rnd.randrange(P.R) for _ in range(7)]
+    assert P.poly_normalize(P.interpolate(list(enumerate(ys)))) == P.poly_normalize(P.interpolate_int_domain(ys))
+    cs, _w = RC.iterated_cubic(6, 5)
+    q = O.QAP(cs.n, cs.m, *csrs(cs))
+    col = [0] * cs.n
+    k = int(cs.O.col[1])
+    for g in range(cs.n):
+        for e in range(cs.O.ptr[g], cs.O.ptr[g + 1]):
+            if cs.O.col[e] == k:
+                col[g] = int.from_bytes(bytes(cs.O.val[32 * e:32 * e + 32]), "little")
+    assert P.poly_normalize(RC.fr_ints(q.poly(2, k))) == P.poly_normalize(P.interpolate(list(enumerate(col))))
+    assert P.poly_normalize(RC.fr_ints(q.poly(3))) == P.z_poly(cs.n)                       # polynomial.ml:248-251 `z`
+
+
 def test_readme_circuit_fixture():
     d = json.load(open(GOLDEN))
     for case in d["cases"]:
