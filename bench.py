@@ -37,7 +37,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 T_START = time.perf_counter()
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 MAX_RANKS_PER_DEVICE = 6      # a GPU box admits at most 6 processes on its card at once
@@ -224,6 +224,10 @@ PAIR_BYTES = {"g1": 128.0, "g2": 224.0}
 # G2 on a lane pair 8 fused double products + 2 squares per lane = 2 x 5488 = 28.0.  The SECOND step of a chunk adds two affine points
 # (mmadd-2008-s): G1 2 + 2 squares + 1 fused = 1974 = 5.04; G2 2 x 3136 = 16.0.  The FIRST entry of a chunk or of a run is a copy: no product.
 MADD_PRODUCTS = {"g1": 9.04, "g2": 28.0}
+# The multiplier ceiling from the HARDWARE, not from a kernel of this library: one 14 x 14-limb Montgomery product is 392 v_mad_u64_u32, which issues at
+# ~5 cycles per wave64 and SIMD (scripts/proto/valu_rate.hip; DESIGN.md 4 -- 4.4-5 measured), 1024 SIMDs, 2.4 GHz maximum clock (MI355X_MICROARCH.md;
+# under this load the chip holds ~2.2 GHz at its power cap, which the measured peak beside it includes and this figure does not).
+ALU_PEAK_HW = 1024 * 2.4e9 / 5.0 * 64 / 392 / 1e9          # = 80.2 G Fp products/s
 MMADD_PRODUCTS = {"g1": 5.04, "g2": 16.0}
 
 
@@ -259,7 +263,9 @@ def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windo
             o[tag] = {"avg_launch_ms": avg_ms, "launches_per_proof": launches_per_proof, "algorithmic_bytes_per_launch": bytes_per_launch,
                       "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                       "alu": {"unit": "G Fp products/s", "achieved": mul_equiv, "peak_measured": peak_products,
-                              "frac": mul_equiv / peak_products if peak_products else None}}
+                              "frac": mul_equiv / peak_products if peak_products else None,
+                              "peak_hw": ALU_PEAK_HW, "frac_hw": mul_equiv / ALU_PEAK_HW,
+                              "peak_hw_is": "1024 SIMDs x 2.4 GHz / 5 cycles per v_mad_u64_u32 (wave64) x 64 lanes / 392 multiply-adds per Fp product"}}
         t = None
         if traffic and workload_key in traffic.get("workloads", {}):
             t = traffic["workloads"][workload_key].get(fam, {}).get("hbm_bytes_per_launch")
@@ -272,13 +278,19 @@ def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windo
     return objs
 
 
-def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, world, dist, lagrange=False, replicated_fr=False, events=True, derive_upto=None):
-    """Times `steps` steps of `--proofs-per-step` proofs at n = 2^log_n * world; returns the result dict (rank 0 checks parity)."""
+def bench_groth16(args, L, _lib, log_n, steps, warmup, inflight, settle, rank, world, dist, lagrange=False, replicated_fr=False, events=True, derive_upto=None,
+                  family="iterated_cubic"):
+    """Times `steps` steps of `--proofs-per-step` proofs at n = 2^log_n * world; returns the result dict (rank 0 checks parity).
+    family: "iterated_cubic" (the metric's circuit, one entry per l / r row) or "dense_rows" (zukelang_amd/r1cs.py random_r1cs: 8 entries in
+    every row of all three matrices, full-width coefficients mixed in, an eighth of the variables in no gate -- never the headline)."""
     from zukelang_amd import r1cs as RC
     from zukelang_amd.groth16 import Groth16
     t_setup = time.perf_counter()
     n = (1 << log_n) * world if args.weak else (1 << log_n)          # strong scaling by default: the same proof on every N
-    cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
+    if family == "dense_rows":
+        cs, w = RC.random_r1cs(n, n + 2, 0xD0D0, nnz=(8, 8))
+    else:
+        cs, w = RC.iterated_cubic(n, next(RC.fr_stream(0x5EED0001)))
     rng = seeded(0x5EED0002)
     toxic = [rng() for _ in range(5)]
     it = iter(toxic)
@@ -658,7 +670,7 @@ def compact_line(full):
                      "constraints": cfg.get("constraints"), "key_form": key_form, "tau_power_value": tpf.get("value"),
                      "derive_lagrange_s": cfg.get("derive_lagrange_s"), "break_even_proofs": tpf.get("break_even_proofs"),
                      "proofs_in_flight": cfg.get("proofs_in_flight"), "proofs_per_step": cfg.get("proofs_per_step"),
-                     "sharding": (cfg.get("sharding") or "")[:160], "rehearsal_ranks_share_gpus": cfg.get("rehearsal_ranks_share_gpus"), "device_list": cfg.get("device_list"),
+                     "sharding": (cfg.get("sharding") or "")[:160], "fr_stage": (cfg.get("fr_stage") or None) and cfg["fr_stage"][:120], "rehearsal_ranks_share_gpus": cfg.get("rehearsal_ranks_share_gpus"), "device_list": cfg.get("device_list"),
                      "prove_algorithmic_bytes_per_constraint": cfg.get("prove_algorithmic_bytes_per_constraint"), "prove_hbm_frac": cfg.get("prove_hbm_frac")}
     out["ms_per_proof"] = full.get("ms_per_proof")
     out["single_proof_latency_ms"] = full.get("single_proof_latency_ms")
@@ -668,7 +680,9 @@ def compact_line(full):
         out["roofline"] = {"kernel": roof.get("kernel"), "bound": roof.get("bound"), "peak": roof.get("peak"), "unit": roof.get("unit"),
                            "algorithmic_bytes_per_launch": t.get("algorithmic_bytes_per_launch"), "avg_launch_ms": t.get("avg_launch_ms"),
                            "achieved": roof.get("achieved"), "frac": roof.get("frac"), "traffic": roof.get("traffic"),
-                           "alu_frac": (t.get("alu") or {}).get("frac"), "measured": roof.get("frac_is")}
+                           "alu_frac": (t.get("alu") or {}).get("frac"), "alu_frac_hw": (t.get("alu") or {}).get("frac_hw"),
+                           "alu_peak_hw": "%.1f G Fp products/s = 1024 SIMDs x 2.4 GHz / 5 cyc per v_mad_u64_u32 x 64 lanes / 392 mads" % ALU_PEAK_HW,
+                           "measured": roof.get("frac_is")}
     else:
         out["roofline"] = None
     cpu = full.get("cpu_baseline")
@@ -727,6 +741,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: 2^log_n constraints PER GPU (n = 2^log_n x N, \"scaling\": \"weak\") instead of the same 2^log_n-constraint proof on every N; "
                     "BASELINE config 4 is --gpus 8 --log-n 19 --weak")
     ap.add_argument("--sizes", default="16,18,22", help="one GPU: further log2 sizes timed in the same run and reported under other_workloads ('' = none)")
+    ap.add_argument("--config4-world", type=int, default=8, help="N at which the run ALSO measures BASELINE config 4 (2^config4-log-n constraints per rank, weak) into other_workloads")
+    ap.add_argument("--config4-log-n", type=int, default=19)
+    ap.add_argument("--dense-rows", type=int, default=20, help="one GPU: log2 size of the dense_rows workload (random R1CS, 8 entries per row; other_workloads only), -1 = skip")
     ap.add_argument("--no-pinocchio", action="store_true", help="skip the Pinocchio 2^18 workload (config 5) of the default run")
     ap.add_argument("--headline-only", action="store_true", help="only the headline workload (profiling runs): same as --sizes '' --no-pinocchio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -798,25 +815,67 @@ def main():
     else:
         _lib.check(L.zk_init(local_rank))
 
+    # N > 1: a REHEARSAL first -- one tiny parity-gated proof through the distributed Fr stage (all-to-all of scalar slices + all-gather of partial sums
+    # over RCCL).  If that path raises on this node (on every rank together: a collective the backend refuses), the SAME processes go on with the
+    # replicated Fr stage (one all-gather per proof) instead of dying without a line; the line says which one ran.  A hang cannot be caught: none is known.
+    fr_note = None
+    replicated = args.replicated_fr
+    if world > 1 and not replicated:
+        import argparse
+        import torch
+        tiny = argparse.Namespace(**vars(args))
+        tiny.weak = False
+        err = ""
+        try:
+            bench_groth16(tiny, L, _lib, min(args.log_n, 10), 1, 0, 2, 0.0, rank, world, dist, derive_upto=None, events=False)
+            ok = 1
+        except BaseException as e:          # SystemExit of a parity failure included: wrong bytes are a reason to fall back AND to say so
+            ok, err = 0, "%s: %s" % (type(e).__name__, str(e)[:200])
+        flag = torch.tensor([ok], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            replicated = True
+            fr_note = "REPLICATED Fr stage: the distributed-Fr rehearsal (2^%d) failed on at least one rank (this rank: %s)" % (min(args.log_n, 10), err or "ok")
+            print("bench.py rank %d: %s" % (rank, fr_note), file=sys.stderr)
+        else:
+            fr_note = "distributed Fr stage (rehearsed at 2^%d against the oracle before the timed run)" % min(args.log_n, 10)
     head = bench_groth16(args, L, _lib, args.log_n, args.steps, args.warmup, args.inflight, args.settle, rank, world, dist,
-                         lagrange=args.lagrange_key, replicated_fr=args.replicated_fr, events=not args.no_live_events,
+                         lagrange=args.lagrange_key, replicated_fr=replicated, events=not args.no_live_events,
                          derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
+    # BASELINE config 4 (2^22 constraints, MSM point-sharded over 8 ranks) beside the N = 8 line of the scaling curve: the driver's SCALE command
+    # measures the SAME 2^log_n proof on every N (strong scaling); config 4 is `--gpus 8 --weak --log-n 19`, so the 8-rank run adds it itself
+    # (reference-format key sharded at upload, no derivation: a few proofs, parity-gated)
+    config4 = None
+    if world > 1 and world == args.config4_world and not args.weak and not args.headline_only:
+        import argparse
+        a4 = argparse.Namespace(**vars(args))
+        a4.weak = True
+        r4 = bench_groth16(a4, L, _lib, args.config4_log_n, 1, 0, args.inflight, 0.0, rank, world, dist, replicated_fr=replicated, events=False, derive_upto=None)
+        if rank == 0:
+            config4 = {"workload": "groth16_prove 2^%d point-sharded over %d ranks (BASELINE config 4: --weak --log-n %d), reference-format key as uploaded"
+                                   % ((r4["constraints"] - 1).bit_length(), world, args.config4_log_n),
+                       "value": r4["value"], "constraints": r4["constraints"], "ms_per_proof": r4["ms_per_proof"], "parity": r4["parity"], "tau_power_form": {"value": r4["value"]},
+                       "derive_lagrange_s": None}
     peak = C.c_double()
     _lib.check(L.zk_bench_field_mul(1 | 8, 2000, C.byref(peak)))   # the library's dependent-chain product benchmark on this chip, in this process: best of 2 / 4 / 6 / 8 waves per SIMD
     traffic = pmc_traffic()
     head_pub, roofs = summarize(head, world, peak.value, traffic, args.lagrange_key)
 
-    others = []
+    others = [config4] if config4 else []
 
-    def other_size(ln):
+    def other_size(ln, family="iterated_cubic"):
         per = {16: 320, 18: 80, 20: 24, 22: 8}.get(ln, max(8, int(0.6 / (2e-3 * (1 << max(0, ln - 16))))))       # proofs for >= 0.5 s at last round's rates
         infl = args.inflight if ln <= 20 else 4
         steps = max(1, (per + args.proofs_per_step - 1) // args.proofs_per_step)
+        dense = family == "dense_rows"          # proved from the Lagrange-form EXTENSION the keygen emits: the derived key's prove path without paying its derivation again
         r = bench_groth16(args, L, _lib, ln, steps, 1 if ln <= 18 else 0, infl, args.settle if ln <= 18 else min(args.settle, 2.0), 0, 1, None,
-                          lagrange=args.lagrange_key, events=not args.no_live_events,
-                          derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None)
-        pub, _ = summarize(r, 1, peak.value, traffic, args.lagrange_key)
-        pub["workload"] = "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {16: "2", 20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-"))
+                          lagrange=args.lagrange_key or dense, events=not args.no_live_events,
+                          derive_upto=args.derive_lagrange_upto if args.derive_lagrange_upto >= 0 else None, family=family)
+        pub, _ = summarize(r, 1, peak.value, traffic, args.lagrange_key or dense)
+        pub["workload"] = ("groth16_prove 2^%d dense_rows (random R1CS, 8 entries per row in L, R and O; Lagrange-form key extension)" % ln if dense else
+                           "groth16_prove 2^%d (BASELINE config %s), same run" % (ln, {16: "2", 20: "3's size", 22: "4's size on ONE GPU"}.get(ln, "-")))
         others.append(pub)
 
     # order: the short workloads, Pinocchio, the CPU ladder -- and the sizes above 2^20 LAST, so that the wall-clock guard of their (minutes-long)
@@ -824,6 +883,11 @@ def main():
     sizes = [int(t) for t in args.sizes.split(",") if t.strip() and int(t) != args.log_n] if world == 1 and rank == 0 and not args.headline_only else []
     for ln in [x for x in sizes if x <= 20]:
         other_size(ln)
+    if world == 1 and rank == 0 and not args.headline_only and args.dense_rows >= 0:
+        if time.perf_counter() - T_START + 60 < args.time_budget:          # ~25 s of host-side generation + keygen at 2^20
+            other_size(args.dense_rows, "dense_rows")
+        else:
+            print("bench.py: the dense_rows workload does not fit --time-budget: skipped", file=sys.stderr)
     if world == 1 and rank == 0 and not args.headline_only and not args.no_pinocchio:
         others.append(bench_pinocchio(args, L, _lib, 18, 48, 8, peak.value))
     cpu = None
@@ -878,6 +942,7 @@ def main():
                                     ("ONE process, one key handle sharded over device list %s (zk_set_device_list): Fr stage on the slot's owner device, peer copies of the scalar slices, 768 B partial sums added on the first device" % dev_list
                                      if len(dev_list) > 1 else "single GPU"),
                        "exchange": head.get("exchange"),
+                       "fr_stage": fr_note,
                        "derive_lagrange_s": head.get("derive_lagrange_s"),      # one-time, per key, outside the timed region
                        "tau_power_form": head.get("tau_power_form"),
                        "rehearsal_ranks_share_gpus": rehearsal or (len(dev_list) > len(set(dev_list))),

@@ -122,6 +122,13 @@ typedef struct {
     const uint8_t* val;        /* nnz * 32, Fr */
 } zk_csr;
 
+/* One sparse matrix times one vector over Fr: y[g] = sum_e val[e] * x[col[e]] over row g.  With M = one R1CS matrix and x = the solution it gives the
+ * VALUES at X = g of `eval' vps` (QAP.ml:121-131: sum_k sol_k poly_k evaluated at the gate's point); with M transposed and x = the Lagrange basis at tau
+ * it gives every u_k(tau) of a keygen at once (groth16.ml:59-68, pinocchio.ml:104-109 -- `Poly.apply u_k s` per variable in the reference).
+ * ZK_ERR_ARG for a malformed matrix (row_ptr not monotone, column >= cols), ZK_ERR_SCALAR_RANGE for a value >= r. */
+int zk_fr_spmv(uint32_t rows, uint32_t cols, const zk_csr* M, const uint8_t* x /* cols * 32 */, uint8_t* y /* rows * 32 */);
+
+
 /* Proving key of groth16.ml:24-34, fields in declaration order, plus the circuit.
  *   g1: a | d1 | b1 | ti1[n+2] | tiztd[n-1] | ltd_mid[n_mid]   (ltd_mid in Var.Map key order)
  *   g2: b2 | d2 | ti2[n+2]

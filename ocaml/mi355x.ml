@@ -153,6 +153,10 @@ let matrix_of_rows (rows : (int * bytes) list list) : matrix =
   setf c csr_val (CArray.start keep_val);
   { c; keep_ptr; keep_col; keep_val }
 
+(* y = M x over Fr for one sparse matrix (header: zk_fr_spmv): QAP.eval's sums at the gates' points, or -- M transposed, x = the Lagrange basis at
+   tau -- every u_k(tau) of a keygen at once, where the reference runs Poly.apply per variable *)
+let zk_fr_spmv = fn "zk_fr_spmv" (uint32_t @-> uint32_t @-> ptr csr @-> ocaml_bytes @-> ocaml_bytes @-> returning int)
+
 (* ------------------------------------------------------------------ Groth16: groth16.ml:24-34,116-161,235-237 *)
 
 let zk_groth16_pk_upload =

@@ -78,13 +78,16 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     the card and exchange over gloo (rehearsal); the line must say n_gpus 2, carry the parity gate's verdict and the proof of groth16.ml:123-161
     must not depend on N (the gate compares with the oracle's trapdoor evaluation, which knows nothing of ranks)."""
     import json
-    res = _bench(["--gpus", "2", "--log-n", "12", "--steps", "2", "--warmup", "1", "--settle", "0"])
+    res = _bench(["--gpus", "2", "--log-n", "12", "--steps", "2", "--warmup", "1", "--settle", "0", "--config4-world", "2", "--config4-log-n", "10"])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
     import torch
     assert d["n_gpus"] == 2 and d["config"]["constraints"] == 4096 and d["scaling"] == "strong"
+    assert d["config"]["fr_stage"].startswith("distributed Fr stage (rehearsed")                 # the rehearsal ran and passed: no fallback
+    c4 = d["other_workloads"][0]                                                                  # config 4's leg at the world size the flag names
+    assert "BASELINE config 4" in c4["workload"] and c4["parity"] is True and c4["value"] > 0
     assert d["config"]["rehearsal_ranks_share_gpus"] == (torch.cuda.device_count() < 2)
     assert d["parity"].startswith("passed") and "oracle" in d["parity"]
     assert len(lines[0]) < 4096                        # the driver parses this line: compact, the detail is in bench_detail.json / stderr
@@ -97,7 +100,7 @@ def test_bench_line_of_a_real_one_gpu_run_is_compact_and_complete():
     (tau-power pass, derivation, derived pass, a second workload, Pinocchio off, the cpu_baseline ladder cut short) -- the LAST stdout line is < 4 KB of
     strict JSON carrying `roofline` and `cpu_baseline`, and bench_detail.json holds the long form."""
     import json
-    res = _bench(["--log-n", "12", "--steps", "2", "--warmup", "1", "--settle", "0", "--sizes", "10", "--no-pinocchio", "--cpu-baseline-budget", "1"])
+    res = _bench(["--log-n", "12", "--steps", "2", "--warmup", "1", "--settle", "0", "--sizes", "10", "--dense-rows", "10", "--no-pinocchio", "--cpu-baseline-budget", "1"])
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     last = [ln for ln in res.stdout.splitlines() if ln.strip()][-1]
     assert len(last) < 4096
@@ -109,7 +112,8 @@ def test_bench_line_of_a_real_one_gpu_run_is_compact_and_complete():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
-    assert d["parity"].startswith("passed") and [o["parity"] for o in d["other_workloads"]] == [True]
+    assert d["parity"].startswith("passed") and [o["parity"] for o in d["other_workloads"]] == [True, True] and "dense_rows" in d["other_workloads"][1]["workload"]
+    assert 0 < r["alu_frac_hw"] < r["alu_frac"] * 1.2 and "v_mad_u64_u32" in r["alu_peak_hw"]
     detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
     assert detail["roofline_g1"] and detail["roofline_g2"] and detail["cpu_baseline"]["ladder"] and detail["proof_compressed_hex"]
 

@@ -618,6 +618,32 @@ int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_wit_can
 
 using namespace zk;
 
+// y = M x over Fr for one sparse matrix: the R1CS product at the heart of QAP.eval (rows = gates: the values at X = g of sum_k sol_k poly_k,
+// QAP.ml:121-131) and, with M TRANSPOSED, of keygen (u_k(tau) = sum_g M[g][k] l_g(tau): groth16.ml:59-68, pinocchio.ml:104-109 through the Lagrange basis).
+extern "C" int zk_fr_spmv(uint32_t rows, uint32_t cols, const zk_csr* M, const uint8_t* x, uint8_t* y) {
+    if (!M || !x || !y || rows == 0 || cols == 0) ZK_FAIL(ZK_ERR_ARG, "zk_fr_spmv: null or empty argument");
+    ZKCHK(ensure_init());
+    Ctx& c = ctx();
+    CsrDev d;
+    ZKCHK(upload_csr(d, M, rows, cols, c.stream));          // validates row_ptr / col, ZK_ERR_SCALAR_RANGE for a coefficient >= r
+    DevBuf dx, dy, flag;
+    ZKCHK(dx.alloc(32 * (size_t)cols));
+    ZKCHK(dy.alloc(32 * (size_t)rows));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
+    HIPCHK(hipMemcpyAsync(dx.p, x, 32 * (size_t)cols, hipMemcpyHostToDevice, c.stream));
+    ZKCHK(fr_to_mont(dx.p, dx.p, cols, flag.as<int>(), c.stream));
+    hipLaunchKernelGGL(k_spmv, g1d(rows), dim3(256), 0, c.stream, (const uint32_t*)FRP(d.ptr), (const uint32_t*)FRP(d.col), (const uint32_t*)FRP(d.val), (const uint32_t*)FRP(dx), FRP(dy), rows);
+    HIPCHK(hipGetLastError());
+    ZKCHK(fr_from_mont(dy.p, dy.p, rows, c.stream));
+    int hf = 0;
+    HIPCHK(hipMemcpyAsync(&hf, flag.p, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipMemcpyAsync(y, dy.p, 32 * (size_t)rows, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (hf) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "zk_fr_spmv: vector element >= r");
+    return ZK_OK;
+}
+
 extern "C" int zk_fr_poly_mul(const uint8_t* a, size_t na, const uint8_t* b, size_t nb, uint8_t* out, size_t* nout) {
     if (!nout) ZK_FAIL(ZK_ERR_ARG, "zk_fr_poly_mul: null nout");
     *nout = 0;

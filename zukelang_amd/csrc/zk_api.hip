@@ -50,7 +50,7 @@ static const char* const PUBLIC_OPTIONS[] = {
     "ZK_SORT_TWO_LEVEL", "ZK_SORT_TWO_LEVEL_MIN", "ZK_SORT_MIN_WGS", "ZK_SORT_SCALAR_MAJOR", "ZK_SORT_FINE_STAGED", "ZK_SORT_COARSE_STAGED",
     "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_DS_WIDE_GROUP", "ZK_RED_WAVES",
     "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_MSM_BA_CURVES", "ZK_MSM_BA_ROUNDS", "ZK_MSM_API_PRECOMP",
-    "ZK_DERIVE_SIDE_BY_SIDE", "ZK_FR_RNS", "ZK_LONE_SPLIT",
+    "ZK_DERIVE_SIDE_BY_SIDE", "ZK_FR_RNS",
 };
 struct OptionTable {
     std::mutex mu;

@@ -100,6 +100,21 @@ def _lagrange_at(n, tau):
     return lag, zt
 
 
+def columns_at(circuit, lag):
+    """u_k = sum_g M[g][k] * lag[g] for M = L, R, O and every variable k (Python ints): v_k(tau), w_k(tau), y_k(tau) through the Lagrange basis of
+    the gates' points -- the reference evaluates `Poly.apply u_k tau` on dense polynomials per variable (groth16.ml:59-68, pinocchio.ml:104-109), the
+    same field elements.  Three sparse products M^T x on the GPU (zk_fr_spmv)."""
+    from .r1cs import fr_ints
+    x = fr_bytes(lag)
+    out = []
+    for M in (circuit.L, circuit.R, circuit.O):
+        T = M.transposed(circuit.m)
+        y = np.zeros(32 * circuit.m, dtype=np.uint8)
+        _lib.check(_lib.lib().zk_fr_spmv(C.c_uint32(circuit.m), C.c_uint32(circuit.n), C.byref(_csr(T)), _p(x), _p(y)))
+        out.append(fr_ints(y))
+    return out
+
+
 def all_gather_bytes(part, world):
     """The exchange step of the point-sharded prover: every rank contributes one
     fixed-size uint8 block, every rank receives all of them in rank order.  RCCL on the GPU box
@@ -204,13 +219,8 @@ class Groth16:
         n, m = circuit.n, circuit.m
         lag, zt = _lagrange_at(n, t)
         dinv, ginv = pow(d, P - 2, P), pow(gm, P - 2, P)
-        Lk = [0] * m
-        for M, mult in ((circuit.L, b), (circuit.R, a), (circuit.O, 1)):
-            vals = bytes(M.val)
-            for g in range(n):
-                for e in range(M.ptr[g], M.ptr[g + 1]):
-                    coef = int.from_bytes(vals[32 * e:32 * e + 32], "little")
-                    Lk[M.col[e]] = (Lk[M.col[e]] + coef * lag[g] % P * mult) % P
+        vk, wk, yk = columns_at(circuit, lag)
+        Lk = [(b * vk[k] + a * wk[k] + yk[k]) % P for k in range(m)]          # L_k(tau) = beta v_k(tau) + alpha w_k(tau) + y_k(tau), groth16.ml:59-68
         ex1 = [a, d, b]
         ti = 1
         for _ in range(n + 2):

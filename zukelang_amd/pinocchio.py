@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 from .curve import G1, G2
-from .groth16 import _csr, _lagrange_at, _p, ZK_ERR_REMAINDER
+from .groth16 import _csr, _lagrange_at, _p, columns_at, ZK_ERR_REMAINDER
 from .r1cs import FR_MODULUS, R1CS, fr_bytes
 
 
@@ -54,17 +54,9 @@ class Proof:
 
 def _uks(circuit, s):
     """v_k(s), w_k(s), y_k(s) for every variable and t(s), through the Lagrange basis of 0..n-1."""
-    P = FR_MODULUS
     lag, t = _lagrange_at(circuit.n, s)
-    out = []
-    for M in (circuit.L, circuit.R, circuit.O):
-        u = [0] * circuit.m
-        vals = bytes(M.val)
-        for g in range(circuit.n):
-            for e in range(M.ptr[g], M.ptr[g + 1]):
-                u[M.col[e]] = (u[M.col[e]] + int.from_bytes(vals[32 * e:32 * e + 32], "little") * lag[g]) % P
-        out.append(u)
-    return out[0], out[1], out[2], t
+    vk, wk, yk = columns_at(circuit, lag)          # three sparse products M^T x on the GPU (zk_fr_spmv)
+    return vk, wk, yk, t
 
 
 def keygen(rng, circuit: R1CS):

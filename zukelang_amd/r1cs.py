@@ -54,6 +54,18 @@ class Matrix:
         return Matrix(np.array(ptr, dtype=np.uint32), np.array(col, dtype=np.uint32), fr_bytes(vals))
 
 
+    def transposed(self, cols):
+        """The transpose as another CSR matrix (rows = this matrix's columns): what keygen multiplies by the Lagrange basis at tau
+        (u_k(tau) = sum_g M[g][k] l_g(tau)).  Stable in the row order, so every column's entries stay in gate order."""
+        n = len(self.ptr) - 1
+        rows = np.repeat(np.arange(n, dtype=np.uint32), np.diff(self.ptr.astype(np.int64)))
+        order = np.argsort(self.col, kind="stable")
+        tptr = np.zeros(cols + 1, dtype=np.uint32)
+        tptr[1:] = np.cumsum(np.bincount(self.col, minlength=cols))
+        tval = np.ascontiguousarray(self.val.reshape(-1, 32)[order]).reshape(-1)
+        return Matrix(tptr, np.ascontiguousarray(rows[order]), tval)
+
+
 @dataclass
 class R1CS:
     n: int            # gates / constraints
