@@ -758,7 +758,7 @@ def main():
     ap.add_argument("--derive-lagrange-upto", type=int, default=22, help="one GPU: for workloads of at most 2^K constraints, measure the reference-format key as uploaded, "
                     "then derive its Lagrange form on the device (zk_groth16_pk_derive_lagrange: once per key, untimed -- 2.7 s at 2^16, 6.7 s at 2^18, 31 s at 2^20, 147 s at 2^22) and "
                     "measure again: `value` is the derived key's figure, `tau_power_form` the other one.  -1 = never derive")
-    ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock the whole run aims to stay within: a derivation whose estimate (31 s x n / 2^20, 8 % more above 2^20) does not fit what is left "
+    ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock the whole run aims to stay within: a derivation whose estimate (31 s x n / 2^20, 8 %% more above 2^20) does not fit what is left "
                     "is skipped and that workload reports its tau-power figure only (the default run is ~5 min with the 147 s derivation of the 2^22 key)")
     ap.add_argument("--host-witness", action="store_true", help="one GPU: hand the witness over as a host buffer with every proof (the PCIe-inclusive rate of DESIGN.md 8) instead of "
                     "proving from the copy made resident by zk_groth16_set_witness; never the headline")
@@ -821,7 +821,6 @@ def main():
     fr_note = None
     replicated = args.replicated_fr
     if world > 1 and not replicated:
-        import argparse
         import torch
         tiny = argparse.Namespace(**vars(args))
         tiny.weak = False
@@ -849,7 +848,6 @@ def main():
     # (reference-format key sharded at upload, no derivation: a few proofs, parity-gated)
     config4 = None
     if world > 1 and world == args.config4_world and not args.weak and not args.headline_only:
-        import argparse
         a4 = argparse.Namespace(**vars(args))
         a4.weak = True
         r4 = bench_groth16(a4, L, _lib, args.config4_log_n, 1, 0, args.inflight, 0.0, rank, world, dist, replicated_fr=replicated, events=False, derive_upto=None)

@@ -50,6 +50,14 @@ int frstage_eval(const FrStage& f, FrScratch& sc, const void* d_witness_canonica
 int frstage_init_lagrange(FrStage& f, hipStream_t s);     // after frstage_init
 int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_witness_canonical, hipStream_t s);
 
+// kappa[0], kappa[1] (Montgomery, 2 x 32 B on device) = the X^(n-1) coefficients of the interpolants of the VALUES a = sc.abc[0..n), b = sc.abc[n..2n):
+// sum_i x_i c_i with the barycentric weights c_i = (-1)^(n-1-i) / (i! (n-1-i)!) -- after either frstage_eval form.  d_partials: 2 * LEAD_BLOCKS Fr of
+// scratch.  (Pinocchio's compact h pool, pinocchio.hip: v = kappa X^(n-1) + a polynomial of degree <= n-2.)
+static constexpr uint32_t LEAD_BLOCKS = 128;
+int frstage_leading_coeffs(const FrStage& f, const FrScratch& sc, void* d_kappa, void* d_partials, hipStream_t s);
+// out[t] = (n + t)^e for t < cnt (Montgomery)
+int frstage_shifted_powers(void* d_out, uint32_t n, uint32_t e, uint32_t cnt, hipStream_t s);
+
 // subproduct-tree tables over the points offset .. offset + n2 - 1 (plain Montgomery form, see frstage.hip)
 int frstage_tree_tables(uint32_t n2, uint32_t log_n2, uint32_t offset, void* pntt, DevBuf& q, hipStream_t s, std::vector<DevBuf>* p_rns = nullptr, uint32_t rns_first_level = 0);
 

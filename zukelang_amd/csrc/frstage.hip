@@ -614,6 +614,63 @@ int frstage_eval_lagrange(const FrStage& f, FrScratch& sc, const void* d_wit_can
     return ZK_OK;
 }
 
+// ---- leading coefficients of the interpolants of a and b (frstage.cuh): block-wise partial sums of x_i c_i, then one small launch adds them
+static constexpr uint32_t LEAD_THREADS = 256;
+__global__ __launch_bounds__(LEAD_THREADS) void k_lead_partial(uint32_t* __restrict__ part, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                               const uint32_t* __restrict__ invfact, uint32_t n) {
+    __shared__ __attribute__((aligned(32))) uint32_t sh[2][LEAD_THREADS][8];
+    Fr sa = fe_zero<FrParams>(), sb = fe_zero<FrParams>();
+    for (uint64_t i = (uint64_t)blockIdx.x * LEAD_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * LEAD_THREADS) {
+        Fr c = fe_mul(fe_load<FrParams>(invfact + 8 * i), fe_load<FrParams>(invfact + 8 * (uint64_t)(n - 1 - i)));
+        if ((n - 1 - i) & 1) c = fe_neg(c);
+        sa = fe_add(sa, fe_mul(fe_load<FrParams>(a + 8 * i), c));
+        sb = fe_add(sb, fe_mul(fe_load<FrParams>(b + 8 * i), c));
+    }
+    fe_store<FrParams>(sh[0][threadIdx.x], sa);
+    fe_store<FrParams>(sh[1][threadIdx.x], sb);
+    __syncthreads();
+    for (uint32_t w = LEAD_THREADS / 2; w; w >>= 1) {
+        if (threadIdx.x < w) {
+            fe_store<FrParams>(sh[0][threadIdx.x], fe_add(fe_load<FrParams>(sh[0][threadIdx.x]), fe_load<FrParams>(sh[0][threadIdx.x + w])));
+            fe_store<FrParams>(sh[1][threadIdx.x], fe_add(fe_load<FrParams>(sh[1][threadIdx.x]), fe_load<FrParams>(sh[1][threadIdx.x + w])));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) fe_store<FrParams>(part + 8 * (2 * (uint64_t)blockIdx.x + threadIdx.x), fe_load<FrParams>(sh[threadIdx.x][0]));
+}
+__global__ void k_lead_final(uint32_t* __restrict__ out, const uint32_t* __restrict__ part, uint32_t nblocks) {
+    if (threadIdx.x >= 2) return;
+    Fr s = fe_zero<FrParams>();
+    for (uint32_t k = 0; k < nblocks; k++) s = fe_add(s, fe_load<FrParams>(part + 8 * (2 * (uint64_t)k + threadIdx.x)));
+    fe_store<FrParams>(out + 8 * threadIdx.x, s);
+}
+int frstage_leading_coeffs(const FrStage& f, const FrScratch& sc, void* d_kappa, void* d_partials, hipStream_t s) {
+    const uint32_t n = f.n;
+    uint32_t blocks = (n + LEAD_THREADS - 1) / LEAD_THREADS;
+    if (blocks > LEAD_BLOCKS) blocks = LEAD_BLOCKS;
+    const uint32_t* a = FRP(sc.abc);
+    hipLaunchKernelGGL(k_lead_partial, dim3(blocks), dim3(LEAD_THREADS), 0, s, (uint32_t*)d_partials, a, a + 8 * (uint64_t)n, (const uint32_t*)FRP(f.invfact), n);
+    hipLaunchKernelGGL(k_lead_final, dim3(1), dim3(64), 0, s, (uint32_t*)d_kappa, (const uint32_t*)d_partials, blocks);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+__global__ void k_shifted_powers(uint32_t* __restrict__ out, uint32_t n, uint32_t e, uint32_t cnt) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    Fr base = fe_from_u32<FrParams>(n + t), r = fe_one<FrParams>();
+    for (uint32_t k = e; k; k >>= 1) {
+        if (k & 1) r = fe_mul(r, base);
+        base = fe_mul(base, base);
+    }
+    fe_store<FrParams>(out + 8 * (uint64_t)t, r);
+}
+int frstage_shifted_powers(void* d_out, uint32_t n, uint32_t e, uint32_t cnt, hipStream_t s) {
+    if (!cnt) return ZK_OK;
+    hipLaunchKernelGGL(k_shifted_powers, g1d(cnt), dim3(256), 0, s, (uint32_t*)d_out, n, e, cnt);
+    HIPCHK(hipGetLastError());
+    return ZK_OK;
+}
+
 }  // namespace zk
 
 using namespace zk;

@@ -14,6 +14,18 @@
 //   yayy' = <yay  | yayt,            c_mid | dy>                      (:497-498)
 //   bvwy' = <bvwy | vbt | wbt | ybt, c_mid | dv | dw | dy>            (:500-505)
 // NonZK.prove (Compute.f) is the same with dv = dw = dy = 0.
+//
+// The COMPACT h pool (round 5; default, ZK_PIN_COMPACT_H=0 / a key that fails the check below keeps the layout above).  v_all[k] = [v_k(s)] and
+// w_all[k] = [w_k(s)] are 2 m of the h product's n + 1 + 2 m points (4 n of 5 n in the iterated-cubic benchmark) and serve the blinding only:
+//   sum_k (dw c_k) [v_k(s)] = dw [v(s)],   v = sum_k c_k v_k  -- the very polynomial QAP.eval builds,
+// so with the coefficients of v, w the prover already holds (the tau-power Fr stage) the two terms ride on si:
+//   h' = <si, h + dv dw Z - dy e_0 + dw v + dv w>                                    n + 1 points,
+// and with the derived key, where v, w exist as VALUES (v(n + t) for t < n - 1 from the extrapolation, a_i on 0 .. n-1),
+//   v = kappa_v X^(n-1) + (a polynomial of degree <= n - 2),   kappa_v = sum_i a_i c_i  (leading coefficient of the interpolant),
+//   h' = <[lambda_t(s)] | [Z(s)] | [1] | [s^(n-1)],  h(n+t) + dw (v(n+t) - kappa_v (n+t)^(n-1)) + dv (w(n+t) - kappa_w (n+t)^(n-1)) | dv dw | -dy | dw kappa_v + dv kappa_w>
+// n + 2 points.  Same group element, same bytes -- PROVIDED the key's v_all / w_all are what KeyGen.generate makes them (pinocchio.ml:104-109,
+// 140-147): that is checked at upload on the key's own points (pin_compact_check: <v_all, rho> = <si, coefficients of sum_k rho_k v_k> for a
+// pseudo-random rho, likewise w_all); a key that fails keeps the full pool and is used point by point exactly as the reference uses it.
 #include "ec.cuh"
 #include "frstage.cuh"
 #include "msm.cuh"
@@ -33,6 +45,7 @@ struct PinSlot {
     MsmWorkspace ws1[PIN_G1], ws2[PIN_G2];
     DevBuf scal1[PIN_G1], scal2[PIN_G2];
     DevBuf wit_raw, deltas, results, out_dev;
+    DevBuf kappa;                     // compact derived pool: kappa_v | kappa_w | the partial sums of frstage_leading_coeffs
     hipStream_t st = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;      // slot 0 only: the G2 pair and the h pool run beside the five I_mid pools while the proof is alone
     hipEvent_t done = nullptr, fork = nullptr, join1 = nullptr, join2 = nullptr;
@@ -61,6 +74,8 @@ struct PinKey {
     DevBuf mid_idx, wit_resident;
     bool have_witness = false;
     bool lagrange = false;              // pool 5 holds [lambda_t(s)] (n-1) | [Z(s)] | [1] | v_all | w_all instead of si (n+1) | v_all | w_all
+    bool compact = false;               // pool 5 without v_all | w_all: si (n+1), or derived [lambda_t(s)] (n-1) | [Z(s)] | [1] | [s^(n-1)]  (header comment)
+    DevBuf pw;                          // compact + derived: (n + t)^(n-1), t < n - 1
     std::unique_ptr<PinSlot> slots[PIN_MAX_SLOTS];
 };
 int derive_shifted_bases_g1(const FrStage& f, const uint8_t* d_si, uint8_t* d_out, hipStream_t s);   // lagrange_derive.hip
@@ -76,29 +91,64 @@ struct PinScalPtrs {
     uint32_t* s1[PIN_G1];
     uint32_t* s2[PIN_G2];
 };
-// one lane per entry of the longest vector (the h pool: n + 1 + 2 m)
-__global__ void k_pinocchio_scalars(PinScalPtrs out, const uint32_t* __restrict__ h, const uint32_t* __restrict__ z,
-                                    const uint32_t* __restrict__ wit_mont, const uint32_t* __restrict__ mid_idx,
-                                    const uint32_t* __restrict__ deltas, uint32_t n, uint32_t m, uint32_t n_mid, uint32_t lagrange) {
+// the inputs of the h product's scalar vector, by key form (PinKey::lagrange, PinKey::compact)
+struct PinHArgs {
+    const uint32_t* h;          // tau-power: n - 1 coefficients; derived: h(n + t), t < n - 1
+    const uint32_t* z;          // Z's n + 1 coefficients
+    const uint32_t* vco;        // compact, tau-power: the coefficients of v and w (n each)
+    const uint32_t* wco;
+    const uint32_t* sa;         // compact, derived: the convolution outputs Sa_j, Sb_j at j = n + t (v(j) = zt[t] Sa_j), zt, (n + t)^(n-1), kappa_v | kappa_w
+    const uint32_t* sb;
+    const uint32_t* zt;
+    const uint32_t* pw;
+    const uint32_t* kappa;
+    uint32_t lagrange, compact;
+};
+static inline uint64_t pin_h_points(uint32_t n, uint32_t m, bool lagrange, bool compact) {
+    return compact ? (uint64_t)n + (lagrange ? 2 : 1) : (uint64_t)n + 1 + 2 * (uint64_t)m;
+}
+// one lane per entry of the longest vector (the h pool, or the pools over the mids where the compact h pool is shorter)
+__global__ void k_pinocchio_scalars(PinScalPtrs out, PinHArgs ha, const uint32_t* __restrict__ wit_mont, const uint32_t* __restrict__ mid_idx,
+                                    const uint32_t* __restrict__ deltas, uint32_t n, uint32_t m, uint32_t n_mid) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t ph = (uint64_t)n + 1 + 2 * (uint64_t)m;
-    if (i >= ph) return;
+    const uint32_t lagrange = ha.lagrange;
+    const uint64_t ph = ha.compact ? (uint64_t)n + (lagrange ? 2 : 1) : (uint64_t)n + 1 + 2 * (uint64_t)m;
+    if (i >= ph && i >= (uint64_t)n_mid + 3) return;
     const Fr dv = fe_to_mont(fe_load<FrParams>(deltas)), dw = fe_to_mont(fe_load<FrParams>(deltas + 8)),
              dy = fe_to_mont(fe_load<FrParams>(deltas + 16));
+    const uint32_t* h = ha.h;
+    const uint32_t* z = ha.z;
     // pool 5: h'
-    Fr x;
-    if (i <= n && lagrange) {
-        // derived key: h through its VALUES on n .. 2n-2 against [lambda_t(s)], then dv dw on the single point [Z(s)], -dy on [1]
-        if (i + 1 < n) x = fe_load<FrParams>(h + 8 * i);
-        else if (i + 1 == n) x = fe_mul(dv, dw);
-        else x = fe_neg(dy);
-    } else if (i <= n) {
-        x = fe_mul(fe_mul(dv, dw), fe_load<FrParams>(z + 8 * i));            // dv dw Z_i
-        if (i + 1 < n) x = fe_add(x, fe_load<FrParams>(h + 8 * i));          // h has n - 1 coefficients
-        if (i == 0) x = fe_sub(x, dy);
-    } else if (i <= (uint64_t)n + m) x = fe_mul(dw, fe_load<FrParams>(wit_mont + 8 * (i - n - 1)));
-    else x = fe_mul(dv, fe_load<FrParams>(wit_mont + 8 * (i - n - 1 - m)));
-    fe_store<FrParams>(out.s1[5] + 8 * i, fe_from_mont(x));
+    if (i < ph) {
+        Fr x;
+        if (ha.compact && lagrange) {
+            const Fr kv = fe_load<FrParams>(ha.kappa), kw = fe_load<FrParams>(ha.kappa + 8);
+            if (i + 1 < n) {
+                const Fr p = fe_load<FrParams>(ha.pw + 8 * i), zt = fe_load<FrParams>(ha.zt + 8 * i);
+                const Fr ve = fe_sub(fe_mul(zt, fe_load<FrParams>(ha.sa + 8 * ((uint64_t)n + i))), fe_mul(kv, p));      // (v - kappa_v X^(n-1))(n + t)
+                const Fr we = fe_sub(fe_mul(zt, fe_load<FrParams>(ha.sb + 8 * ((uint64_t)n + i))), fe_mul(kw, p));
+                x = fe_add(fe_load<FrParams>(h + 8 * i), fe_add(fe_mul(dw, ve), fe_mul(dv, we)));
+            } else if (i + 1 == n) x = fe_mul(dv, dw);                                   // [Z(s)]
+            else if (i == n) x = fe_neg(dy);                                             // [1]
+            else x = fe_add(fe_mul(dw, kv), fe_mul(dv, kw));                             // [s^(n-1)]
+        } else if (ha.compact) {
+            x = fe_mul(fe_mul(dv, dw), fe_load<FrParams>(z + 8 * i));                    // dv dw Z_i, i <= n
+            if (i + 1 < n) x = fe_add(x, fe_load<FrParams>(h + 8 * i));
+            if (i < n) x = fe_add(x, fe_add(fe_mul(dw, fe_load<FrParams>(ha.vco + 8 * i)), fe_mul(dv, fe_load<FrParams>(ha.wco + 8 * i))));
+            if (i == 0) x = fe_sub(x, dy);
+        } else if (i <= n && lagrange) {
+            // derived key: h through its VALUES on n .. 2n-2 against [lambda_t(s)], then dv dw on the single point [Z(s)], -dy on [1]
+            if (i + 1 < n) x = fe_load<FrParams>(h + 8 * i);
+            else if (i + 1 == n) x = fe_mul(dv, dw);
+            else x = fe_neg(dy);
+        } else if (i <= n) {
+            x = fe_mul(fe_mul(dv, dw), fe_load<FrParams>(z + 8 * i));            // dv dw Z_i
+            if (i + 1 < n) x = fe_add(x, fe_load<FrParams>(h + 8 * i));          // h has n - 1 coefficients
+            if (i == 0) x = fe_sub(x, dy);
+        } else if (i <= (uint64_t)n + m) x = fe_mul(dw, fe_load<FrParams>(wit_mont + 8 * (i - n - 1)));
+        else x = fe_mul(dv, fe_load<FrParams>(wit_mont + 8 * (i - n - 1 - m)));
+        fe_store<FrParams>(out.s1[5] + 8 * i, fe_from_mont(x));
+    }
     // pools over the mids
     if (i < (uint64_t)n_mid + 3) {
         Fr c = fe_zero<FrParams>();
@@ -117,6 +167,69 @@ __global__ void k_pinocchio_scalars(PinScalPtrs out, const uint32_t* __restrict_
         put(out.s2[0], 1, dw, dw, dw);       // ww | wt
         put(out.s2[1], 1, dw, dw, dw);       // waw | wawt
     }
+}
+
+// ---- the compact h pool's precondition: v_all / w_all are the images of the key's own powers si (header comment)
+static bool pin_compact_wanted() {          // read per key (set-up path)
+    const char* e = ::zk::opt("ZK_PIN_COMPACT_H");
+    return !(e && atoi(e) == 0);
+}
+// rho[k]: pseudo-random canonical scalars below 2^254 (splitmix64 of the index: a consistency check of a key against itself, not a secret)
+__global__ void k_pin_rho(uint32_t* __restrict__ rho, uint64_t m, uint64_t seed) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    Fr r;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint64_t x = seed + (4 * k + q + 1) * 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        r.v[2 * q] = (uint32_t)x;
+        r.v[2 * q + 1] = (uint32_t)(x >> 32);
+    }
+    r.v[7] &= 0x3fffffffu;
+    fe_store<FrParams>(rho + 8 * k, r);
+}
+// four scalar vectors over si | v_all | w_all (canonical):  0: coefficients of v_rho on si,  1: rho on v_all,  2: coefficients of w_rho on si,  3: rho on w_all
+__global__ void k_pin_check_scalars(uint32_t* __restrict__ out, const uint32_t* __restrict__ vco, const uint32_t* __restrict__ wco,
+                                    const uint32_t* __restrict__ rho, uint32_t n, uint32_t m) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t ph = (uint64_t)n + 1 + 2 * (uint64_t)m;
+    if (i >= ph) return;
+    const Fr zero = fe_zero<FrParams>();
+    Fr x[4] = {zero, zero, zero, zero};
+    if (i < n) { x[0] = fe_from_mont(fe_load<FrParams>(vco + 8 * i)); x[2] = fe_from_mont(fe_load<FrParams>(wco + 8 * i)); }
+    else if (i > n && i <= (uint64_t)n + m) x[1] = fe_load<FrParams>(rho + 8 * (i - n - 1));
+    else if (i > (uint64_t)n + m) x[3] = fe_load<FrParams>(rho + 8 * (i - n - 1 - m));
+#pragma unroll
+    for (int q = 0; q < 4; q++) fe_store<FrParams>(out + 8 * (q * ph + i), x[q]);
+}
+// *ok = the key's v_all / w_all equal sum_j (v_k)_j si[j] / sum_j (w_k)_j si[j] for every variable k (up to the 2^-254 of a random combination).
+// `full`: si | v_all | w_all as a plain (one-window) base set.
+static int pin_compact_check(const FrStage& fr, const MsmBases& full, uint32_t n, uint32_t m, bool* ok, hipStream_t s) {
+    *ok = false;
+    const uint64_t ph = (uint64_t)n + 1 + 2 * (uint64_t)m;
+    if (full.n != ph) ZK_FAIL(ZK_ERR_ARG, "pin_compact_check: unexpected pool length");
+    FrScratch fs;
+    MsmWorkspace w;
+    DevBuf rho, scal, res;
+    ZKCHK(frstage_scratch_alloc(fr, fs));
+    ZKCHK(msm_workspace_alloc(w, full));
+    ZKCHK(rho.alloc(32 * (size_t)m));
+    ZKCHK(scal.alloc(32 * 4 * (size_t)ph));
+    ZKCHK(res.alloc(4 * xyzz_bytes(CURVE_G1)));
+    hipLaunchKernelGGL(k_pin_rho, g1d(m), dim3(256), 0, s, rho.as<uint32_t>(), (uint64_t)m, 0x5EEDC0DE2026ull ^ ((uint64_t)n << 32) ^ m);
+    HIPCHK(hipGetLastError());
+    ZKCHK(frstage_eval(fr, fs, rho.p, s));          // v_rho = sum_k rho_k v_k and w_rho as coefficient vectors (rho satisfies no gate: flags and h are not read)
+    hipLaunchKernelGGL(k_pin_check_scalars, g1d(ph), dim3(256), 0, s, scal.as<uint32_t>(), (const uint32_t*)fs.d.as<uint32_t>(),
+                       (const uint32_t*)(fs.d.as<uint32_t>() + 8 * (uint64_t)fr.n2), (const uint32_t*)rho.as<uint32_t>(), n, m);
+    HIPCHK(hipGetLastError());
+    for (int q = 0; q < 4; q++) ZKCHK(msm_run(full, w, scal.as<uint8_t>() + 32 * q * ph, res.as<uint8_t>() + q * xyzz_bytes(CURVE_G1), s));
+    uint8_t pts[4 * 96];
+    ZKCHK(points_xyzz_to_bytes(CURVE_G1, res.p, 4, pts, s));          // synchronises
+    *ok = memcmp(pts, pts + 96, 96) == 0 && memcmp(pts + 192, pts + 288, 96) == 0;
+    return ZK_OK;
 }
 
 static int pin_lookup(uint64_t handle, PinKey** out) {
@@ -162,7 +275,21 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     ZKCHK(pool1(2, VAV, nm, {ONES + 96 * 2}));
     ZKCHK(pool1(3, YAY, nm, {ONES + 96 * 3}));
     ZKCHK(pool1(4, BV, nm, {ONES + 96 * 4, ONES + 96 * 5, ONES + 96 * 6}));
-    ZKCHK(pool1(5, SI, (uint64_t)n + 1 + 2 * (uint64_t)m, {}));          // si | v_all | w_all are contiguous in the key
+    const uint64_t ph_full = (uint64_t)n + 1 + 2 * (uint64_t)m;          // si | v_all | w_all are contiguous in the key
+    if (pin_compact_wanted()) {
+        // every point is decoded and checked as before (of_bytes_exn); the pool then keeps v_all | w_all only if they fail the check of the header comment
+        MsmBases full;
+        ZKCHK(msm_bases_from_bytes(full, CURVE_G1, SI, ph_full, 0, false, c.stream, key_subgroup_check()));
+        bool ok = false;
+        ZKCHK(pin_compact_check(k.fr, full, n, m, &ok, c.stream));
+        const uint64_t keep = ok ? (uint64_t)n + 1 : ph_full;
+        DevBuf dense;
+        ZKCHK(dense.alloc(96 * keep));
+        ZKCHK(msm_bases_dense(full, 0, keep, dense.p, c.stream));
+        ZKCHK(msm_bases_from_device_affine(k.g1[5], CURVE_G1, dense.p, keep, 0, true, c.stream, full.in_subgroup));
+        HIPCHK(hipStreamSynchronize(c.stream));          // `dense` is read by the table build
+        k.compact = ok;
+    } else ZKCHK(pool1(5, SI, ph_full, {}));
     auto pool2 = [&](int idx, const uint8_t* base, const uint8_t* extra) -> int {
         buf.assign(base, base + 192 * nm);
         buf.insert(buf.end(), extra, extra + 192);
@@ -191,13 +318,13 @@ int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
     HIPCHK(hipDeviceSynchronize());
     Ctx& c = ctx();
     const uint32_t n = k.n;
-    const uint64_t ph = (uint64_t)n + 1 + 2 * (uint64_t)k.m;
+    const uint64_t ph_old = pin_h_points(n, k.m, false, k.compact), ph = pin_h_points(n, k.m, true, k.compact);
     MsmBases& old = k.g1[5];
-    if (old.n != ph) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: unexpected pool length");
+    if (old.n != ph_old) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: unexpected pool length");
     DevBuf pool, old_dense;
     ZKCHK(pool.alloc(96 * ph));
-    ZKCHK(old_dense.alloc(96 * ph));
-    ZKCHK(msm_bases_dense(old, 0, ph, old_dense.p, c.stream));            // window 0 = the pool as uploaded, back in the dense affine format
+    ZKCHK(old_dense.alloc(96 * ph_old));
+    ZKCHK(msm_bases_dense(old, 0, ph_old, old_dense.p, c.stream));            // window 0 = the pool as uploaded, back in the dense affine format
     const uint8_t* si = old_dense.as<uint8_t>();
     // [lambda_t(s)], t < n - 1
     ZKCHK(derive_shifted_bases_g1(k.fr, si, pool.as<uint8_t>(), c.stream));
@@ -220,13 +347,20 @@ int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
         HIPCHK(hipStreamSynchronize(c.stream));
     }
     HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * (uint64_t)n, si, 96, hipMemcpyDeviceToDevice, c.stream));                                       // [1] = si[0]
-    HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * ((uint64_t)n + 1), si + 96 * ((uint64_t)n + 1), 96 * 2 * (uint64_t)k.m, hipMemcpyDeviceToDevice, c.stream));   // v_all | w_all
+    if (k.compact) {
+        HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * ((uint64_t)n + 1), si + 96 * (uint64_t)(n - 1), 96, hipMemcpyDeviceToDevice, c.stream));    // [s^(n-1)]
+        ZKCHK(k.pw.alloc(32 * (size_t)(n > 1 ? n - 1 : 1)));
+        ZKCHK(frstage_shifted_powers(k.pw.p, n, n - 1, n - 1, c.stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * ((uint64_t)n + 1), si + 96 * ((uint64_t)n + 1), 96 * 2 * (uint64_t)k.m, hipMemcpyDeviceToDevice, c.stream));   // v_all | w_all
+    }
     MsmBases nb;
     ZKCHK(msm_bases_from_device_affine(nb, CURVE_G1, pool.p, ph, old.c, true, c.stream, old.in_subgroup));      // derived from the old pool's points: msm.cuh, msm_fold
     ZKCHK(frstage_init_lagrange(k.fr, c.stream));
     HIPCHK(hipStreamSynchronize(c.stream));
     k.g1[5] = std::move(nb);
     k.lagrange = true;
+    for (uint32_t i = 0; i < PIN_MAX_SLOTS; i++) k.slots[i].reset();          // the h pool changed its length (compact) and the Fr scratch its form: slots are rebuilt on demand
     return ZK_OK;
 }
 int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t capacity_points, size_t* count) {
@@ -263,6 +397,7 @@ static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
         for (int i = 0; i < PIN_G2; i++) { ZKCHK(msm_workspace_alloc(sl->ws2[i], k.g2[i])); ZKCHK(sl->scal2[i].alloc(32 * k.g2[i].n)); }
         ZKCHK(sl->wit_raw.alloc(32 * (size_t)k.m));
         ZKCHK(sl->deltas.alloc(96));
+        ZKCHK(sl->kappa.alloc(32 * (2 + 2 * (size_t)LEAD_BLOCKS)));
         ZKCHK(sl->results.alloc(PIN_G1 * xyzz_bytes(CURVE_G1) + PIN_G2 * xyzz_bytes(CURVE_G2)));
         ZKCHK(sl->out_dev.alloc(960));
         HIPCHK(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
@@ -326,10 +461,21 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     PinScalPtrs ptrs;
     for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = sl.scal1[i].as<uint32_t>();
     for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = sl.scal2[i].as<uint32_t>();
-    const uint64_t ph = (uint64_t)k.n + 1 + 2 * (uint64_t)k.m;
-    hipLaunchKernelGGL(k_pinocchio_scalars, g1d(ph), dim3(256), 0, s0, ptrs, (const uint32_t*)sl.fs.h.as<uint32_t>(),
-                       (const uint32_t*)k.fr.z.as<uint32_t>(), (const uint32_t*)sl.fs.wit.as<uint32_t>(),
-                       (const uint32_t*)k.mid_idx.as<uint32_t>(), (const uint32_t*)sl.deltas.as<uint32_t>(), k.n, k.m, k.n_mid, k.lagrange ? 1u : 0u);
+    const uint64_t ph = pin_h_points(k.n, k.m, k.lagrange, k.compact);
+    PinHArgs ha{};
+    ha.h = sl.fs.h.as<uint32_t>(); ha.z = k.fr.z.as<uint32_t>();
+    ha.lagrange = k.lagrange ? 1u : 0u; ha.compact = k.compact ? 1u : 0u;
+    if (k.compact && k.lagrange) {
+        uint32_t* kap = sl.kappa.as<uint32_t>();
+        ZKCHK(frstage_leading_coeffs(k.fr, sl.fs, kap, kap + 16, s0));
+        ha.sa = sl.fs.bufA.as<uint32_t>(); ha.sb = sl.fs.bufA.as<uint32_t>() + 8 * (uint64_t)k.fr.S;
+        ha.zt = k.fr.zt.as<uint32_t>(); ha.pw = k.pw.as<uint32_t>(); ha.kappa = kap;
+    } else if (k.compact) {
+        ha.vco = sl.fs.d.as<uint32_t>(); ha.wco = sl.fs.d.as<uint32_t>() + 8 * (uint64_t)k.fr.n2;
+    }
+    const uint64_t lanes = ph > (uint64_t)k.n_mid + 3 ? ph : (uint64_t)k.n_mid + 3;
+    hipLaunchKernelGGL(k_pinocchio_scalars, g1d(lanes), dim3(256), 0, s0, ptrs, ha, (const uint32_t*)sl.fs.wit.as<uint32_t>(),
+                       (const uint32_t*)k.mid_idx.as<uint32_t>(), (const uint32_t*)sl.deltas.as<uint32_t>(), k.n, k.m, k.n_mid);
     HIPCHK(hipGetLastError());
     char* res = sl.results.as<char>();
     char* out = sl.out_dev.as<char>();
