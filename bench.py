@@ -580,6 +580,7 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight, peak_products=None)
         prover.derive_lagrange()
         derive_s = time.perf_counter() - t_d
     dt, lat, parity = measure()
+    h_points = prover.pool_size(5)
     if as_uploaded is not None:
         saved = as_uploaded["ms_per_proof"] - dt / nproofs * 1e3
         as_uploaded["break_even_proofs"] = int(derive_s * 1e3 / saved) + 1 if saved > 0 else None
@@ -611,11 +612,14 @@ def bench_pinocchio(args, L, _lib, log_n, nproofs, inflight, peak_products=None)
     m_mid = cs.n_mid
     alg = 5 * 128 * m_mid + 2 * 128 * cs.m + 2 * 128 * n + 2 * 224 * m_mid + 192 * n       # 1792 n B at m_mid = m = n
     # scalar-point pairs per proof: five pools over I_mid (+ their appended single points), the h pool (n + 1 + 2m), two G2 pools over I_mid
-    pairs = {"g1": 4 * (m_mid + 1) + (m_mid + 3) + (n + 1 + 2 * cs.m), "g2": 2 * (m_mid + 1)}
+    # -- the h pool as the prover holds it: n + 2 points (compact, derived), n + 1 (compact, as uploaded) or the reference's n + 1 + 2m (csrc/pinocchio.hip);
+    # the kernel rooflines count the pairs the launches really carry, the whole-prove figure keeps the reference's 1792 B per constraint
+    pairs = {"g1": 4 * (m_mid + 1) + (m_mid + 3) + h_points, "g2": 2 * (m_mid + 1)}
     roofs = roofline_objects(fams.get("timed", {}), nproofs, fams.get("alone", {}), 2, pairs, 1, 16, peak_products, None, "", fams.get("counters"))
     return {"workload": "pinocchio_zk_prove (BASELINE config 5), iterated-cubic R1CS, key+circuit+witness resident in HBM", "log_n": log_n, "constraints": n,
             "value": n * nproofs / dt, "unit": "constraints/s", "ms_per_proof": dt / nproofs * 1e3, "timed_s": dt, "timed_proofs": nproofs,
             "proofs_in_flight": depth, "single_proof_latency_ms": lat * 1e3, "single_proof_note": "one at a time, witness handed over as a host buffer",
+            "h_pool_points": h_points, "h_pool_form": "compact: dw [v(s)] + dv [w(s)] ride on the bases of h (v_all | w_all checked against si at upload)" if h_points <= n + 2 else "si | v_all | w_all",
             "prove_algorithmic_bytes_per_constraint": alg / n, "prove_hbm_frac": alg / (dt / nproofs) / 1e9 / HBM_PEAK_GBS, "parity": parity,
             "derive_lagrange_s": None if derive_s is None else round(derive_s, 2), "as_uploaded": as_uploaded, "cpu_baseline": cpu,
             "roofline_g1": roofs.get("g1"), "roofline_g2": roofs.get("g2"),      # the six G1 / two G2 accumulate launches of a proof, as for Groth16

@@ -263,17 +263,26 @@ int zk_groth16_combine_device(const void* d_partials /* device */, size_t stride
  * zk_pinocchio_prove = ZKCompute.f (:427-514) with dv, dw, dy supplied in the order the reference draws
  * them (:428-430); all three zero gives Compute.f (:210-248), i.e. NonZK.prove.
  * proof: vv (G1) | ww (G2) | yy | h | vavv | waww (G2) | yayy | bvwy = 960 B uncompressed, the field order
- * of Compute.proof (:195-208).  ZK_ERR_REMAINDER as for Groth16. */
+ * of Compute.proof (:195-208).  ZK_ERR_REMAINDER as for Groth16.
+ * The h product's points v_all | w_all carry the blinding terms sum_k (dw c_k) [v_k(s)] + sum_k (dv c_k) [w_k(s)] (:481-486) = dw [v(s)] + dv [w(s)]
+ * with v = sum_k c_k v_k, w = sum_k c_k w_k -- the polynomials QAP.eval builds anyway.  At upload the library checks v_all / w_all against the
+ * key's own powers (<v_all, rho> = <si, coefficients of sum_k rho_k v_k> for a pseudo-random rho, likewise w_all: true of every key
+ * KeyGen.generate makes, :104-109,140-147) and then lets the two terms ride on si: the COMPACT h pool, n + 1 points instead of n + 1 + 2 m, same
+ * proof bytes.  A key that fails the check, or any key under zk_set_option("ZK_PIN_COMPACT_H", "0"), keeps the full pool and is used point by
+ * point as ZKCompute.f uses it. */
 int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                            const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
                            const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
 /* As zk_groth16_pk_derive_lagrange, for the evaluation key of pinocchio.ml:37-60: the powers si are turned into the Lagrange basis of the points
  * n .. 2n-2 in the exponent (plus [Z(s)] = <si, Z>, once), so that h enters its multi-scalar product through VALUES; v(s), w(s) never needed
- * coefficient vectors (they come from the per-variable pools).  Once per key; proofs byte-identical. */
+ * coefficient vectors (they come from the per-variable pools).  Once per key; proofs byte-identical.  With the compact h pool the blinding terms
+ * follow: v = kappa_v X^(n-1) + (degree <= n-2), so dw [v(s)] + dv [w(s)] ride on [lambda_t(s)] through the values v(n+t), w(n+t) the prover
+ * already extrapolates, plus ONE more base [s^(n-1)] = si[n-1] for the leading coefficients. */
 int zk_pinocchio_pk_derive_lagrange(uint64_t handle);
 /* A resident base pool of the key as uncompressed points, in pool order (out == NULL: only *count).  Pools 0..5 are the G1 products
- * vv|vt, yy|yt, vav|vavt, yay|yayt, bvwy|vbt|wbt|ybt and the h pool (si | v_all | w_all, or after zk_pinocchio_pk_derive_lagrange
- * [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all); 6..7 the G2 products ww|wt and waw|wawt (pinocchio.ml:37-60). */
+ * vv|vt, yy|yt, vav|vavt, yay|yayt, bvwy|vbt|wbt|ybt and the h pool; 6..7 the G2 products ww|wt and waw|wawt (pinocchio.ml:37-60).
+ * The h pool by key form:  compact (default): si (n + 1 points); after zk_pinocchio_pk_derive_lagrange [lambda_t(s)] (n-1) | [Z(s)] | [1] | [s^(n-1)];
+ *                          full:              si | v_all | w_all;   after the derivation [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all. */
 int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t capacity_points, size_t* count);
 int zk_pinocchio_pk_free(uint64_t handle);
 int zk_pinocchio_prove(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32],

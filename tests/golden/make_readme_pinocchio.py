@@ -61,7 +61,7 @@ def main():
     g1 = lambda e: P.g1_to_bytes(P.pt_mul(P.G1, e % R)).hex()
     g2 = lambda e: P.g2_to_bytes(P.pt_mul(P.G2, e % R)).hex()
     proof = g1(e_vv) + g2(e_ww) + g1(e_yy) + g1(e_h) + g1(av * e_vv) + g2(aw * e_ww) + g1(ay * e_yy) + g1(e_bv)
-    # the h pool after zk_pinocchio_pk_derive_lagrange: [lambda_t(s)] (n-1) | [Z(s)] | [1] | v_all | w_all, lambda_t over the points n .. 2n-2
+    # the h pool after zk_pinocchio_pk_derive_lagrange: [lambda_t(s)] (n-1) | [Z(s)] | [1] | ..., lambda_t over the points n .. 2n-2
     pts = list(range(n, 2 * n - 1))
     lam = []
     for i, xi in enumerate(pts):
@@ -71,7 +71,29 @@ def main():
                 num = num * (s - xj) % R
                 den = den * (xi - xj) % R
         lam.append(num * inv(den) % R)
-    derived_h_pool = lam + [t, 1] + vk + wk
+    derived_h_pool_full = lam + [t, 1] + vk + wk                       # a key whose v_all / w_all fail the upload's consistency check, or ZK_PIN_COMPACT_H=0
+    # the COMPACT h pool (csrc/pinocchio.hip, the default): v_all | w_all leave the product -- dw [v(s)] + dv [w(s)] ride on the bases of h plus [s^(n-1)]
+    derived_h_pool = lam + [t, 1, pow(s, n - 1, R)]
+    # the compact pool's scalar vector gives the same exponent as e_h: h(n+t) + dw (v - kv X^(n-1))(n+t) + dv (w - kw X^(n-1))(n+t) | dv dw | -dy | dw kv + dv kw
+    def interp_eval(vals, x):                                            # the interpolant of (i, vals[i]), i < n, at x
+        acc = 0
+        for i in range(n):
+            num = den = 1
+            for j in range(n):
+                if j != i:
+                    num = num * (x - j) % R
+                    den = den * (i - j) % R
+            acc = (acc + vals[i] * num * inv(den)) % R
+        return acc
+    row = lambda M: [sum(M[g].get(k, 0) * c[k] for k in range(m)) % R for g in range(n)]
+    a_vals, b_vals, c_vals = row(Lm), row(Rm), row(Om)
+    lead = lambda vals: sum(vals[i] * inv(__import__("math").prod((i - j) for j in range(n) if j != i) % R) for i in range(n)) % R
+    kv, kw = lead(a_vals), lead(b_vals)
+    zat = lambda x: __import__("math").prod((x - i) for i in range(n)) % R
+    hv = [((interp_eval(a_vals, x) * interp_eval(b_vals, x) - interp_eval(c_vals, x)) * inv(zat(x))) % R for x in pts]
+    sc = [(hv[i] + dw * (interp_eval(a_vals, x) - kv * pow(x, n - 1, R)) + dv * (interp_eval(b_vals, x) - kw * pow(x, n - 1, R))) % R for i, x in enumerate(pts)]
+    sc += [dv * dw % R, -dy % R, (dw * kv + dv * kw) % R]
+    assert sum(a * b for a, b in zip(sc, derived_h_pool)) % R == e_h, "compact h pool: scalar vector does not reproduce h'"
     # verification key (pinocchio.ml:62-75) flattened as include/zkmi355x.h lays it out, and the NonZK proof (Compute.f, :210-248: no blinding)
     ios = [k for k in range(m) if not mid[k]]
     vx1 = [1, aw, gm * b % R] + [rv * vk[k] % R for k in ios] + [ry * yk[k] % R for k in ios]
@@ -81,7 +103,7 @@ def main():
     out = {"how": "python tests/golden/make_readme_pinocchio.py (first-principles Python big integers, oracle/pyref.py)",
            "toxic": [hex(v) for v in (rv, rw, s, av, aw, ay, b, gm)], "deltas": [hex(v) for v in (dv, dw, dy)],
            "witness": [hex(v) for v in c], "mid": mid, "pk_g1": [g1(e) for e in ex1], "pk_g2": [g2(e) for e in ex2],
-           "derived_h_pool_g1": [g1(e) for e in derived_h_pool], "proof": proof,
+           "derived_h_pool_g1": [g1(e) for e in derived_h_pool], "derived_h_pool_g1_full": [g1(e) for e in derived_h_pool_full], "proof": proof,
            "pk_exponents_g1": [hex(e % R) for e in ex1], "pk_exponents_g2": [hex(e % R) for e in ex2],
            "vk_exponents_g1": [hex(e % R) for e in vx1], "vk_exponents_g2": [hex(e % R) for e in vx2],
            "vk_g1": [g1(e) for e in vx1], "vk_g2": [g2(e) for e in vx2], "io": [hex(c[k]) for k in ios], "proof_nonzk": proof0}

@@ -79,3 +79,13 @@ def test_emit_writes_the_detail_file_and_prints_the_line_last(tmp_path, capsys, 
     assert len(out_lines) == 1 and len(out_lines[0]) < 4096 and json.loads(out_lines[0])["metric"] == full["metric"]
     assert cap.err.startswith("BENCH_DETAIL {") and json.loads(cap.err[len("BENCH_DETAIL "):]) == full
     assert json.load(open(tmp_path / "bench_detail.json")) == full
+
+
+def test_bench_parses_its_arguments_and_prints_its_help():
+    """`python bench.py --help` goes through main() up to the parser: a name shadowed inside main (round 5: a function-local `import argparse`)
+    or a help string argparse cannot format kills the driver's default run before its first line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "--gpus" in res.stdout and "--steps" in res.stdout and "--warmup" in res.stdout, res.stderr[-2000:]

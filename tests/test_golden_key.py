@@ -96,9 +96,22 @@ def test_gpu_reproduces_the_pinocchio_fixture():
     pp = PIN.ZK(cs, key)
     assert pp.prove_with(W, *PDEL).to_bytes() == PPROOF
     n, m = cs.n, cs.m
-    assert bytes(pp.pool_points(5)) == PPK1[96 * 15:96 * (15 + n + 1 + 2 * m)]                      # si | v_all | w_all as uploaded
+    assert bytes(pp.pool_points(5)) == PPK1[96 * 15:96 * (15 + n + 1)]                              # the compact h pool: si alone (v_all | w_all passed the consistency check)
     pp.derive_lagrange()
-    assert bytes(pp.pool_points(5)) == PDER                                                        # [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all, derived without s
+    assert bytes(pp.pool_points(5)) == PDER                                                        # [lambda_t(s)] | [Z(s)] | [1] | [s^(n-1)], derived without s
+    assert pp.prove_with(W, *PDEL).to_bytes() == PPROOF
+    pp.close()
+    # the full pool (ZK_PIN_COMPACT_H=0): si | v_all | w_all as uploaded, [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all derived
+    from zukelang_amd import _lib
+    _lib.check(_lib.lib().zk_set_option(b"ZK_PIN_COMPACT_H", b"0"))
+    try:
+        pp = PIN.ZK(cs, key)
+    finally:
+        _lib.check(_lib.lib().zk_set_option(b"ZK_PIN_COMPACT_H", None))
+    assert bytes(pp.pool_points(5)) == PPK1[96 * 15:96 * (15 + n + 1 + 2 * m)]
+    assert pp.prove_with(W, *PDEL).to_bytes() == PPROOF
+    pp.derive_lagrange()
+    assert bytes(pp.pool_points(5)) == cat(PFIX["derived_h_pool_g1_full"])
     assert pp.prove_with(W, *PDEL).to_bytes() == PPROOF
     pp.close()
 

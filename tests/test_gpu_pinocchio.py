@@ -133,3 +133,83 @@ def test_pinocchio_derived_h_bases_give_the_same_proofs(maker):
     with pytest.raises(AssertionError):
         prover.prove_with(w_bad, *ds[0])
     prover.close()
+
+
+def _set_option(name, value):
+    from zukelang_amd import _lib
+    _lib.check(_lib.lib().zk_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+@pytest.mark.parametrize("maker", [lambda: RC.readme_circuit(3), lambda: RC.random_r1cs(1, 6, 76, nnz=(1, 2)), lambda: RC.random_r1cs(2, 5, 75, nnz=(1, 2)), lambda: RC.iterated_cubic(6, 9), lambda: RC.random_r1cs(24, 40, 77),
+                                   lambda: RC.random_r1cs(48, 30, 78, one=False), lambda: RC.iterated_cubic(300, 14)])
+def test_compact_h_pool_its_switch_and_its_fallback(maker):
+    """Round 5 (csrc/pinocchio.hip): the h product sum_k (dw c_k) [v_k(s)] + sum_k (dv c_k) [w_k(s)] over v_all | w_all (pinocchio.ml:481-486) is
+    dw [v(s)] + dv [w(s)] and rides on the powers si (n + 1 points instead of n + 1 + 2 m; derived key: n + 2) -- for keys whose v_all / w_all
+    pass the upload's consistency check against si.  Three keys: the default, the switch off (ZK_PIN_COMPACT_H=0: the full pool), and a key with
+    ONE v_all point replaced by another subgroup point (the check fails, the full pool stays, and the proof is what ZKCompute.f computes FROM
+    THAT KEY point by point: the literal oracle on the tampered bytes).  Every proof, tau-power and derived form, against the oracles."""
+    cs, w = maker()
+    n, m = cs.n, cs.m
+    L, R_, Oo = csrs(cs)
+    st = P.fr_stream(0x5EED0C0B)
+    tox = [next(st) for _ in range(8)]
+    toxic = frs(tox)
+    it = iter(tox)
+    pk, _vk = PIN.ZK.keygen(lambda: next(it), cs)
+    ds = [[next(st) for _ in range(3)] for _ in range(2)] + [[0, 0, 0]]
+    exp = [O.pinocchio_prove_trapdoor(n, m, L, R_, Oo, cs.mid, frs(w), toxic, *(P.fr_to_bytes(x) for x in d)) for d in ds]
+    q = O.QAP(n, m, L, R_, Oo)
+    if n <= 64:
+        for d, e in zip(ds, exp):
+            rc, ref = O.pinocchio_prove(q, bytes(pk.g1), bytes(pk.g2), cs.mid, frs(w), *(P.fr_to_bytes(x) for x in d))
+            assert rc == 0 and ref == e
+    nm = sum(1 for k in range(m) if cs.mid[k])
+    si0 = 5 * nm                                                       # first point of si in the flattened G1 key
+    full = bytes(pk.g1[96 * si0:96 * (si0 + n + 1 + 2 * m)])
+
+    def run(prover, want, tag):
+        got = [prover.prove_with(w, *d).to_bytes() for d in ds]
+        assert got == want, tag
+        prover.derive_lagrange()
+        got = [prover.prove_with(w, *d).to_bytes() for d in ds]
+        assert got == want, tag + ", derived"
+        prover.set_witness(w)
+        for slot, d in enumerate(ds):
+            prover.prove_async(*d, slot)
+        for slot in range(len(ds)):
+            assert prover.prove_wait(slot).to_bytes() == want[slot], tag + ", pipelined"
+
+    # the default: compact
+    prover = PIN.ZK(cs, pk)
+    assert bytes(prover.pool_points(5)) == full[:96 * (n + 1)]
+    run(prover, exp, "compact")
+    pool = bytes(prover.pool_points(5))
+    assert len(pool) == 96 * (n + 2) and pool[96 * n:96 * (n + 1)] == full[:96] and pool[96 * (n + 1):] == full[96 * (n - 1):96 * n]      # ... | [1] | [s^(n-1)]
+    prover.close()
+    # the switch
+    _set_option("ZK_PIN_COMPACT_H", 0)
+    try:
+        prover = PIN.ZK(cs, pk)
+    finally:
+        _set_option("ZK_PIN_COMPACT_H", None)
+    assert bytes(prover.pool_points(5)) == full
+    run(prover, exp, "full pool")
+    assert len(prover.pool_points(5)) == 96 * (n + 1 + 2 * m)
+    prover.close()
+    # a key whose v_all is not the image of its si: variable k's point replaced by [7] G1 (on the curve, in the subgroup -- only the relation to si is broken)
+    k = next(k for k in range(m) if w[k] % RC.FR_MODULUS != 0)
+    bad = np.array(pk.g1, copy=True)
+    off = 96 * (si0 + n + 1 + k)
+    bad[off:off + 96] = np.frombuffer(O.g1_mul(O.g1_generator(), P.fr_to_bytes(7)), dtype=np.uint8)
+    bad_key = PIN.PKey(bad, pk.g2)
+    prover = PIN.ZK(cs, bad_key)
+    assert bytes(prover.pool_points(5)) == bytes(bad[96 * si0:96 * (si0 + n + 1 + 2 * m)]), "an inconsistent key keeps its full h pool"
+    if n <= 64:
+        want = []
+        for d in ds:
+            rc, ref = O.pinocchio_prove(q, bytes(bad), bytes(pk.g2), cs.mid, frs(w), *(P.fr_to_bytes(x) for x in d))
+            assert rc == 0
+            want.append(ref)
+        assert want[0] != exp[0] and want[2] == exp[2]                 # the blinding terms see the replaced point, the NonZK proof does not
+        run(prover, want, "inconsistent key")
+    prover.close()

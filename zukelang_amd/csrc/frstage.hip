@@ -649,6 +649,11 @@ int frstage_leading_coeffs(const FrStage& f, const FrScratch& sc, void* d_kappa,
     uint32_t blocks = (n + LEAD_THREADS - 1) / LEAD_THREADS;
     if (blocks > LEAD_BLOCKS) blocks = LEAD_BLOCKS;
     const uint32_t* a = FRP(sc.abc);
+    if (n == 1) {          // one gate: the interpolants are the constants a_0, b_0 (frstage_init builds no table for it)
+        HIPCHK(hipMemcpyAsync(d_kappa, a, 32, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync((uint8_t*)d_kappa + 32, a + 8, 32, hipMemcpyDeviceToDevice, s));
+        return ZK_OK;
+    }
     hipLaunchKernelGGL(k_lead_partial, dim3(blocks), dim3(LEAD_THREADS), 0, s, (uint32_t*)d_partials, a, a + 8 * (uint64_t)n, (const uint32_t*)FRP(f.invfact), n);
     hipLaunchKernelGGL(k_lead_final, dim3(1), dim3(64), 0, s, (uint32_t*)d_kappa, (const uint32_t*)d_partials, blocks);
     HIPCHK(hipGetLastError());

@@ -94,7 +94,8 @@ class _Prover:
 
     def derive_lagrange(self):
         """zk_pinocchio_pk_derive_lagrange: the h pool rewritten for the values of h (bases derived from the key's own powers si on the
-        device, once); afterwards every proof skips the basis conversion.  Proof bytes do not change."""
+        device, once); afterwards every proof skips the basis conversion.  Proof bytes do not change.  Pool 5 becomes
+        [lambda_t(s)] (n-1) | [Z(s)] | [1] | [s^(n-1)] (compact, the default) or [lambda_t(s)] | [Z(s)] | [1] | v_all | w_all."""
         _lib.check(_lib.lib().zk_pinocchio_pk_derive_lagrange(self.handle))
 
     def pool_points(self, pool):
@@ -104,6 +105,13 @@ class _Prover:
         out = np.zeros(cnt.value * (96 if pool < 6 else 192), dtype=np.uint8)
         _lib.check(_lib.lib().zk_pinocchio_pool_points(self.handle, C.c_int(pool), _p(out), C.c_size_t(cnt.value), C.byref(cnt)))
         return out
+
+    def pool_size(self, pool):
+        """Points in a resident pool.  Pool 5 tells the key's form: n + 1 + 2m = si | v_all | w_all as pinocchio.ml:481-486 reads them, n + 1 = the
+        compact h pool (v_all | w_all passed the upload's consistency check and ride on si: csrc/pinocchio.hip), n + 2 = its derived form."""
+        cnt = C.c_size_t()
+        _lib.check(_lib.lib().zk_pinocchio_pool_points(self.handle, C.c_int(pool), None, C.c_size_t(0), C.byref(cnt)))
+        return cnt.value
 
     def close(self):
         if getattr(self, "handle", None) is not None:
