@@ -213,3 +213,27 @@ def test_compact_h_pool_its_switch_and_its_fallback(maker):
         assert want[0] != exp[0] and want[2] == exp[2]                 # the blinding terms see the replaced point, the NonZK proof does not
         run(prover, want, "inconsistent key")
     prover.close()
+    # One sort per distinct scalar vector (vv / vav, yy / yay, ww / waw share theirs): switched off -- same proofs; and a key in which vav holds the identity
+    # where vv holds a point (never the case in a key KeyGen.generate made): the identity flags differ, the pair must NOT share, the proof follows the key
+    _set_option("ZK_PIN_SHARED_SORT", 0)
+    try:
+        prover = PIN.ZK(cs, pk)
+    finally:
+        _set_option("ZK_PIN_SHARED_SORT", None)
+    run(prover, exp, "own sorts")
+    prover.close()
+    mids = [v for v in range(m) if cs.mid[v]]
+    ident = bytes([0x40]) + bytes(95)
+    j = next((j for j, v in enumerate(mids) if w[v] % RC.FR_MODULUS != 0 and bytes(pk.g1[96 * j:96 * j + 96]) != ident), None)
+    if j is not None and n <= 64:
+        bad = np.array(pk.g1, copy=True)
+        bad[96 * (2 * nm + j):96 * (2 * nm + j + 1)] = np.frombuffer(ident, dtype=np.uint8)          # vav[j] := O
+        prover = PIN.ZK(cs, PIN.PKey(bad, pk.g2))
+        want = []
+        for d in ds:
+            rc, ref = O.pinocchio_prove(q, bytes(bad), bytes(pk.g2), cs.mid, frs(w), *(P.fr_to_bytes(x) for x in d))
+            assert rc == 0
+            want.append(ref)
+        assert want[0] != exp[0]
+        run(prover, want, "vav with an identity of its own")
+        prover.close()

@@ -61,6 +61,14 @@ struct MsmWorkspace {
     uint32_t red_chunk = 0;
 };
 
+static inline dim3 grid_for(uint64_t n, unsigned threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
+
+// ---- the counting sort's geometry (msm_sort.hip), shared with the workspace sizing of msm.hip
+static constexpr uint32_t MAX_SORT_JOBS = 4;          // MSMs over the same bases per chain of sort launches (blockIdx.y = job)
+static constexpr uint32_t SORT_MAX_BUCKETS = 32768;   // buckets whose whole histogram fits one workgroup's LDS (128 KiB): the single-level LDS sort
+static constexpr uint32_t SORT_FEW_BINS = 512;        // coarse bins of the two-level sort's first level (2 KiB of LDS)
+static constexpr uint32_t SORT_MAX_FINE = 4096;       // fine buckets one workgroup of the second level ranks in LDS
+
 uint32_t msm_auto_window(uint64_t n, bool precomp);
 // check_subgroup: also require [r] P = O of every point (proving keys: the reference's of_bytes_exn raises otherwise, curve.ml:199-212)
 int msm_bases_from_bytes(MsmBases& b, Curve curve, const uint8_t* host_bytes, uint64_t n, uint32_t c, bool precomp, hipStream_t s, bool check_subgroup = false);
@@ -80,6 +88,12 @@ int msm_run(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, void* d_r
 int msm_sort_accumulate(const MsmBases& b, MsmWorkspace& w, const void* d_scalars, hipStream_t s);
 // ... and for up to 4 MSMs over the same bases (different scalar vectors) as one chain of launches
 int msm_sort_accumulate_many(const MsmBases& b, MsmWorkspace* const* ws, const void* const* d_scalars, uint32_t count, hipStream_t s);
+// its two halves: the sort alone (msm_sort.hip), and the accumulation over sorted references -- ws[i]'s own or those of from[i], a workspace of ANOTHER
+// base set with the same geometry (points, window plan, identity flags) that sorted the same scalar vector
+int msm_sort_launch(const MsmBases& b, MsmWorkspace* const* ws, const void* const* d_scalars, uint32_t count, hipStream_t s);
+int msm_accumulate_sorted(const MsmBases& b, MsmWorkspace* const* ws, MsmWorkspace* const* from, uint32_t count, hipStream_t s);
+// may product `b` read the sort of a product over `a` with the same scalars?  (same curve-independent geometry and the same identity flags, compared on the device)
+int msm_bases_same_geometry(const MsmBases& a, const MsmBases& b, bool* same, hipStream_t s);
 int msm_reduce(const MsmBases& b, MsmWorkspace* const* ws, void* const* outs, uint32_t count, hipStream_t s);
 // the same for n1 products in G1 and n2 in G2 together (one window plan): one chain of launches for both curves
 int msm_reduce_mixed(const MsmBases* b1, MsmWorkspace* const* ws1, void* const* outs1, uint32_t n1,

@@ -16,7 +16,6 @@
 
 namespace zk {
 
-static inline dim3 grid_for(uint64_t n, unsigned threads) { return dim3((unsigned)((n + threads - 1) / threads)); }
 
 // A run cut by chunk borders left one partial sum per chunk.  Usually that is a handful per bucket
 // (one lane adds them); a bucket that swallowed a large share of the digits (boolean-heavy witnesses,

@@ -74,6 +74,10 @@ struct PinKey {
     DevBuf mid_idx, wit_resident;
     bool have_witness = false;
     bool lagrange = false;              // pool 5 holds [lambda_t(s)] (n-1) | [Z(s)] | [1] | v_all | w_all instead of si (n+1) | v_all | w_all
+    // One sort per distinct scalar vector (round 5): vv|vt and vav|vavt carry (c_mid | dv), yy|yt and yay|yayt (c_mid | dy), ww|wt and waw|wawt (c_mid | dw)
+    // (pinocchio.ml:438-447,489-498).  share1[i] / share2[i] = the pool whose sorted references pool i's bucket accumulation reads, -1 = its own: set at
+    // upload when the two base sets have the same geometry AND the same identity flags (msm_bases_same_geometry; v_k = 0 makes both of a pair the identity).
+    int share1[PIN_G1] = {-1, -1, -1, -1, -1, -1}, share2[PIN_G2] = {-1, -1};
     bool compact = false;               // pool 5 without v_all | w_all: si (n+1), or derived [lambda_t(s)] (n-1) | [Z(s)] | [1] | [s^(n-1)]  (header comment)
     DevBuf pw;                          // compact + derived: (n + t)^(n-1), t < n - 1
     std::unique_ptr<PinSlot> slots[PIN_MAX_SLOTS];
@@ -156,6 +160,7 @@ __global__ void k_pinocchio_scalars(PinScalPtrs out, PinHArgs ha, const uint32_t
         if (is_mid) c = fe_load<FrParams>(wit_mont + 8 * (uint64_t)mid_idx[i]);
         const uint64_t e = i - n_mid;      // index among the appended single points
         auto put = [&](uint32_t* dst, uint32_t extras, const Fr& e0, const Fr& e1, const Fr& e2) {
+            if (!dst) return;                                    // a pool that reads another pool's sort (PinKey::share1 / share2)
             if (is_mid) fe_store<FrParams>(dst + 8 * i, fe_from_mont(c));
             else if (e < extras) fe_store<FrParams>(dst + 8 * i, fe_from_mont(e == 0 ? e0 : (e == 1 ? e1 : e2)));
         };
@@ -297,6 +302,18 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     };
     ZKCHK(pool2(0, WW, ONES2));
     ZKCHK(pool2(1, WAW, ONES2 + 192));
+    {
+        const char* e = ::zk::opt("ZK_PIN_SHARED_SORT");          // 0: every product sorts for itself (A/B, tests)
+        if (!(e && atoi(e) == 0)) {
+            bool same = false;
+            ZKCHK(msm_bases_same_geometry(k.g1[0], k.g1[2], &same, c.stream));
+            if (same) k.share1[2] = 0;
+            ZKCHK(msm_bases_same_geometry(k.g1[1], k.g1[3], &same, c.stream));
+            if (same) k.share1[3] = 1;
+            ZKCHK(msm_bases_same_geometry(k.g2[0], k.g2[1], &same, c.stream));
+            if (same) k.share2[1] = 0;
+        }
+    }
     ZKCHK(k.mid_idx.alloc(4 * (nm ? nm : 1)));
     if (nm) HIPCHK(hipMemcpyAsync(k.mid_idx.p, mids.data(), 4 * nm, hipMemcpyHostToDevice, c.stream));
     ZKCHK(k.wit_resident.alloc(32 * (size_t)m));
@@ -459,8 +476,8 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     if (k.lagrange) ZKCHK(frstage_eval_lagrange(k.fr, sl.fs, wit, s0));
     else ZKCHK(frstage_eval(k.fr, sl.fs, wit, s0));
     PinScalPtrs ptrs;
-    for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = sl.scal1[i].as<uint32_t>();
-    for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = sl.scal2[i].as<uint32_t>();
+    for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = k.share1[i] < 0 ? sl.scal1[i].as<uint32_t>() : nullptr;
+    for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = k.share2[i] < 0 ? sl.scal2[i].as<uint32_t>() : nullptr;
     const uint64_t ph = pin_h_points(k.n, k.m, k.lagrange, k.compact);
     PinHArgs ha{};
     ha.h = sl.fs.h.as<uint32_t>(); ha.z = k.fr.z.as<uint32_t>();
@@ -487,8 +504,17 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     // window plan go out as ONE mixed G1 / G2 chain of launches (from 2^16 constraints up that is the whole group); one to-bytes launch.
     // G1 products [lo1, hi1), G2 products [lo2, hi2).
     auto group = [&](int lo1, int hi1, int lo2, int hi2, hipStream_t st) -> int {
-        for (int i = lo2; i < hi2; i++) ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], sl.scal2[i].p, st));
-        for (int i = lo1; i < hi1; i++) ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], sl.scal1[i].p, st));
+        // a pool whose scalar vector another pool of the group has sorted reads that sort (the source has the lower index: it ran first on this stream)
+        for (int i = lo2; i < hi2; i++) {
+            const int f = k.share2[i];
+            if (f >= lo2 && f < i) { MsmWorkspace *w1[1] = {&sl.ws2[i]}, *f1[1] = {&sl.ws2[f]}; ZKCHK(msm_accumulate_sorted(k.g2[i], w1, f1, 1, st)); }
+            else ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], f < 0 ? sl.scal2[i].p : sl.scal2[f].p, st));
+        }
+        for (int i = lo1; i < hi1; i++) {
+            const int f = k.share1[i];
+            if (f >= lo1 && f < i) { MsmWorkspace *w1[1] = {&sl.ws1[i]}, *f1[1] = {&sl.ws1[f]}; ZKCHK(msm_accumulate_sorted(k.g1[i], w1, f1, 1, st)); }
+            else ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], f < 0 ? sl.scal1[i].p : sl.scal1[f].p, st));
+        }
         bool done1[PIN_G1] = {}, done2[PIN_G2] = {};
         for (;;) {
             int lead_c = -1, lead_nw = -1;

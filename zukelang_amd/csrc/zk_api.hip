@@ -51,6 +51,7 @@ static const char* const PUBLIC_OPTIONS[] = {
     "ZK_TAIL_SLOTS", "ZK_TAIL_FIXUP_SLOTS", "ZK_FIXUP_BY_CHUNK", "ZK_DS_WIDE_GROUP", "ZK_RED_WAVES",
     "ZK_ACC_G1_GLDS", "ZK_ACC_G1_MMADD", "ZK_ACC_G2_INLINE", "ZK_MSM_BA_CURVES", "ZK_MSM_BA_ROUNDS", "ZK_MSM_API_PRECOMP",
     "ZK_DERIVE_SIDE_BY_SIDE", "ZK_FR_RNS",
+    "ZK_PIN_SHARED_SORT",       // 0: every Pinocchio product sorts its own scalar vector (default: vv / vav, yy / yay, ww / waw share one sort each)
     "ZK_PIN_COMPACT_H",         // 0: Pinocchio keys uploaded afterwards keep v_all | w_all in the h pool (pinocchio.hip: the compact h pool is the default)
 };
 struct OptionTable {
