@@ -404,7 +404,7 @@ int frstage_init(FrStage& f, uint32_t n, uint32_t m, const zk_csr* L, const zk_c
     const uint32_t n2 = f.n2, S = f.S;
     // round 4: convolutions through the residue number system where the transforms fit it (rns_ntt.cuh) -- an OPTION (ZK_FR_RNS=1 when the key is
     // uploaded: the tables and the residue arrays of the slots cost 72 bytes per element; measured slower than the Fr transforms in its present form,
-    // DESIGN.md 9b), kept under parity by the GPU suite.  The levels of the fused LDS kernel keep the Fr transform.
+    // DESIGN.md A.2), kept under parity by the GPU suite.  The levels of the fused LDS kernel keep the Fr transform.
     f.rns_ok = f.log_S <= RNS_MAX_LOG && rns_enabled();
     f.rns_first_level = (f.log_n2 < (uint32_t)NTT_LOG_T ? f.log_n2 : (uint32_t)NTT_LOG_T) + 1;
     if (f.rns_ok) {

@@ -160,7 +160,7 @@ template <class F> __global__ void k_ident_flags(uint8_t* flags, const uint8_t* 
 
 // acc[i] = sum_j parts[j * npoints + i] on dense XYZZ points: the sum of the ranks' / devices' partial sums of a proof.  One lane per point in G1, a lane PAIR
 // in G2 (F = Fp2H), additions expanded in place on the lane's registers: round 3's form (a whole Fp2 point per lane through the out-of-line addition)
-// carried 3 KiB of private memory per lane -- 1.6 GiB of scratch reserved on every queue the kernel was dispatched on.
+// carried 3 KiB of private memory per lane -- 1.6 GiB of scratch reserved on every queue the kernel was dispatched on (DESIGN A.2).
 template <class F> __global__ __launch_bounds__(64) void k_xyzz_sum_columns(uint8_t* out, const uint8_t* parts, uint32_t count, uint32_t npoints) {
     constexpr int XB = FieldOps<F>::WORDS * 16;          // dense XYZZ bytes of one point: 192 (G1) / 384 (G2: FieldOps<Fp2H> keeps Fp2's memory layout)
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / RawLayout<F>::LANES;
