@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel summary of a rocprofv3 --pmc collection (the *_counter_collection.csv of one pass).
 
-usage: pmc_summary.py <counter_collection.csv> [--proofs N | --steady KERNEL] [--json out.json]
+usage: pmc_summary.py <counter_collection.csv> [--proofs N | --steady KERNEL [--steady-skip K]] [--json out.json]
 
 --steady KERNEL: count only dispatches from the first dispatch of KERNEL on (the first kernel of the first proof, e.g.
 k_fr_to_mont_flag2: key set-up launches the same NTT kernels and would blur the per-proof figures) and take the number of
@@ -35,7 +35,11 @@ def main():
     with open(path, newline="") as f:
         rows = sorted(csv.DictReader(f), key=lambda r: int(r["Dispatch_Id"]))
     if steady:
-        first = next(i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == steady)
+        # --steady-skip K: the first K dispatches of KERNEL belong to key set-up (Pinocchio's upload runs the Fr stage once for its consistency check)
+        skip = int(args[args.index("--steady-skip") + 1]) if "--steady-skip" in args else 0
+        counters0 = {r["Counter_Name"] for r in rows}
+        hits = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == steady]
+        first = hits[skip * max(1, len(counters0))]
         rows = rows[first:]
         counters = {r["Counter_Name"] for r in rows}
         proofs = sum(1 for r in rows if short(r["Kernel_Name"]) == steady) // max(1, len(counters))
