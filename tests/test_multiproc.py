@@ -33,7 +33,7 @@ def test_point_sharded_sum_is_exact_gloo_cpu(world, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n", [(2, 256), (3, 1000), (4, 512), (2, 1 << 17)])      # the last: a realistic slice (2^16 per rank, LDS sort path, c = 16)
+@pytest.mark.parametrize("world,n", [(2, 256), (3, 1000), (4, 512), (2, 1 << 16)])      # the last: a realistic slice (1.5 * 2^16 G1 points per rank: the two-level LDS sort, c = 16; 2^17 ran here until round 5: 31 s)
 def test_point_sharded_prove_gpu(world, n):
     _run("gpu", world, n)
 
