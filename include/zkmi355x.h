@@ -269,7 +269,9 @@ int zk_groth16_combine_device(const void* d_partials /* device */, size_t stride
  * key's own powers (<v_all, rho> = <si, coefficients of sum_k rho_k v_k> for a pseudo-random rho, likewise w_all: true of every key
  * KeyGen.generate makes, :104-109,140-147) and then lets the two terms ride on si: the COMPACT h pool, n + 1 points instead of n + 1 + 2 m, same
  * proof bytes.  A key that fails the check, or any key under zk_set_option("ZK_PIN_COMPACT_H", "0"), keeps the full pool and is used point by
- * point as ZKCompute.f uses it. */
+ * point as ZKCompute.f uses it.  Products that carry the SAME scalar vector -- vv|vt and vav|vavt, yy|yt and yay|yayt, ww|wt and waw|wawt (:438-447,
+ * 489-498) -- share one counting sort of it when their base sets have the same identity pattern (true of generated keys; decided per key at upload;
+ * "ZK_PIN_SHARED_SORT" = "0" switches it off). */
 int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O,
                            const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
                            const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle);
