@@ -140,12 +140,28 @@ while time.time() < t_end:
     n_g16 += 1
     # ---- every fourth round: Pinocchio ZK prove at a random size against the trapdoor evaluation, then the product's verifier
     if n_g16 % 4 == 0:
-        n = 2 * rnd.randrange(1, 400)
-        cs, w = RC.iterated_cubic(n, rnd.randrange(1, P.R))
+        if rnd.random() < 0.5:
+            n = 2 * rnd.randrange(1, 400)
+            cs, w = RC.iterated_cubic(n, rnd.randrange(1, P.R))
+        else:          # round 5: the general family too (multi-term rows, unused variables = identity key points, special witness values, with / without ONE)
+            n = rnd.randrange(1, 300)
+            hi = rnd.choice([1, 2, 5, 9])
+            cs, w = RC.random_r1cs(n, rnd.randrange(hi + 2, hi + 2 + 2 * n), rnd.randrange(1 << 30), nnz=(1, hi), one=rnd.random() < 0.7)
         tox = [rnd.randrange(1, P.R) for _ in range(11)]
         it = iter(tox)
         pk, vk = PIN.ZK.keygen(lambda: next(it), cs)
-        prover = PIN.ZK(cs, pk)
+        # round 5: the compact h pool and the shared sorts are the default; every third case switches one of them off, every fifth runs the Fr stage through the RNS
+        opts = {"ZK_PIN_COMPACT_H": "0" if n_pin % 3 == 1 else None, "ZK_PIN_SHARED_SORT": "0" if n_pin % 3 == 2 else None}
+        for k_, v_ in opts.items():
+            _lib.check(_lib.lib().zk_set_option(k_.encode(), None if v_ is None else v_.encode()))
+        if n_pin % 5 == 4:
+            os.environ["ZK_FR_RNS"] = "1"
+        try:
+            prover = PIN.ZK(cs, pk)
+        finally:
+            for k_ in opts:
+                _lib.check(_lib.lib().zk_set_option(k_.encode(), None))
+        assert prover.pool_size(5) == (cs.n + 1 if opts["ZK_PIN_COMPACT_H"] is None else cs.n + 1 + 2 * cs.m), ("h pool form", n)
         proof = prover.prove(lambda: next(it), w)
         csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
         exp = O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, b"".join(frb(x) for x in w), b"".join(frb(x) for x in tox[:8]), *(frb(x) for x in tox[8:]))
@@ -157,6 +173,7 @@ while time.time() < t_end:
         if n <= 40:
             assert PIN.ZK.verify([w[k] for k in range(cs.m) if not cs.mid[k]], vk, proof)
         prover.close()
+        os.environ.pop("ZK_FR_RNS", None)          # set for every fifth case from the upload to the last proof (the switch is read per call under ZK_TEST_FORMS)
         n_pin += 1
     if (n_msm % 10) == 0:
         print("soak: %d MSM cases, %d Groth16 cases (%d multi-device, %d RNS), %d Pinocchio cases ok" % (n_msm, n_g16, n_multi, n_rns, n_pin), flush=True)
