@@ -6,11 +6,14 @@
  *   NonZK.prove (:536-538, Compute.f :210-248)    the same call with dv = dw = dy = 0
  *   verify  (Verify.f :254-420)    zk_pinocchio_verify on the flattened verification key; a wrong public input is rejected
  *   a long-lived key: zk_pinocchio_pk_derive_lagrange, after which the same calls give the same bytes
+ * With arguments -- HIP device indices, e.g. `c_pinocchio 0 1` -- the SAME calls run on a multi-device key: zk_set_device_list cuts every pool of the
+ * key over the listed devices behind the one handle (an index may repeat: several shards on one card), and every byte stays the same.
  * on the README circuit `x*x*x + x + 3` (README.md:49).  Every output is compared with the first-principles bytes of
  * examples/readme_pinocchio_fixture.h (tests/golden/readme_pinocchio_key.json, written by tests/golden/make_readme_pinocchio.py from Python
  * integers).  Needs a GPU; tests/test_golden_key.py builds it with -std=c99 -pedantic -Werror and runs it on the GPU box. */
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "readme_pinocchio_fixture.h"
@@ -30,7 +33,7 @@ enum { N = 3, M = 5, N_MID = 3, N_IO = 2, PK1 = 5 * N_MID + (N + 1) + 2 * M + 7,
 
 static void fr_small(uint8_t out[32], uint32_t v) { memset(out, 0, 32); out[0] = (uint8_t)v; }
 
-int main(void) {
+int main(int argc, char** argv) {
     /* gates (Gate.compare order): c4 = input*input ; c5 = c4*input ; v6 = (c5 + input + 3 ONE) * (1 ONE); variables ONE, c4, c5, input, v6 */
     static const uint32_t l_ptr[4] = {0, 1, 2, 5}, l_col[5] = {3, 1, 0, 2, 3};
     static const uint32_t r_ptr[4] = {0, 1, 2, 3}, r_col[3] = {3, 3, 0};
@@ -48,7 +51,13 @@ int main(void) {
     R.row_ptr = r_ptr; R.col = r_col; R.val = r_val;
     O.row_ptr = o_ptr; O.col = o_col; O.val = o_val;
     memset(zero, 0, sizeof zero);
-    CHECK(zk_init(0));
+    if (argc > 1) {          /* N GPUs behind the one handle: the only line a host adds */
+        int32_t devs[16];
+        uint32_t nd = 0;
+        for (i = 1; i < argc && nd < 16; i++) devs[nd++] = (int32_t)atoi(argv[i]);
+        CHECK(zk_set_device_list(devs, nd));
+    } else
+        CHECK(zk_init(0));
 
     /* keygen: exponents -> points, evaluation key first, then the verification key's points (its `one` is the generator, not a product) */
     CHECK(zk_g1_of_fr(PFIX_PK_EXP_G1, sizeof PFIX_PK_EXP_G1 / 32, g1));
@@ -96,6 +105,6 @@ int main(void) {
     CHECK(zk_pinocchio_prove_wait(h, 1, proof));
     SAME(proof, PFIX_PROOF_NONZK, "NonZK proof (slot 1)");
     CHECK(zk_pinocchio_pk_free(h));
-    printf("c-pinocchio ok: keygen, ZK / NonZK proofs (uploaded and derived key, blocking and pipelined) and verify equal the first-principles fixture\n");
+    printf("c-pinocchio ok (%d device entr%s): keygen, ZK / NonZK proofs (uploaded and derived key, blocking and pipelined) and verify equal the first-principles fixture\n", argc > 1 ? argc - 1 : 1, argc > 2 ? "ies" : "y");
     return 0;
 }

@@ -63,7 +63,12 @@ int zk_shutdown(void);
  *     its slices of the three scalar vectors out of the owner's memory (hipMemcpyPeerAsync over xGMI), runs its part of the three multi-scalar
  *     products and sends 768 bytes of partial sums to the first device, which adds them and emits the proof.  Nothing blocks before _prove_wait.
  *   - zk_groth16_pk_derive_lagrange derives one of the three independent sets per device (devices 0, 1, 2 of the list) and installs every shard.
- *   - everything else (zk_msm_*, zk_fr_*, keygen helpers, Pinocchio, the explicit one-process-per-GPU shard API below) runs on the list's FIRST
+ *   - zk_pinocchio_pk_upload likewise cuts every one of the key's eight pools in N slices behind ONE handle (round 5); zk_pinocchio_prove / _prove_async /
+ *     _prove_wait / _set_witness / _reserve_slots / _pk_derive_lagrange / _pool_points / _pk_free work on it as on a single-GPU key, same bytes: the Fr stage
+ *     and the eight scalar vectors once on the slot's owner device, every device its slices of the eight products (pinocchio.ml:438-505), 1 920 bytes of
+ *     partial sums to the first device, which adds them.  The consistency check behind the compact h pool and the derivation of the h bases run on the
+ *     first device.
+ *   - everything else (zk_msm_*, zk_fr_*, keygen helpers, verify, the explicit one-process-per-GPU shard API below) runs on the list's FIRST
  *     device; the shard API (zk_groth16_pk_upload_sharded, _prove_partial*, _scalars_async ...) refuses multi-device handles with ZK_ERR_ARG.
  * The one-process-per-GPU path (torch.distributed / RCCL, bench.py --gpus N) does not use the device list: every rank keeps its one-entry list. */
 int zk_set_devices(uint64_t mask);

@@ -146,7 +146,11 @@ def test_a_plain_c_host_runs_pinocchio_like_the_ocaml_shim(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "examples"),
                            os.path.join(root, "examples", "c_pinocchio.c"), "-o", exe, "-L" + libdir, "-lzkmi355x", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, timeout=300)
-    assert out.returncode == 0 and out.stdout.startswith(b"c-pinocchio ok"), (out.returncode, out.stdout, out.stderr)
+    assert out.returncode == 0 and out.stdout.startswith(b"c-pinocchio ok (1 device entry)"), (out.returncode, out.stdout, out.stderr)
+    # the same binary with a device list (round 5: Pinocchio keys shard over it too): the one card of the test box listed twice and three times
+    for devs in (["0", "0"], ["0", "0", "0"]):
+        out = subprocess.run([exe] + devs, capture_output=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith(b"c-pinocchio ok (%d device entries)" % len(devs)), (devs, out.returncode, out.stdout, out.stderr)
 
 
 def test_the_pinocchio_fixture_header_is_the_json():

@@ -180,3 +180,58 @@ def test_multi_device_key_error_paths(devices):
     again = prover.prove_rs(w, r, s)
     assert (again.a, again.b, again.c) == (good.a, good.b, good.c)
     prover.close()
+
+
+@pytest.mark.parametrize("devs,maker", [([0, 0], lambda: RC.readme_circuit(3)), ([0, 0, 0], lambda: RC.random_r1cs(1, 6, 76, nnz=(1, 2))), ([0, 0], lambda: RC.iterated_cubic(300, 0xA1)),
+                                        ([0, 0, 0], lambda: RC.random_r1cs(200, 150, 0xA2)), ([0, 0, 0, 0], lambda: RC.iterated_cubic(4096, 0xA3)),
+                                        ([0, 0], lambda: RC.iterated_cubic(1 << 16, 0xA4))])
+def test_multi_device_pinocchio_key_gives_the_single_device_bytes(devices, devs, maker):
+    """Round 5: Pinocchio behind a device list too (csrc/pinocchio.hip, PinGroup).  zk_pinocchio_pk_upload cuts every one of the eight pools in N slices,
+    a proof's Fr stage and scalar vectors run once on the slot's owner device, every device multiplies its slices and the first one adds the 1 920-byte
+    blocks of partial sums -- ZKCompute.f's products (pinocchio.ml:438-505) are sums over key points, so the bytes cannot depend on the cut: they are
+    compared with the single-device prover's and the trapdoor oracle's, as uploaded and with the h bases derived (on the first device, then installed
+    slice by slice), blocking and pipelined over slots with rotating owners; the handle presents the WHOLE pools.  Tiny circuits leave some devices with
+    EMPTY slices of some pools (the readme circuit has three mids; n = 1 has a two-point h pool)."""
+    from zukelang_amd import pinocchio as PIN
+    cs, w = maker()
+    L, R_, Oo = csrs(cs)
+    rng = seeded_rng(0x5EED0A00 + cs.n + len(devs))
+    tox = [rng() for _ in range(8)]
+    it = iter(tox)
+    pk, _vk = PIN.ZK.keygen(lambda: next(it), cs)
+    ds = [[rng() for _ in range(3)] for _ in range(4)] + [[0, 0, 0]]
+    exp = [O.pinocchio_prove_trapdoor(cs.n, cs.m, L, R_, Oo, cs.mid, frs(w), frs(tox), *(P.fr_to_bytes(x) for x in d)) for d in ds]
+    single = PIN.ZK(cs, pk)
+    assert single.prove_with(w, *ds[0]).to_bytes() == exp[0]
+    pools = [bytes(single.pool_points(i)) for i in range(8)]
+    single.derive_lagrange()
+    pool5_derived = bytes(single.pool_points(5))
+    single.close()
+
+    devs = physical(devs)
+    devices(devs)
+    prover = PIN.ZK(cs, pk)                                    # the SAME call: zk_pinocchio_pk_upload shards over the list behind one handle
+    assert prover.handle.value >= 0x7000000000
+    with pytest.raises(_lib.ZkError):                          # a live key pins the device list
+        _lib.set_device_list([0])
+    assert [bytes(prover.pool_points(i)) for i in range(8)] == pools
+    for stage in ("as uploaded", "derived"):
+        if stage == "derived":
+            prover.derive_lagrange()
+            prover.derive_lagrange()                           # idempotent
+            assert bytes(prover.pool_points(5)) == pool5_derived
+            assert [bytes(prover.pool_points(i)) for i in range(8) if i != 5] == [p for i, p in enumerate(pools) if i != 5]
+        for d, e in zip(ds[:2] + ds[4:], exp[:2] + exp[4:]):
+            assert prover.prove_with(w, *d).to_bytes() == e, (stage, "blocking")
+        prover.set_witness(w)
+        for slot, d in enumerate(ds):                          # five proofs in flight: owners 0, 1, ..., wrapping round the list
+            prover.prove_async(*d, slot)
+        for slot in range(len(ds)):
+            assert prover.prove_wait(slot).to_bytes() == exp[slot], (stage, "slot %d" % slot)
+    if cs.n > 1 and cs.m == cs.n + 2:                          # the iterated-cubic family (and the README circuit): variable 2 sits in a gate for sure
+        w_bad = list(w)
+        w_bad[2] = (w_bad[2] + 1) % RC.FR_MODULUS
+        with pytest.raises(AssertionError):                    # QAP.ml:134, from the owner device's Fr stage
+            prover.prove_with(w_bad, *ds[0])
+        assert prover.prove_with(w, *ds[1]).to_bytes() == exp[1]      # the slot is usable afterwards
+    prover.close()

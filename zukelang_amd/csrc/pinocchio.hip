@@ -69,6 +69,11 @@ static bool key_subgroup_check() {          // read per key (set-up path); witho
 }
 struct PinKey {
     uint32_t n = 0, m = 0, n_mid = 0;
+    // A whole key is shard 0 of 1.  A shard of a multi-device key (PinGroup below) holds the points [lo, hi) of every pool -- the pools are cut in `world`
+    // equal slices -- with its own window tables; full = the pool's length.  An EMPTY slice (a pool shorter than the device list) has no base set at all.
+    uint32_t rank = 0, world = 1;
+    uint64_t full1[PIN_G1] = {}, lo1[PIN_G1] = {}, hi1[PIN_G1] = {};
+    uint64_t full2[PIN_G2] = {}, lo2[PIN_G2] = {}, hi2[PIN_G2] = {};
     FrStage fr;
     MsmBases g1[PIN_G1], g2[PIN_G2];
     DevBuf mid_idx, wit_resident;
@@ -85,9 +90,6 @@ struct PinKey {
 int derive_shifted_bases_g1(const FrStage& f, const uint8_t* d_si, uint8_t* d_out, hipStream_t s);   // lagrange_derive.hip
 static std::map<uint64_t, std::unique_ptr<PinKey>>& g_pin = *new std::map<uint64_t, std::unique_ptr<PinKey>>;   // never destroyed (see ntt.hip)
 static uint64_t g_pin_next = 0x5000000001ull;
-static void pin_release() { g_pin.clear(); }
-uint64_t pinocchio_live_handles() { return g_pin.size(); }
-static CleanupRegistrar g_pin_cleanup(pin_release);
 
 static inline dim3 g1d(uint64_t n, unsigned t = 256) { return dim3((unsigned)((n + t - 1) / t)); }
 
@@ -243,20 +245,21 @@ static int pin_lookup(uint64_t handle, PinKey** out) {
     *out = it->second.get();
     return ZK_OK;
 }
+static inline void pin_slice(uint64_t full, uint32_t rank, uint32_t world, uint64_t* lo, uint64_t* hi) {
+    *lo = full * rank / world;
+    *hi = full * (rank + 1) / world;
+}
 
-}  // namespace zk
-
-using namespace zk;
-extern "C" {
-
-int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
-                           const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
-    if (!handle || !mid || !pk_g1 || !pk_g2) ZK_FAIL(ZK_ERR_ARG, "pinocchio pk_upload: null argument");
-    ZKCHK(ensure_init());
+// Builds a key -- whole (rank 0 of world 1) or rank's shard -- on the CURRENT virtual device; nothing is registered under a handle.
+// compact_in: -1 = decide here (the upload's consistency check of v_all / w_all against si, header comment: needs the WHOLE h pool, so rank 0 of a
+// group runs it and hands its verdict to the other shards), 0 / 1 = the verdict.
+static int pin_key_build(std::unique_ptr<PinKey>& out, uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
+                         const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint32_t rank, uint32_t world, int compact_in) {
+    if (!mid || !pk_g1 || !pk_g2) ZK_FAIL(ZK_ERR_ARG, "pinocchio pk_upload: null argument");
     Ctx& c = ctx();
     auto key = std::make_unique<PinKey>();
     PinKey& k = *key;
-    k.n = n; k.m = m;
+    k.n = n; k.m = m; k.rank = rank; k.world = world;
     std::vector<uint32_t> mids;
     for (uint32_t i = 0; i < m; i++)
         if (mid[i]) mids.push_back(i);
@@ -270,9 +273,20 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
                   *SI = BV + 96 * nm, *VALL = SI + 96 * (uint64_t)(n + 1), *WALL = VALL + 96 * (uint64_t)m, *ONES = WALL + 96 * (uint64_t)m;
     const uint8_t *WW = pk_g2, *WAW = WW + 192 * nm, *ONES2 = WAW + 192 * nm + 192 * (uint64_t)(n + 1);
     std::vector<uint8_t> buf;
+    // pool idx = base[0 .. cnt) | extras, of which this shard keeps [lo, hi)
     auto pool1 = [&](int idx, const uint8_t* base, uint64_t cnt, std::initializer_list<const uint8_t*> extras) -> int {
-        buf.assign(base, base + 96 * cnt);
-        for (auto e : extras) buf.insert(buf.end(), e, e + 96);
+        const uint64_t full = cnt + extras.size();
+        k.full1[idx] = full;
+        pin_slice(full, rank, world, &k.lo1[idx], &k.hi1[idx]);
+        const uint64_t lo = k.lo1[idx], hi = k.hi1[idx];
+        if (hi == lo) return ZK_OK;
+        buf.clear();
+        if (lo < cnt) buf.assign(base + 96 * lo, base + 96 * (hi < cnt ? hi : cnt));
+        uint64_t e = cnt;
+        for (auto x : extras) {
+            if (e >= lo && e < hi) buf.insert(buf.end(), x, x + 96);
+            e++;
+        }
         return msm_bases_from_bytes(k.g1[idx], CURVE_G1, buf.data(), buf.size() / 96, 0, true, c.stream, key_subgroup_check());
     };
     ZKCHK(pool1(0, VV, nm, {ONES + 96 * 0}));
@@ -281,113 +295,118 @@ int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr
     ZKCHK(pool1(3, YAY, nm, {ONES + 96 * 3}));
     ZKCHK(pool1(4, BV, nm, {ONES + 96 * 4, ONES + 96 * 5, ONES + 96 * 6}));
     const uint64_t ph_full = (uint64_t)n + 1 + 2 * (uint64_t)m;          // si | v_all | w_all are contiguous in the key
-    if (pin_compact_wanted()) {
+    int compact = compact_in;
+    if (compact < 0) compact = 0;
+    if (compact_in < 0 && pin_compact_wanted()) {
         // every point is decoded and checked as before (of_bytes_exn); the pool then keeps v_all | w_all only if they fail the check of the header comment
         MsmBases full;
         ZKCHK(msm_bases_from_bytes(full, CURVE_G1, SI, ph_full, 0, false, c.stream, key_subgroup_check()));
         bool ok = false;
         ZKCHK(pin_compact_check(k.fr, full, n, m, &ok, c.stream));
-        const uint64_t keep = ok ? (uint64_t)n + 1 : ph_full;
-        DevBuf dense;
-        ZKCHK(dense.alloc(96 * keep));
-        ZKCHK(msm_bases_dense(full, 0, keep, dense.p, c.stream));
-        ZKCHK(msm_bases_from_device_affine(k.g1[5], CURVE_G1, dense.p, keep, 0, true, c.stream, full.in_subgroup));
-        HIPCHK(hipStreamSynchronize(c.stream));          // `dense` is read by the table build
-        k.compact = ok;
-    } else ZKCHK(pool1(5, SI, ph_full, {}));
+        compact = ok ? 1 : 0;
+    }
+    k.compact = compact != 0;
+    ZKCHK(pool1(5, SI, k.compact ? (uint64_t)n + 1 : ph_full, {}));          // this shard's slice decodes and checks its own points (rank 0 has seen all of them when it ran the check)
     auto pool2 = [&](int idx, const uint8_t* base, const uint8_t* extra) -> int {
-        buf.assign(base, base + 192 * nm);
-        buf.insert(buf.end(), extra, extra + 192);
-        return msm_bases_from_bytes(k.g2[idx], CURVE_G2, buf.data(), nm + 1, 0, true, c.stream, key_subgroup_check());
+        k.full2[idx] = nm + 1;
+        pin_slice(nm + 1, rank, world, &k.lo2[idx], &k.hi2[idx]);
+        const uint64_t lo = k.lo2[idx], hi = k.hi2[idx];
+        if (hi == lo) return ZK_OK;
+        buf.clear();
+        if (lo < nm) buf.assign(base + 192 * lo, base + 192 * (hi < nm ? hi : nm));
+        if (hi == nm + 1) buf.insert(buf.end(), extra, extra + 192);
+        return msm_bases_from_bytes(k.g2[idx], CURVE_G2, buf.data(), buf.size() / 192, 0, true, c.stream, key_subgroup_check());
     };
     ZKCHK(pool2(0, WW, ONES2));
     ZKCHK(pool2(1, WAW, ONES2 + 192));
     {
         const char* e = ::zk::opt("ZK_PIN_SHARED_SORT");          // 0: every product sorts for itself (A/B, tests)
         if (!(e && atoi(e) == 0)) {
-            bool same = false;
-            ZKCHK(msm_bases_same_geometry(k.g1[0], k.g1[2], &same, c.stream));
-            if (same) k.share1[2] = 0;
-            ZKCHK(msm_bases_same_geometry(k.g1[1], k.g1[3], &same, c.stream));
-            if (same) k.share1[3] = 1;
-            ZKCHK(msm_bases_same_geometry(k.g2[0], k.g2[1], &same, c.stream));
-            if (same) k.share2[1] = 0;
+            auto try_share = [&](const MsmBases& a, const MsmBases& b, int* slot, int from) -> int {
+                if (!a.n || !b.n) return ZK_OK;
+                bool same = false;
+                ZKCHK(msm_bases_same_geometry(a, b, &same, c.stream));
+                if (same) *slot = from;
+                return ZK_OK;
+            };
+            ZKCHK(try_share(k.g1[0], k.g1[2], &k.share1[2], 0));
+            ZKCHK(try_share(k.g1[1], k.g1[3], &k.share1[3], 1));
+            ZKCHK(try_share(k.g2[0], k.g2[1], &k.share2[1], 0));
         }
     }
     ZKCHK(k.mid_idx.alloc(4 * (nm ? nm : 1)));
     if (nm) HIPCHK(hipMemcpyAsync(k.mid_idx.p, mids.data(), 4 * nm, hipMemcpyHostToDevice, c.stream));
     ZKCHK(k.wit_resident.alloc(32 * (size_t)m));
     HIPCHK(hipStreamSynchronize(c.stream));
-    *handle = g_pin_next++;
-    g_pin[*handle] = std::move(key);
+    out = std::move(key);
     return ZK_OK;
 }
-// The h pool of an uploaded key (si | v_all | w_all) rewritten for the VALUES of h: [lambda_t(s)]_1 derived from the powers si in the exponent
-// (lagrange_derive.hip: the transposed interpolation over the points n .. 2n-2), [Z(s)]_1 = <si, Z> once, [1] = si[0].  Same pool length,
-// same proofs; the per-proof basis conversion disappears (only h ever needed coefficients: v(s), w(s) come from the per-variable pools).
-int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
-    PinKey* kp;
-    ZKCHK(pin_lookup(handle, &kp));
-    PinKey& k = *kp;
-    if (k.lagrange) return ZK_OK;
-    for (uint32_t i = 0; i < PIN_MAX_SLOTS; i++)
-        if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: a proof is in flight on this key");
-    HIPCHK(hipDeviceSynchronize());
-    Ctx& c = ctx();
+
+// ---- the derivation of the h pool (zk_pinocchio_pk_derive_lagrange), in two halves so that a multi-device key can run the first on one device
+// d_old: the WHOLE h pool as uploaded, dense affine (si | v_all | w_all, or si alone when compact), on the current device.
+// pool_out: the whole derived pool, dense affine:  [lambda_t(s)] (n-1) | [Z(s)] | [1] | [s^(n-1)]   resp.   ... | [1] | v_all | w_all
+static int pin_derive_pool(const PinKey& k, const uint8_t* d_old, DevBuf& pool_out, hipStream_t s) {
     const uint32_t n = k.n;
-    const uint64_t ph_old = pin_h_points(n, k.m, false, k.compact), ph = pin_h_points(n, k.m, true, k.compact);
-    MsmBases& old = k.g1[5];
-    if (old.n != ph_old) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: unexpected pool length");
-    DevBuf pool, old_dense;
-    ZKCHK(pool.alloc(96 * ph));
-    ZKCHK(old_dense.alloc(96 * ph_old));
-    ZKCHK(msm_bases_dense(old, 0, ph_old, old_dense.p, c.stream));            // window 0 = the pool as uploaded, back in the dense affine format
-    const uint8_t* si = old_dense.as<uint8_t>();
+    const uint64_t ph = pin_h_points(n, k.m, true, k.compact);
+    ZKCHK(pool_out.alloc(96 * ph));
+    uint8_t* pool = pool_out.as<uint8_t>();
+    const uint8_t* si = d_old;
     // [lambda_t(s)], t < n - 1
-    ZKCHK(derive_shifted_bases_g1(k.fr, si, pool.as<uint8_t>(), c.stream));
+    ZKCHK(derive_shifted_bases_g1(k.fr, si, pool, s));
     // [Z(s)] = sum_i Z_i [s^i]: one MSM over the n + 1 powers with the canonical coefficients of Z
     {
         MsmBases b;
         MsmWorkspace w;
         DevBuf zc, res, bytes, flag;
-        ZKCHK(msm_bases_from_device_affine(b, CURVE_G1, si, (uint64_t)n + 1, 0, false, c.stream));
+        ZKCHK(msm_bases_from_device_affine(b, CURVE_G1, si, (uint64_t)n + 1, 0, false, s));
         ZKCHK(msm_workspace_alloc(w, b));
         ZKCHK(zc.alloc(32 * ((size_t)n + 1)));
         ZKCHK(res.alloc(xyzz_bytes(CURVE_G1)));
         ZKCHK(bytes.alloc(96));
         ZKCHK(flag.alloc(4));
-        ZKCHK(fr_from_mont(zc.p, k.fr.z.p, (uint64_t)n + 1, c.stream));
-        ZKCHK(msm_run(b, w, zc.p, res.p, c.stream));
-        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res.p, 1, bytes.p, c.stream));
-        HIPCHK(hipMemsetAsync(flag.p, 0, 4, c.stream));
-        ZKCHK(points_bytes_to_affine(CURVE_G1, pool.as<uint8_t>() + 96 * (uint64_t)(n - 1), bytes.p, 1, flag.as<int>(), c.stream));
-        HIPCHK(hipStreamSynchronize(c.stream));
+        ZKCHK(fr_from_mont(zc.p, k.fr.z.p, (uint64_t)n + 1, s));
+        ZKCHK(msm_run(b, w, zc.p, res.p, s));
+        ZKCHK(points_xyzz_to_bytes_dev(CURVE_G1, res.p, 1, bytes.p, s));
+        HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
+        ZKCHK(points_bytes_to_affine(CURVE_G1, pool + 96 * (uint64_t)(n - 1), bytes.p, 1, flag.as<int>(), s));
+        HIPCHK(hipStreamSynchronize(s));
     }
-    HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * (uint64_t)n, si, 96, hipMemcpyDeviceToDevice, c.stream));                                       // [1] = si[0]
-    if (k.compact) {
-        HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * ((uint64_t)n + 1), si + 96 * (uint64_t)(n - 1), 96, hipMemcpyDeviceToDevice, c.stream));    // [s^(n-1)]
-        ZKCHK(k.pw.alloc(32 * (size_t)(n > 1 ? n - 1 : 1)));
-        ZKCHK(frstage_shifted_powers(k.pw.p, n, n - 1, n - 1, c.stream));
-    } else {
-        HIPCHK(hipMemcpyAsync(pool.as<uint8_t>() + 96 * ((uint64_t)n + 1), si + 96 * ((uint64_t)n + 1), 96 * 2 * (uint64_t)k.m, hipMemcpyDeviceToDevice, c.stream));   // v_all | w_all
-    }
+    HIPCHK(hipMemcpyAsync(pool + 96 * (uint64_t)n, si, 96, hipMemcpyDeviceToDevice, s));                                       // [1] = si[0]
+    if (k.compact) HIPCHK(hipMemcpyAsync(pool + 96 * ((uint64_t)n + 1), si + 96 * (uint64_t)(n - 1), 96, hipMemcpyDeviceToDevice, s));    // [s^(n-1)]
+    else HIPCHK(hipMemcpyAsync(pool + 96 * ((uint64_t)n + 1), si + 96 * ((uint64_t)n + 1), 96 * 2 * (uint64_t)k.m, hipMemcpyDeviceToDevice, s));   // v_all | w_all
+    HIPCHK(hipStreamSynchronize(s));
+    return ZK_OK;
+}
+// d_pool: the whole derived pool on the current device; the key takes its slice of it (own window tables), the Fr stage flips to the values of h
+static int pin_install_derived(PinKey& k, const uint8_t* d_pool, hipStream_t s) {
+    const uint32_t n = k.n;
+    const uint64_t ph = pin_h_points(n, k.m, true, k.compact);
+    const MsmBases& old = k.g1[5];
+    uint64_t lo, hi;
+    pin_slice(ph, k.rank, k.world, &lo, &hi);
     MsmBases nb;
-    ZKCHK(msm_bases_from_device_affine(nb, CURVE_G1, pool.p, ph, old.c, true, c.stream, old.in_subgroup));      // derived from the old pool's points: msm.cuh, msm_fold
-    ZKCHK(frstage_init_lagrange(k.fr, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
+    if (hi > lo) ZKCHK(msm_bases_from_device_affine(nb, CURVE_G1, d_pool + 96 * lo, hi - lo, old.n ? old.c : 0, true, s, old.n ? old.in_subgroup : key_subgroup_check()));   // derived from checked points: msm.cuh, msm_fold
+    if (k.compact) {
+        ZKCHK(k.pw.alloc(32 * (size_t)(n > 1 ? n - 1 : 1)));
+        ZKCHK(frstage_shifted_powers(k.pw.p, n, n - 1, n - 1, s));
+    }
+    ZKCHK(frstage_init_lagrange(k.fr, s));
+    HIPCHK(hipStreamSynchronize(s));
     k.g1[5] = std::move(nb);
+    k.full1[5] = ph; k.lo1[5] = lo; k.hi1[5] = hi;
     k.lagrange = true;
     for (uint32_t i = 0; i < PIN_MAX_SLOTS; i++) k.slots[i].reset();          // the h pool changed its length (compact) and the Fr scratch its form: slots are rebuilt on demand
     return ZK_OK;
 }
-int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t capacity_points, size_t* count) {
-    PinKey* kp;
-    ZKCHK(pin_lookup(handle, &kp));
-    if (pool < 0 || pool >= PIN_G1 + PIN_G2) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: pool 0..5 (G1) or 6..7 (G2)");
-    const MsmBases& b = pool < PIN_G1 ? kp->g1[pool] : kp->g2[pool - PIN_G1];
-    if (count) *count = b.n;
-    if (!out) return ZK_OK;
-    if (capacity_points < b.n) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: buffer too small");
+static int pin_check_idle(PinKey& k, const char* who) {
+    for (uint32_t i = 0; i < PIN_MAX_SLOTS; i++)
+        if (k.slots[i] && k.slots[i]->busy) ZK_FAIL(ZK_ERR_ARG, who);
+    return ZK_OK;
+}
+// this shard's slice of pool `pool` (0..5 G1, 6..7 G2) as uncompressed points at out (host)
+static int pin_slice_points(PinKey& k, int pool, uint8_t* out) {
+    const MsmBases& b = pool < PIN_G1 ? k.g1[pool] : k.g2[pool - PIN_G1];
+    if (!b.n) return ZK_OK;
     Ctx& c = ctx();
     DevBuf bytes, dense;
     ZKCHK(bytes.alloc(aff_bytes(b.curve) * b.n));
@@ -398,20 +417,15 @@ int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t cap
     HIPCHK(hipStreamSynchronize(c.stream));
     return ZK_OK;
 }
-int zk_pinocchio_pk_free(uint64_t handle) {
-    auto it = g_pin.find(handle);
-    if (it == g_pin.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Pinocchio key handle");
-    (void)hipDeviceSynchronize();
-    g_pin.erase(it);
-    return ZK_OK;
-}
+
 static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
     if (idx >= PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "pinocchio: slot index out of range (max 15 proofs in flight)");
     if (!k.slots[idx]) {
         auto sl = std::make_unique<PinSlot>();
         ZKCHK(frstage_scratch_alloc(k.fr, sl->fs));
-        for (int i = 0; i < PIN_G1; i++) { ZKCHK(msm_workspace_alloc(sl->ws1[i], k.g1[i])); ZKCHK(sl->scal1[i].alloc(32 * k.g1[i].n)); }
-        for (int i = 0; i < PIN_G2; i++) { ZKCHK(msm_workspace_alloc(sl->ws2[i], k.g2[i])); ZKCHK(sl->scal2[i].alloc(32 * k.g2[i].n)); }
+        // scalar vectors over the FULL pools (any shard may own a proof's Fr stage); workspaces for the shard's own base sets
+        for (int i = 0; i < PIN_G1; i++) { if (k.g1[i].n) ZKCHK(msm_workspace_alloc(sl->ws1[i], k.g1[i])); ZKCHK(sl->scal1[i].alloc(32 * k.full1[i])); }
+        for (int i = 0; i < PIN_G2; i++) { if (k.g2[i].n) ZKCHK(msm_workspace_alloc(sl->ws2[i], k.g2[i])); ZKCHK(sl->scal2[i].alloc(32 * k.full2[i])); }
         ZKCHK(sl->wit_raw.alloc(32 * (size_t)k.m));
         ZKCHK(sl->deltas.alloc(96));
         ZKCHK(sl->kappa.alloc(32 * (2 + 2 * (size_t)LEAD_BLOCKS)));
@@ -419,7 +433,7 @@ static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
         ZKCHK(sl->out_dev.alloc(960));
         HIPCHK(hipStreamCreateWithFlags(&sl->st, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&sl->done, hipEventDisableTiming));
-        if (idx == 0 && !::zk::opt("ZK_SERIAL_STREAMS")) {
+        if (idx == 0 && k.world == 1 && !::zk::opt("ZK_SERIAL_STREAMS")) {
             // the slot of the synchronous zk_pinocchio_prove: two more streams, used only while no other proof is in flight (groth16.hip, slot 0)
             HIPCHK(hipStreamCreateWithFlags(&sl->s1, hipStreamNonBlocking));
             HIPCHK(hipStreamCreateWithFlags(&sl->s2, hipStreamNonBlocking));
@@ -433,38 +447,10 @@ static int pin_slot_get(PinKey& k, uint32_t idx, PinSlot** out) {
     *out = k.slots[idx].get();
     return ZK_OK;
 }
-int zk_pinocchio_reserve_slots(uint64_t handle, uint32_t count) {
-    PinKey* kp;
-    ZKCHK(pin_lookup(handle, &kp));
-    if (count > PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_reserve_slots: at most 15 slots");
-    for (uint32_t i = 0; i < count; i++) {
-        PinSlot* sl;
-        ZKCHK(pin_slot_get(*kp, i, &sl));
-    }
-    return ZK_OK;
-}
-int zk_pinocchio_set_witness(uint64_t handle, const uint8_t* sol) {
-    PinKey* kp;
-    ZKCHK(pin_lookup(handle, &kp));
-    if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_set_witness: null");
-    Ctx& c = ctx();
-    (void)hipDeviceSynchronize();      // no proof may still be reading the previous witness
-    HIPCHK(hipMemcpyAsync(kp->wit_resident.p, sol, 32 * (size_t)kp->m, hipMemcpyHostToDevice, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
-    kp->have_witness = true;
-    return ZK_OK;
-}
-// Enqueues one proof on the slot's stream and returns without waiting:
-// Fr stage -> the eight scalar vectors -> eight MSMs -> affine bytes -> pinned host buffer.
-int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32], const uint8_t dy[32], uint32_t slot) {
-    PinKey* kp;
-    ZKCHK(pin_lookup(handle, &kp));
-    PinKey& k = *kp;
-    if (!dv || !dw || !dy) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_async: null argument");
-    PinSlot* slp;
-    ZKCHK(pin_slot_get(k, slot, &slp));
-    PinSlot& sl = *slp;
-    if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call zk_pinocchio_prove_wait first");
+
+// First half of a proof, on the slot's stream: the Fr stage, then the eight scalar vectors over the FULL pools.  all_vectors: also the vectors of
+// pools that read another pool's sort on THIS key (a multi-device key's other shards decide on their own slices).
+static int pin_scalars_enqueue(PinKey& k, PinSlot& sl, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32], const uint8_t dy[32], bool all_vectors) {
     hipStream_t s0 = sl.st;
     const void* wit = k.wit_resident.p;
     if (sol) {
@@ -476,8 +462,8 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     if (k.lagrange) ZKCHK(frstage_eval_lagrange(k.fr, sl.fs, wit, s0));
     else ZKCHK(frstage_eval(k.fr, sl.fs, wit, s0));
     PinScalPtrs ptrs;
-    for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = k.share1[i] < 0 ? sl.scal1[i].as<uint32_t>() : nullptr;
-    for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = k.share2[i] < 0 ? sl.scal2[i].as<uint32_t>() : nullptr;
+    for (int i = 0; i < PIN_G1; i++) ptrs.s1[i] = all_vectors || k.share1[i] < 0 ? sl.scal1[i].as<uint32_t>() : nullptr;
+    for (int i = 0; i < PIN_G2; i++) ptrs.s2[i] = all_vectors || k.share2[i] < 0 ? sl.scal2[i].as<uint32_t>() : nullptr;
     const uint64_t ph = pin_h_points(k.n, k.m, k.lagrange, k.compact);
     PinHArgs ha{};
     ha.h = sl.fs.h.as<uint32_t>(); ha.z = k.fr.z.as<uint32_t>();
@@ -494,28 +480,41 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     hipLaunchKernelGGL(k_pinocchio_scalars, g1d(lanes), dim3(256), 0, s0, ptrs, ha, (const uint32_t*)sl.fs.wit.as<uint32_t>(),
                        (const uint32_t*)k.mid_idx.as<uint32_t>(), (const uint32_t*)sl.deltas.as<uint32_t>(), k.n, k.m, k.n_mid);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sl.host + 960, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, s0));
+    return ZK_OK;
+}
+// proof byte offsets: vv 0 | ww 96 | yy 288 | h 384 | vavv 480 | waww 576 | yayy 768 | bvwy 864
+static const uint32_t PIN_OFF1[PIN_G1] = {0, 288, 480, 768, 864, 384};
+static const uint32_t PIN_OFF2[PIN_G2] = {96, 576};
+// Second half: the eight products over this key's slices of the pools, scalars from sl.scal*[i] + lo.  raw: the XYZZ (partial) sums stay in sl.results --
+// six G1 then two G2 points, the identity for an empty slice -- for the first device of a multi-device key to add up; else affine bytes in sl.out_dev.
+static int pin_msms_enqueue(PinKey& k, PinSlot& sl, bool raw) {
+    hipStream_t s0 = sl.st;
     char* res = sl.results.as<char>();
     char* out = sl.out_dev.as<char>();
     const size_t x1 = xyzz_bytes(CURVE_G1), x2 = xyzz_bytes(CURVE_G2);
-    // proof byte offsets: vv 0 | ww 96 | yy 288 | h 384 | vavv 480 | waww 576 | yayy 768 | bvwy 864
-    const size_t off1[PIN_G1] = {0, 288, 480, 768, 864, 384};
-    const size_t off2[PIN_G2] = {96, 576};
+    auto sc1 = [&](int i) { return (const void*)(sl.scal1[i].as<char>() + 32 * k.lo1[i]); };
+    auto sc2 = [&](int i) { return (const void*)(sl.scal2[i].as<char>() + 32 * k.lo2[i]); };
     // One group of products on one stream: sort + bucket accumulation per MSM; the reductions of every product whose pool got the same
     // window plan go out as ONE mixed G1 / G2 chain of launches (from 2^16 constraints up that is the whole group); one to-bytes launch.
     // G1 products [lo1, hi1), G2 products [lo2, hi2).
     auto group = [&](int lo1, int hi1, int lo2, int hi2, hipStream_t st) -> int {
         // a pool whose scalar vector another pool of the group has sorted reads that sort (the source has the lower index: it ran first on this stream)
         for (int i = lo2; i < hi2; i++) {
+            if (!k.g2[i].n) { HIPCHK(hipMemsetAsync(res + PIN_G1 * x1 + i * x2, 0, x2, st)); continue; }          // empty slice: the identity
             const int f = k.share2[i];
             if (f >= lo2 && f < i) { MsmWorkspace *w1[1] = {&sl.ws2[i]}, *f1[1] = {&sl.ws2[f]}; ZKCHK(msm_accumulate_sorted(k.g2[i], w1, f1, 1, st)); }
-            else ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], f < 0 ? sl.scal2[i].p : sl.scal2[f].p, st));
+            else ZKCHK(msm_sort_accumulate(k.g2[i], sl.ws2[i], f < 0 ? sc2(i) : sc2(f), st));
         }
         for (int i = lo1; i < hi1; i++) {
+            if (!k.g1[i].n) { HIPCHK(hipMemsetAsync(res + i * x1, 0, x1, st)); continue; }
             const int f = k.share1[i];
             if (f >= lo1 && f < i) { MsmWorkspace *w1[1] = {&sl.ws1[i]}, *f1[1] = {&sl.ws1[f]}; ZKCHK(msm_accumulate_sorted(k.g1[i], w1, f1, 1, st)); }
-            else ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], f < 0 ? sl.scal1[i].p : sl.scal1[f].p, st));
+            else ZKCHK(msm_sort_accumulate(k.g1[i], sl.ws1[i], f < 0 ? sc1(i) : sc1(f), st));
         }
         bool done1[PIN_G1] = {}, done2[PIN_G2] = {};
+        for (int i = lo1; i < hi1; i++) done1[i] = !k.g1[i].n;
+        for (int i = lo2; i < hi2; i++) done2[i] = !k.g2[i].n;
         for (;;) {
             int lead_c = -1, lead_nw = -1;
             for (int i = lo1; i < hi1 && lead_c < 0; i++) if (!done1[i]) { lead_c = (int)k.g1[i].c; lead_nw = (int)k.g1[i].nw; }
@@ -531,13 +530,14 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
                 if (!done2[i] && (int)k.g2[i].c == lead_c && (int)k.g2[i].nw == lead_nw) { w2[n2] = &sl.ws2[i]; o2[n2] = res + PIN_G1 * x1 + i * x2; n2++; done2[i] = true; b2 = &k.g2[i]; }
             ZKCHK(msm_reduce_mixed(b1, w1, o1, n1, b2, w2, o2, n2, st));
         }
+        if (raw) return ZK_OK;
         uint32_t o1[PIN_G1], o2[PIN_G2];
-        for (int i = lo1; i < hi1; i++) o1[i - lo1] = (uint32_t)off1[i];
-        for (int i = lo2; i < hi2; i++) o2[i - lo2] = (uint32_t)off2[i];
+        for (int i = lo1; i < hi1; i++) o1[i - lo1] = PIN_OFF1[i];
+        for (int i = lo2; i < hi2; i++) o2[i - lo2] = PIN_OFF2[i];
         return proof_points_to_bytes_dev(res + lo1 * x1, hi1 - lo1, o1, res + PIN_G1 * x1 + lo2 * x2, hi2 - lo2, o2, out, st);
     };
     // fork only while this is the one proof in flight on the key (single-proof latency); with others in flight every slot keeps to one stream
-    bool forked = sl.s1 != nullptr && ctx().profiling < 2;
+    bool forked = sl.s1 != nullptr && ctx().profiling < 2 && !raw;
     for (uint32_t i = 0; forked && i < PIN_MAX_SLOTS; i++)
         if (k.slots[i] && k.slots[i].get() != &sl && k.slots[i]->busy) forked = false;
     if (forked) {
@@ -546,7 +546,7 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
         HIPCHK(hipStreamWaitEvent(sl.s2, sl.fork, 0));
         ZKCHK(group(0, 0, 0, PIN_G2, sl.s1));                  // the G2 pair: the longest reduction chain
         HIPCHK(hipEventRecord(sl.join1, sl.s1));
-        ZKCHK(group(5, 6, 0, 0, sl.s2));                       // the h pool: n + 1 + 2m points
+        ZKCHK(group(5, 6, 0, 0, sl.s2));                       // the h pool
         HIPCHK(hipEventRecord(sl.join2, sl.s2));
         ZKCHK(group(0, 5, 0, 0, s0));                          // the five pools over I_mid
         HIPCHK(hipStreamWaitEvent(s0, sl.join1, 0));
@@ -554,16 +554,405 @@ int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t 
     } else {
         ZKCHK(group(0, PIN_G1, 0, PIN_G2, s0));                // all eight products: one chain of reductions, one to-bytes launch
     }
-    HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 960, hipMemcpyDeviceToHost, s0));
-    HIPCHK(hipMemcpyAsync(sl.host + 960, sl.fs.flag.p, 4, hipMemcpyDeviceToHost, s0));
-    HIPCHK(hipEventRecord(sl.done, s0));
+    return ZK_OK;
+}
+
+// ================================================================== multi-device keys: N GPUs behind ONE handle (round 5; groth16_multi.hip is the model)
+// With a device list of N entries (zk_set_devices / zk_set_device_list) zk_pinocchio_pk_upload builds one SHARD per entry -- 1/N of the points of each
+// of the eight pools, with its own window tables, slots and streams on its device -- and returns one handle.  A proof on slot t runs the Fr stage and
+// the eight scalar vectors ONCE, on the slot's owner device (t mod N); every device copies its slices of the vectors out of the owner's memory
+// (hipMemcpyPeerAsync over xGMI; a plain device copy where two shards share a card) behind an event of the owner's stream, runs the eight products over
+// its slices (pinocchio.ml:438-505: each is a sum over key points, so it splits by points) and sends 1 920 bytes of XYZZ partial sums to the first
+// device, which adds the N blocks per product (exact group additions: the bytes do not depend on N), converts and lands the proof in pinned memory.
+// The consistency check behind the compact h pool runs on the first device (it needs the whole h pool), and so does the derivation of the h bases; the
+// derived pool then travels to every device, which installs its slice.
+struct PinGroupSlot {
+    DevBuf parts, g1p, g2p, sum, out;          // on the first device: [device][1920] landing area, the combine's scratch
+    uint8_t* host = nullptr;                   // pinned: the proof (960 B)
+    hipEvent_t ev_scal = nullptr;              // the owner's scalar vectors are complete
+    std::vector<hipEvent_t> ev_part;           // per device: its block has landed on the first device
+    hipEvent_t done = nullptr;
+    bool busy = false;
+    int owner = 0;
+    ~PinGroupSlot() {
+        if (ev_scal) (void)hipEventDestroy(ev_scal);
+        for (hipEvent_t e : ev_part)
+            if (e) (void)hipEventDestroy(e);
+        if (done) (void)hipEventDestroy(done);
+        if (host) (void)hipHostFree(host);
+    }
+};
+struct PinGroup {
+    uint32_t n = 0, m = 0;
+    bool broken = false;
+    std::vector<std::unique_ptr<PinKey>> sub;
+    std::unique_ptr<PinGroupSlot> slots[PIN_MAX_SLOTS];
+};
+static constexpr size_t PIN_PARTIAL_BYTES = PIN_G1 * 192 + PIN_G2 * 384;
+static std::map<uint64_t, std::unique_ptr<PinGroup>>& g_pin_groups = *new std::map<uint64_t, std::unique_ptr<PinGroup>>;
+static uint64_t g_pin_group_next = 0x7000000001ull;
+static PinGroup* pin_group_lookup(uint64_t handle) {
+    auto it = g_pin_groups.find(handle);
+    return it == g_pin_groups.end() ? nullptr : it->second.get();
+}
+static void pin_group_destroy(PinGroup& g) {
+    {
+        DeviceScope ds(0);
+        for (auto& sl : g.slots) sl.reset();
+    }
+    for (size_t v = 0; v < g.sub.size(); v++) {
+        DeviceScope ds((int)v);
+        g.sub[v].reset();
+    }
+}
+static void pin_release() {
+    g_pin.clear();
+    for (auto& kv : g_pin_groups) pin_group_destroy(*kv.second);
+    g_pin_groups.clear();
+}
+uint64_t pinocchio_live_handles() { return g_pin.size() + g_pin_groups.size(); }
+static CleanupRegistrar g_pin_cleanup(pin_release);
+static int pin_group_sync(PinGroup& g) {
+    for (size_t v = 0; v < g.sub.size(); v++) {
+        DeviceScope ds((int)v);
+        HIPCHK(hipDeviceSynchronize());
+    }
+    return ZK_OK;
+}
+static int pin_group_check_idle(PinGroup& g, const char* who) {
+    if (g.broken) ZK_FAIL(ZK_ERR_HIP, "multi-device Pinocchio key is inconsistent after a failed derivation: free it");
+    for (auto& sl : g.slots)
+        if (sl && sl->busy) ZK_FAIL(ZK_ERR_ARG, who);
+    return ZK_OK;
+}
+static int pin_group_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid, const uint8_t* pk_g1, size_t pk_g1_points,
+                            const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
+    const int N = ctx_count();
+    auto grp = std::make_unique<PinGroup>();
+    PinGroup& g = *grp;
+    g.n = n; g.m = m;
+    g.sub.resize(N);
+    int rc = ZK_OK, compact = -1;
+    // the shards one after another (set-up work; the kernels of one card's shards would take turns anyway, groth16_multi.hip): the first one decides the
+    // form of the h pool for all
+    for (int v = 0; v < N && rc == ZK_OK; v++) {
+        DeviceScope ds(v);
+        try {
+            rc = pin_key_build(g.sub[v], n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, (uint32_t)v, (uint32_t)N, compact);
+        } catch (const std::exception& e) {
+            rc = set_error(ZK_ERR_HIP, e.what(), __FILE__, __LINE__);
+        }
+        if (rc == ZK_OK && v == 0) compact = g.sub[0]->compact ? 1 : 0;
+    }
+    if (rc != ZK_OK) {
+        pin_group_destroy(g);
+        return rc;
+    }
+    *handle = g_pin_group_next++;
+    g_pin_groups[*handle] = std::move(grp);
+    return ZK_OK;
+}
+static int pin_group_slot_get(PinGroup& g, uint32_t idx, PinGroupSlot** out) {
+    if (idx >= PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "pinocchio: slot index out of range (max 15 proofs in flight)");
+    const size_t N = g.sub.size();
+    if (!g.slots[idx]) {
+        for (size_t v = 0; v < N; v++) {
+            DeviceScope ds((int)v);
+            PinSlot* sl;
+            ZKCHK(pin_slot_get(*g.sub[v], idx, &sl));
+        }
+        DeviceScope ds(0);
+        auto gs = std::make_unique<PinGroupSlot>();
+        ZKCHK(gs->parts.alloc(PIN_PARTIAL_BYTES * N));
+        ZKCHK(gs->g1p.alloc(PIN_G1 * 192 * N));
+        ZKCHK(gs->g2p.alloc(PIN_G2 * 384 * N));
+        ZKCHK(gs->sum.alloc(PIN_PARTIAL_BYTES));
+        ZKCHK(gs->out.alloc(960));
+        HIPCHK(hipHostMalloc((void**)&gs->host, 960, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&gs->done, hipEventDisableTiming));
+        gs->ev_part.assign(N, nullptr);
+        gs->owner = (int)(idx % N);
+        {
+            DeviceScope dso(gs->owner);
+            HIPCHK(hipEventCreateWithFlags(&gs->ev_scal, hipEventDisableTiming));
+        }
+        for (size_t v = 0; v < N; v++) {
+            DeviceScope dsv((int)v);
+            HIPCHK(hipEventCreateWithFlags(&gs->ev_part[v], hipEventDisableTiming));
+        }
+        g.slots[idx] = std::move(gs);
+    }
+    *out = g.slots[idx].get();
+    return ZK_OK;
+}
+static int pin_group_prove_async(PinGroup& g, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32], const uint8_t dy[32], uint32_t slot) {
+    if (g.broken) ZK_FAIL(ZK_ERR_HIP, "multi-device Pinocchio key is inconsistent after a failed derivation: free it");
+    PinGroupSlot* gsp;
+    ZKCHK(pin_group_slot_get(g, slot, &gsp));
+    PinGroupSlot& gs = *gsp;
+    if (gs.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call zk_pinocchio_prove_wait first");
+    const int N = (int)g.sub.size(), owner = gs.owner;
+    PinSlot* so = g.sub[owner]->slots[slot].get();
+    {   // ---- the Fr stage and the eight scalar vectors over the FULL pools, on the owner
+        DeviceScope ds(owner);
+        ZKCHK(pin_scalars_enqueue(*g.sub[owner], *so, sol, dv, dw, dy, true));
+        HIPCHK(hipEventRecord(gs.ev_scal, so->st));
+    }
+    gs.busy = true;          // from here on the slot is in flight whatever happens: _wait (or the failure path below) drains it
+    int rc = ZK_OK;
+    for (int v = 0; v < N && rc == ZK_OK; v++) {
+        DeviceScope ds(v);
+        PinKey& k = *g.sub[v];
+        PinSlot& sv = *k.slots[slot];
+        auto body = [&]() -> int {
+            if (v != owner) {
+                HIPCHK(hipStreamWaitEvent(sv.st, gs.ev_scal, 0));
+                // this device's slices of the vectors it sorts itself (a pool that reads another pool's sort on THIS shard needs none)
+                for (int i = 0; i < PIN_G1; i++)
+                    if (k.g1[i].n && k.share1[i] < 0)
+                        ZKCHK(copy_between(sv.scal1[i].as<char>() + 32 * k.lo1[i], v, so->scal1[i].as<char>() + 32 * k.lo1[i], owner, 32 * (k.hi1[i] - k.lo1[i]), sv.st));
+                for (int i = 0; i < PIN_G2; i++)
+                    if (k.g2[i].n && k.share2[i] < 0)
+                        ZKCHK(copy_between(sv.scal2[i].as<char>() + 32 * k.lo2[i], v, so->scal2[i].as<char>() + 32 * k.lo2[i], owner, 32 * (k.hi2[i] - k.lo2[i]), sv.st));
+            }
+            ZKCHK(pin_msms_enqueue(k, sv, true));
+            ZKCHK(copy_between(gs.parts.as<char>() + PIN_PARTIAL_BYTES * v, 0, sv.results.p, v, PIN_PARTIAL_BYTES, sv.st));
+            HIPCHK(hipEventRecord(gs.ev_part[v], sv.st));
+            return ZK_OK;
+        };
+        rc = body();
+    }
+    {   // ---- first device: add the N blocks per product, convert, land the proof (one stream for all slots: groth16_multi.hip says why)
+        DeviceScope ds(0);
+        hipStream_t cs = ctx().stream2;
+        auto body = [&]() -> int {
+            for (int v = 0; v < N; v++) HIPCHK(hipStreamWaitEvent(cs, gs.ev_part[v], 0));
+            if (rc != ZK_OK) return rc;
+            const size_t b1 = PIN_G1 * 192, b2 = PIN_G2 * 384;
+            HIPCHK(hipMemcpy2DAsync(gs.g1p.p, b1, gs.parts.p, PIN_PARTIAL_BYTES, b1, N, hipMemcpyDeviceToDevice, cs));                      // [device][six G1 sums]
+            HIPCHK(hipMemcpy2DAsync(gs.g2p.p, b2, gs.parts.as<char>() + b1, PIN_PARTIAL_BYTES, b2, N, hipMemcpyDeviceToDevice, cs));        // [device][two G2 sums]
+            ZKCHK(xyzz_sum_columns(CURVE_G1, gs.sum.p, gs.g1p.p, N, PIN_G1, cs));
+            ZKCHK(xyzz_sum_columns(CURVE_G2, gs.sum.as<char>() + b1, gs.g2p.p, N, PIN_G2, cs));
+            ZKCHK(proof_points_to_bytes_dev(gs.sum.p, PIN_G1, PIN_OFF1, gs.sum.as<char>() + b1, PIN_G2, PIN_OFF2, gs.out.p, cs));
+            HIPCHK(hipMemcpyAsync(gs.host, gs.out.p, 960, hipMemcpyDeviceToHost, cs));
+            return ZK_OK;
+        };
+        const int rc0 = body();
+        if (rc == ZK_OK) rc = rc0;
+        (void)hipEventRecord(gs.done, cs);
+    }
+    if (rc != ZK_OK) {
+        (void)pin_group_sync(g);
+        gs.busy = false;
+    }
+    return rc;
+}
+static int pin_group_prove_wait(PinGroup& g, uint32_t slot, uint8_t proof[960]) {
+    if (slot >= PIN_MAX_SLOTS || !g.slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_wait: slot never used");
+    PinGroupSlot& gs = *g.slots[slot];
+    if (!gs.busy) ZK_FAIL(ZK_ERR_ARG, "no proof in flight on this slot");
+    {
+        DeviceScope ds(0);
+        HIPCHK(hipEventSynchronize(gs.done));          // behind every device's block, which is behind the owner's Fr stage and its flag copy
+    }
+    gs.busy = false;
+    int hf;
+    memcpy(&hf, g.sub[gs.owner]->slots[slot]->host + 960, 4);
+    if (hf & 2) ZK_FAIL(ZK_ERR_SCALAR_RANGE, "witness value >= r");
+    if (hf & 1) ZK_FAIL(ZK_ERR_REMAINDER, "p mod Z != 0");
+    memcpy(proof, gs.host, 960);
+    return ZK_OK;
+}
+static int pin_group_derive(PinGroup& g) {
+    if (g.sub[0]->lagrange) return ZK_OK;
+    ZKCHK(pin_group_check_idle(g, "zk_pinocchio_pk_derive_lagrange: a proof is in flight on this key"));
+    ZKCHK(pin_group_sync(g));
+    const int N = (int)g.sub.size();
+    PinKey& k0 = *g.sub[0];
+    const uint64_t ph_old = k0.full1[5], ph = pin_h_points(k0.n, k0.m, true, k0.compact);
+    // ---- gather the h pool as uploaded on the first device (window 0 of a shard's tables IS its slice in pool order)
+    DevBuf old_dense;
+    {
+        DeviceScope ds(0);
+        ZKCHK(old_dense.alloc(96 * ph_old));
+    }
+    for (int v = 0; v < N; v++) {
+        DeviceScope ds(v);
+        PinKey& k = *g.sub[v];
+        if (!k.g1[5].n) continue;
+        Ctx& c = ctx();
+        DevBuf t;
+        ZKCHK(t.alloc(96 * k.g1[5].n));
+        ZKCHK(msm_bases_dense(k.g1[5], 0, k.g1[5].n, t.p, c.stream));
+        ZKCHK(copy_between(old_dense.as<char>() + 96 * k.lo1[5], 0, t.p, v, 96 * k.g1[5].n, c.stream));
+        HIPCHK(hipStreamSynchronize(c.stream));
+    }
+    // ---- derive on the first device, send the whole derived pool to every device
+    std::vector<DevBuf> pool(N);
+    {
+        DeviceScope ds(0);
+        ZKCHK(pin_derive_pool(k0, old_dense.as<uint8_t>(), pool[0], ctx().stream));          // nothing of the key has changed yet
+    }
+    for (int v = 1; v < N; v++) {
+        DeviceScope ds(v);
+        ZKCHK(pool[v].alloc(96 * ph));
+        ZKCHK(copy_between(pool[v].p, v, pool[0].p, 0, 96 * ph, ctx().stream));
+        HIPCHK(hipStreamSynchronize(ctx().stream));
+    }
+    // ---- install: from the first commit on the key is only consistent once every device has succeeded
+    {
+        DeviceScope ds(0);
+        for (auto& sl : g.slots) sl.reset();          // group slots refer to the shards' slots, which the install replaces
+    }
+    for (int v = 0; v < N; v++) {
+        DeviceScope ds(v);
+        const int rc = pin_install_derived(*g.sub[v], pool[v].as<uint8_t>(), ctx().stream);
+        if (rc != ZK_OK) {
+            g.broken = true;
+            return rc;
+        }
+    }
+    return ZK_OK;
+}
+
+}  // namespace zk
+
+using namespace zk;
+extern "C" {
+
+int zk_pinocchio_pk_upload(uint32_t n, uint32_t m, const zk_csr* L, const zk_csr* R, const zk_csr* O, const uint8_t* mid,
+                           const uint8_t* pk_g1, size_t pk_g1_points, const uint8_t* pk_g2, size_t pk_g2_points, uint64_t* handle) {
+    if (!handle || !mid || !pk_g1 || !pk_g2) ZK_FAIL(ZK_ERR_ARG, "pinocchio pk_upload: null argument");
+    ZKCHK(ensure_init());
+    if (ctx_count() > 1) return pin_group_upload(n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, handle);
+    std::unique_ptr<PinKey> key;
+    ZKCHK(pin_key_build(key, n, m, L, R, O, mid, pk_g1, pk_g1_points, pk_g2, pk_g2_points, 0, 1, -1));
+    *handle = g_pin_next++;
+    g_pin[*handle] = std::move(key);
+    return ZK_OK;
+}
+// The h pool of an uploaded key (si | v_all | w_all, or si alone: compact) rewritten for the VALUES of h: [lambda_t(s)]_1 derived from the powers si in the
+// exponent (lagrange_derive.hip: the transposed interpolation over the points n .. 2n-2), [Z(s)]_1 = <si, Z> once, [1] = si[0], and for the compact form
+// [s^(n-1)] = si[n-1].  Same proofs; the per-proof basis conversion disappears (only h ever needed coefficients: v(s), w(s) come from the per-variable pools).
+int zk_pinocchio_pk_derive_lagrange(uint64_t handle) {
+    if (PinGroup* g = pin_group_lookup(handle)) return pin_group_derive(*g);
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    PinKey& k = *kp;
+    if (k.lagrange) return ZK_OK;
+    ZKCHK(pin_check_idle(k, "zk_pinocchio_pk_derive_lagrange: a proof is in flight on this key"));
+    HIPCHK(hipDeviceSynchronize());
+    Ctx& c = ctx();
+    const uint64_t ph_old = pin_h_points(k.n, k.m, false, k.compact);
+    if (k.g1[5].n != ph_old) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pk_derive_lagrange: unexpected pool length");
+    DevBuf pool, old_dense;
+    ZKCHK(old_dense.alloc(96 * ph_old));
+    ZKCHK(msm_bases_dense(k.g1[5], 0, ph_old, old_dense.p, c.stream));            // window 0 = the pool as uploaded, back in the dense affine format
+    ZKCHK(pin_derive_pool(k, old_dense.as<uint8_t>(), pool, c.stream));
+    return pin_install_derived(k, pool.as<uint8_t>(), c.stream);
+}
+int zk_pinocchio_pool_points(uint64_t handle, int pool, uint8_t* out, size_t capacity_points, size_t* count) {
+    if (pool < 0 || pool >= PIN_G1 + PIN_G2) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: pool 0..5 (G1) or 6..7 (G2)");
+    if (PinGroup* g = pin_group_lookup(handle)) {          // the handle holds the whole pools (its devices' slices are an internal matter)
+        PinKey& k0 = *g->sub[0];
+        const uint64_t total = pool < PIN_G1 ? k0.full1[pool] : k0.full2[pool - PIN_G1];
+        if (count) *count = total;
+        if (!out) return ZK_OK;
+        if (capacity_points < total) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: buffer too small");
+        ZKCHK(pin_group_check_idle(*g, "zk_pinocchio_pool_points: a proof is in flight on this key"));
+        const size_t pb = pool < PIN_G1 ? 96 : 192;
+        for (size_t v = 0; v < g->sub.size(); v++) {
+            DeviceScope ds((int)v);
+            PinKey& k = *g->sub[v];
+            ZKCHK(pin_slice_points(k, pool, out + pb * (pool < PIN_G1 ? k.lo1[pool] : k.lo2[pool - PIN_G1])));
+        }
+        return ZK_OK;
+    }
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    const MsmBases& b = pool < PIN_G1 ? kp->g1[pool] : kp->g2[pool - PIN_G1];
+    if (count) *count = b.n;
+    if (!out) return ZK_OK;
+    if (capacity_points < b.n) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_pool_points: buffer too small");
+    return pin_slice_points(*kp, pool, out);
+}
+int zk_pinocchio_pk_free(uint64_t handle) {
+    auto ig = g_pin_groups.find(handle);
+    if (ig != g_pin_groups.end()) {
+        (void)pin_group_sync(*ig->second);
+        pin_group_destroy(*ig->second);
+        g_pin_groups.erase(ig);
+        return ZK_OK;
+    }
+    auto it = g_pin.find(handle);
+    if (it == g_pin.end()) ZK_FAIL(ZK_ERR_HANDLE, "unknown Pinocchio key handle");
+    (void)hipDeviceSynchronize();
+    g_pin.erase(it);
+    return ZK_OK;
+}
+int zk_pinocchio_reserve_slots(uint64_t handle, uint32_t count) {
+    if (count > PIN_MAX_SLOTS) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_reserve_slots: at most 15 slots");
+    if (PinGroup* g = pin_group_lookup(handle)) {
+        for (uint32_t i = 0; i < count; i++) {
+            PinGroupSlot* gs;
+            ZKCHK(pin_group_slot_get(*g, i, &gs));
+        }
+        return ZK_OK;
+    }
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    for (uint32_t i = 0; i < count; i++) {
+        PinSlot* sl;
+        ZKCHK(pin_slot_get(*kp, i, &sl));
+    }
+    return ZK_OK;
+}
+int zk_pinocchio_set_witness(uint64_t handle, const uint8_t* sol) {
+    if (!sol) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_set_witness: null");
+    if (PinGroup* g = pin_group_lookup(handle)) {
+        ZKCHK(pin_group_check_idle(*g, "zk_pinocchio_set_witness: a proof is in flight on this key"));
+        for (size_t v = 0; v < g->sub.size(); v++) {          // any device may own a proof's Fr stage
+            DeviceScope ds((int)v);
+            PinKey& k = *g->sub[v];
+            HIPCHK(hipMemcpyAsync(k.wit_resident.p, sol, 32 * (size_t)k.m, hipMemcpyHostToDevice, ctx().stream));
+            HIPCHK(hipStreamSynchronize(ctx().stream));
+            k.have_witness = true;
+        }
+        return ZK_OK;
+    }
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    Ctx& c = ctx();
+    (void)hipDeviceSynchronize();      // no proof may still be reading the previous witness
+    HIPCHK(hipMemcpyAsync(kp->wit_resident.p, sol, 32 * (size_t)kp->m, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    kp->have_witness = true;
+    return ZK_OK;
+}
+// Enqueues one proof on the slot's stream and returns without waiting:
+// Fr stage -> the eight scalar vectors -> eight MSMs -> affine bytes -> pinned host buffer.
+int zk_pinocchio_prove_async(uint64_t handle, const uint8_t* sol, const uint8_t dv[32], const uint8_t dw[32], const uint8_t dy[32], uint32_t slot) {
+    if (!dv || !dw || !dy) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_async: null argument");
+    if (PinGroup* g = pin_group_lookup(handle)) return pin_group_prove_async(*g, sol, dv, dw, dy, slot);
+    PinKey* kp;
+    ZKCHK(pin_lookup(handle, &kp));
+    PinKey& k = *kp;
+    PinSlot* slp;
+    ZKCHK(pin_slot_get(k, slot, &slp));
+    PinSlot& sl = *slp;
+    if (sl.busy) ZK_FAIL(ZK_ERR_ARG, "slot still has a proof in flight: call zk_pinocchio_prove_wait first");
+    ZKCHK(pin_scalars_enqueue(k, sl, sol, dv, dw, dy, false));
+    ZKCHK(pin_msms_enqueue(k, sl, false));
+    HIPCHK(hipMemcpyAsync(sl.host, sl.out_dev.p, 960, hipMemcpyDeviceToHost, sl.st));
+    HIPCHK(hipEventRecord(sl.done, sl.st));
     sl.busy = true;
     return ZK_OK;
 }
 int zk_pinocchio_prove_wait(uint64_t handle, uint32_t slot, uint8_t proof[960]) {
+    if (!proof) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_wait: null proof");
+    if (PinGroup* g = pin_group_lookup(handle)) return pin_group_prove_wait(*g, slot, proof);
     PinKey* kp;
     ZKCHK(pin_lookup(handle, &kp));
-    if (!proof) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_wait: null proof");
     if (slot >= PIN_MAX_SLOTS || !kp->slots[slot]) ZK_FAIL(ZK_ERR_ARG, "zk_pinocchio_prove_wait: slot never used");
     PinSlot& sl = *kp->slots[slot];
     if (!sl.busy) ZK_FAIL(ZK_ERR_ARG, "no proof in flight on this slot");
