@@ -20,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 frb = P.fr_to_bytes
 t_end = time.time() + budget
-n_msm = n_g16 = n_pin = n_der = n_ba = n_multi = n_rns = n_sort = 0
+n_msm = n_g16 = n_pin = n_der = n_ba = n_multi = n_rns = n_sort = n_pin_multi = 0
 _lib.check(_lib.lib().zk_init(0))
 while time.time() < t_end:
     # ---- MSM with duplicates, negations, identity, tiny / huge / zero scalars
@@ -156,12 +156,23 @@ while time.time() < t_end:
             _lib.check(_lib.lib().zk_set_option(k_.encode(), None if v_ is None else v_.encode()))
         if n_pin % 5 == 4:
             os.environ["ZK_FR_RNS"] = "1"
+        pin_devs = [0] * rnd.choice([2, 3, 4]) if n_pin % 4 == 3 else None          # round 5: every fourth case behind a device list (csrc/pinocchio.hip, PinGroup)
+        if pin_devs:
+            _lib.set_device_list(pin_devs)
         try:
             prover = PIN.ZK(cs, pk)
         finally:
             for k_ in opts:
                 _lib.check(_lib.lib().zk_set_option(k_.encode(), None))
         assert prover.pool_size(5) == (cs.n + 1 if opts["ZK_PIN_COMPACT_H"] is None else cs.n + 1 + 2 * cs.m), ("h pool form", n)
+        if pin_devs:
+            n_pin_multi += 1
+            prover.set_witness(w)
+            for slot in range(3):                          # rotating owners
+                prover.prove_async(*tox[8:], slot)
+            for slot in range(3):
+                assert prover.prove_wait(slot).to_bytes() == O.pinocchio_prove_trapdoor(cs.n, cs.m, *[O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)], cs.mid,
+                                                                                        b"".join(frb(x) for x in w), b"".join(frb(x) for x in tox[:8]), *(frb(x) for x in tox[8:])), ("multi-device Pinocchio mismatch", n, pin_devs, slot)
         proof = prover.prove(lambda: next(it), w)
         csr = [O.CSR(M.ptr, M.col, M.val) for M in (cs.L, cs.R, cs.O)]
         exp = O.pinocchio_prove_trapdoor(cs.n, cs.m, *csr, cs.mid, b"".join(frb(x) for x in w), b"".join(frb(x) for x in tox[:8]), *(frb(x) for x in tox[8:]))
@@ -173,9 +184,11 @@ while time.time() < t_end:
         if n <= 40:
             assert PIN.ZK.verify([w[k] for k in range(cs.m) if not cs.mid[k]], vk, proof)
         prover.close()
+        if pin_devs:
+            _lib.set_device_list([0])
         os.environ.pop("ZK_FR_RNS", None)          # set for every fifth case from the upload to the last proof (the switch is read per call under ZK_TEST_FORMS)
         n_pin += 1
     if (n_msm % 10) == 0:
         print("soak: %d MSM cases, %d Groth16 cases (%d multi-device, %d RNS), %d Pinocchio cases ok" % (n_msm, n_g16, n_multi, n_rns, n_pin), flush=True)
-print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds, %d behind a multi-device handle, %d through the residue number system, %d through the forced two-level sort in its plain / staged forms) pinocchio=%d"
-      % (n_msm, n_g16, n_der, n_ba, n_multi, n_rns, n_sort, n_pin))
+print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds, %d behind a multi-device handle, %d through the residue number system, %d through the forced two-level sort in its plain / staged forms) pinocchio=%d (%d of them behind a device list)"
+      % (n_msm, n_g16, n_der, n_ba, n_multi, n_rns, n_sort, n_pin, n_pin_multi))
