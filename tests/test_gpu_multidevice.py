@@ -235,3 +235,43 @@ def test_multi_device_pinocchio_key_gives_the_single_device_bytes(devices, devs,
             prover.prove_with(w_bad, *ds[0])
         assert prover.prove_with(w, *ds[1]).to_bytes() == exp[1]      # the slot is usable afterwards
     prover.close()
+
+
+def test_multi_device_pinocchio_handle_refuses_what_a_single_device_handle_refuses(devices):
+    """slot discipline and error paths of the multi-device Pinocchio handle (the checks of tests/test_gpu_api_errors.py::test_pinocchio_slot_misuse, plus a
+    key with a point outside the curve on a shard that is not the first: the upload fails as a whole and leaves no handle behind)."""
+    from zukelang_amd import pinocchio as PIN
+    cs, w = RC.iterated_cubic(16, 5)
+    pk, _ = PIN.ZK.keygen(seeded_rng(0xE45), cs)
+    devices(physical([0, 0, 0]))
+    pr = PIN.ZK(cs, pk)
+    with pytest.raises(_lib.ZkError):
+        pr.prove_async(1, 2, 3, 0)                         # no resident witness
+    pr.set_witness(w)
+    pr.prove_async(1, 2, 3, 1)
+    with pytest.raises(_lib.ZkError):
+        pr.prove_async(1, 2, 3, 1)                         # the slot is busy
+    with pytest.raises(_lib.ZkError):
+        pr.derive_lagrange()                               # a proof is in flight
+    first = pr.prove_wait(1)
+    with pytest.raises(_lib.ZkError):
+        pr.prove_wait(3)                                   # slot never used
+    with pytest.raises(_lib.ZkError):
+        pr.prove_wait(1)                                   # nothing in flight any more
+    pr.derive_lagrange()
+    pr.prove_async(1, 2, 3, 2)
+    assert pr.prove_wait(2).to_bytes() == first.to_bytes()
+    pr.close()
+    # a bad point in the LAST third of the vv pool (shard 2 decodes it): (1, 1) is not on y^2 = x^3 + 4
+    bad = np.array(pk.g1, copy=True)
+    nm = sum(1 for k in range(cs.m) if cs.mid[k])
+    off = 96 * (nm - 1)
+    bad[off:off + 96] = 0
+    bad[off + 47] = 1
+    bad[off + 95] = 1
+    before = _lib.lib().zk_device_count()
+    with pytest.raises(_lib.ZkError):
+        PIN.ZK(cs, PIN.PKey(bad, pk.g2))
+    assert _lib.lib().zk_device_count() == before
+    _lib.set_device_list([0])                              # succeeds only if the failed upload left no key handle alive
+    _lib.set_device_list(physical([0, 0, 0]))
