@@ -4,10 +4,17 @@
 // from opam bls12-381 (curve.ml:77); a handful of pairings per proof is host work there and here --
 // nothing in this file runs on the GPU (it is a .hip file only so that the one Makefile rule builds it).
 //
-// Deliberately the transparent formulation: Fp on 6 x 64-bit Montgomery limbs, the tower
-// Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3 - (1+u)), Fp12 = Fp6[w]/(w^2 - v) with schoolbook products,
-// the twist point mapped into E(Fp12) (x / w^2, y / w^3), an affine Miller loop over |x| and the final
-// exponentiation as one power (p^12 - 1) / r.  ~0.1 s per pairing product; correctness over speed.
+// Fp on 6 x 64-bit Montgomery limbs, the tower Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3 - (1+u)), Fp12 = Fp6[w]/(w^2 - v) with Karatsuba products.
+// The pairing is DEFINED by the transparent formulation of rounds 1-4 (and of oracle/pyref.py, which the tests compare coefficient by coefficient): the
+// twist point mapped into E(Fp12) as (x / w^2, y / w^3), an affine Miller loop over |x| conjugated at the end (x < 0), one power (p^12 - 1) / r.  Round 5
+// computes the SAME field elements ~25x faster (0.1 s -> a few ms per pairing product):
+//   * the affine point arithmetic runs on the twist in Fp2 -- every Fp12 value of the untwisted loop is an Fp2 value times a fixed power of w (slope
+//     lam = lam' / w), so the line l = yP - lam' xP / w + (lam' x' - y') / w^3 is the same element, held sparsely as yP + B (v w) + C (v^2 w);
+//   * the pairs of a product walk the loop in LOCKSTEP: one squaring of the accumulated f per step for all of them, and their inversions (one per pair and
+//     step) share one field inversion (Montgomery's trick);
+//   * the final power is factored: (p^12 - 1) / r = (p^6 - 1)(p^2 + 1) h, h = (p^4 - p^2 + 1) / r = e1 (x + p)(x^2 + p^2 - 1) + 1 with e1 = (x - 1)^2 / 3
+//     (an identity of integers: scripts/gen_pairing_consts.py asserts it) -- conjugation, one inversion, Frobenius maps, three powers by |x| and one
+//     by the 126-bit e1 instead of a 4 314-bit square-and-multiply.  The plain power stays as final_exp_plain for the tests to hold the two together.
 // GT encoding (ours; the reference's is defined by its external library): the 12 Fp coefficients
 // c0.c0.a, c0.c0.b, c0.c1.a, ... c1.c2.b as 48-byte big-endian integers = 576 B.
 #include "../../include/zkmi355x.h"
@@ -141,9 +148,16 @@ static inline Fp2 f2_one() { return f2(fp_one(), fp_zero()); }
 static inline Fp2 f2_add(const Fp2& x, const Fp2& y) { return f2(fp_add(x.a, y.a), fp_add(x.b, y.b)); }
 static inline Fp2 f2_sub(const Fp2& x, const Fp2& y) { return f2(fp_sub(x.a, y.a), fp_sub(x.b, y.b)); }
 static inline Fp2 f2_neg(const Fp2& x) { return f2(fp_neg(x.a), fp_neg(x.b)); }
-static inline Fp2 f2_mul(const Fp2& x, const Fp2& y) {
-    return f2(fp_sub(fp_mul(x.a, y.a), fp_mul(x.b, y.b)), fp_add(fp_mul(x.a, y.b), fp_mul(x.b, y.a)));
+static inline Fp2 f2_mul(const Fp2& x, const Fp2& y) {          // Karatsuba: three base-field products
+    const Fp aa = fp_mul(x.a, y.a), bb = fp_mul(x.b, y.b);
+    return f2(fp_sub(aa, bb), fp_sub(fp_sub(fp_mul(fp_add(x.a, x.b), fp_add(y.a, y.b)), aa), bb));
 }
+static inline Fp2 f2_sqr(const Fp2& x) {                         // (a + b)(a - b), 2 a b
+    const Fp ab = fp_mul(x.a, x.b);
+    return f2(fp_mul(fp_add(x.a, x.b), fp_sub(x.a, x.b)), fp_add(ab, ab));
+}
+static inline Fp2 f2_mul_fp(const Fp2& x, const Fp& k) { return Fp2{fp_mul(x.a, k), fp_mul(x.b, k)}; }
+static inline Fp2 f2_conj(const Fp2& x) { return Fp2{x.a, fp_neg(x.b)}; }
 static inline Fp2 f2_mul_xi(const Fp2& x) { return f2(fp_sub(x.a, x.b), fp_add(x.a, x.b)); }      // * (1 + u)
 static inline Fp2 f2_inv(const Fp2& x) {
     const Fp d = fp_inv(fp_add(fp_sqr(x.a), fp_sqr(x.b)));
@@ -160,12 +174,20 @@ static inline Fp6 f6_one() { return Fp6{f2_one(), f2_zero(), f2_zero()}; }
 static inline Fp6 f6_add(const Fp6& x, const Fp6& y) { return Fp6{f2_add(x.c0, y.c0), f2_add(x.c1, y.c1), f2_add(x.c2, y.c2)}; }
 static inline Fp6 f6_sub(const Fp6& x, const Fp6& y) { return Fp6{f2_sub(x.c0, y.c0), f2_sub(x.c1, y.c1), f2_sub(x.c2, y.c2)}; }
 static inline Fp6 f6_neg(const Fp6& x) { return Fp6{f2_neg(x.c0), f2_neg(x.c1), f2_neg(x.c2)}; }
-static Fp6 f6_mul(const Fp6& x, const Fp6& y) {
-    const Fp2 t0 = f2_add(f2_mul(x.c0, y.c0), f2_mul_xi(f2_add(f2_mul(x.c1, y.c2), f2_mul(x.c2, y.c1))));
-    const Fp2 t1 = f2_add(f2_add(f2_mul(x.c0, y.c1), f2_mul(x.c1, y.c0)), f2_mul_xi(f2_mul(x.c2, y.c2)));
-    const Fp2 t2 = f2_add(f2_add(f2_mul(x.c0, y.c2), f2_mul(x.c1, y.c1)), f2_mul(x.c2, y.c0));
-    return Fp6{t0, t1, t2};
+static Fp6 f6_mul(const Fp6& x, const Fp6& y) {          // Karatsuba: six products in Fp2
+    const Fp2 v0 = f2_mul(x.c0, y.c0), v1 = f2_mul(x.c1, y.c1), v2 = f2_mul(x.c2, y.c2);
+    const Fp2 m12 = f2_sub(f2_sub(f2_mul(f2_add(x.c1, x.c2), f2_add(y.c1, y.c2)), v1), v2);          // x1 y2 + x2 y1
+    const Fp2 m01 = f2_sub(f2_sub(f2_mul(f2_add(x.c0, x.c1), f2_add(y.c0, y.c1)), v0), v1);          // x0 y1 + x1 y0
+    const Fp2 m02 = f2_sub(f2_sub(f2_mul(f2_add(x.c0, x.c2), f2_add(y.c0, y.c2)), v0), v2);          // x0 y2 + x2 y0
+    return Fp6{f2_add(v0, f2_mul_xi(m12)), f2_add(m01, f2_mul_xi(v2)), f2_add(m02, v1)};
 }
+// x * (B v + C v^2): the shape of a line's w-part (miller_product)
+static Fp6 f6_mul_by_0bc(const Fp6& x, const Fp2& B, const Fp2& C) {
+    const Fp2 v1 = f2_mul(x.c1, B), v2 = f2_mul(x.c2, C);
+    const Fp2 m12 = f2_sub(f2_sub(f2_mul(f2_add(x.c1, x.c2), f2_add(B, C)), v1), v2);               // x1 C + x2 B
+    return Fp6{f2_mul_xi(m12), f2_add(f2_mul(x.c0, B), f2_mul_xi(v2)), f2_add(f2_mul(x.c0, C), v1)};
+}
+static inline Fp6 f6_mul_fp(const Fp6& x, const Fp& k) { return Fp6{f2_mul_fp(x.c0, k), f2_mul_fp(x.c1, k), f2_mul_fp(x.c2, k)}; }
 static inline Fp6 f6_mul_by_v(const Fp6& x) { return Fp6{f2_mul_xi(x.c2), x.c0, x.c1}; }
 static Fp6 f6_inv(const Fp6& x) {
     const Fp2 t0 = f2_sub(f2_mul(x.c0, x.c0), f2_mul_xi(f2_mul(x.c1, x.c2)));
@@ -182,8 +204,18 @@ struct Fp12 {
 static inline Fp12 f12_one() { return Fp12{f6_one(), f6_zero()}; }
 static inline Fp12 f12_add(const Fp12& x, const Fp12& y) { return Fp12{f6_add(x.c0, y.c0), f6_add(x.c1, y.c1)}; }
 static inline Fp12 f12_sub(const Fp12& x, const Fp12& y) { return Fp12{f6_sub(x.c0, y.c0), f6_sub(x.c1, y.c1)}; }
-static Fp12 f12_mul(const Fp12& x, const Fp12& y) {
-    return Fp12{f6_add(f6_mul(x.c0, y.c0), f6_mul_by_v(f6_mul(x.c1, y.c1))), f6_add(f6_mul(x.c0, y.c1), f6_mul(x.c1, y.c0))};
+static Fp12 f12_mul(const Fp12& x, const Fp12& y) {          // Karatsuba: three products in Fp6
+    const Fp6 aa = f6_mul(x.c0, y.c0), bb = f6_mul(x.c1, y.c1);
+    return Fp12{f6_add(aa, f6_mul_by_v(bb)), f6_sub(f6_sub(f6_mul(f6_add(x.c0, x.c1), f6_add(y.c0, y.c1)), aa), bb)};
+}
+static Fp12 f12_sqr(const Fp12& x) {                        // (a + b w)^2 = (a + b)(a + v b) - ab - v ab  +  2 ab w
+    const Fp6 ab = f6_mul(x.c0, x.c1);
+    const Fp6 t = f6_mul(f6_add(x.c0, x.c1), f6_add(x.c0, f6_mul_by_v(x.c1)));
+    return Fp12{f6_sub(f6_sub(t, ab), f6_mul_by_v(ab)), f6_add(ab, ab)};
+}
+// x * (k + (B v + C v^2) w), k in Fp: a line of the Miller loop
+static Fp12 f12_mul_line(const Fp12& x, const Fp& k, const Fp2& B, const Fp2& C) {
+    return Fp12{f6_add(f6_mul_fp(x.c0, k), f6_mul_by_v(f6_mul_by_0bc(x.c1, B, C))), f6_add(f6_mul_by_0bc(x.c0, B, C), f6_mul_fp(x.c1, k))};
 }
 static Fp12 f12_inv(const Fp12& x) {
     const Fp6 d = f6_inv(f6_sub(f6_mul(x.c0, x.c0), f6_mul_by_v(f6_mul(x.c1, x.c1))));
@@ -196,10 +228,37 @@ static inline Fp12 f12_from_fp2(const Fp2& a) { return Fp12{Fp6{a, f2_zero(), f2
 static Fp12 f12_pow(const Fp12& x, const uint64_t* e, int bits) {
     Fp12 acc = f12_one();
     for (int i = bits - 1; i >= 0; i--) {
-        acc = f12_mul(acc, acc);
+        acc = f12_sqr(acc);
         if ((e[i / 64] >> (i % 64)) & 1) acc = f12_mul(acc, x);
     }
     return acc;
+}
+// ---- Frobenius x -> x^p.  On Fp2 it is conjugation; v^p = xi^((p-1)/3) v and w^p = xi^((p-1)/6) w (v^3 = xi, w^2 = v, 6 | p - 1), so
+// (c0 + c1 v + c2 v^2 + (d0 + d1 v + d2 v^2) w)^p = c0~ + c1~ g^2 v + c2~ g^4 v^2 + (d0~ g + d1~ g^3 v + d2~ g^5 v^2) w  with g = xi^((p-1)/6), ~ = conjugate.
+static Fp2 f2_pow(const Fp2& a, const uint64_t* e, int nlimbs) {
+    Fp2 acc = f2_one();
+    for (int i = nlimbs * 64 - 1; i >= 0; i--) {
+        acc = f2_sqr(acc);
+        if ((e[i / 64] >> (i % 64)) & 1) acc = f2_mul(acc, a);
+    }
+    return acc;
+}
+struct FrobConsts {
+    Fp2 g[6];          // g^0 .. g^5
+    FrobConsts() {
+        g[0] = f2_one();
+        g[1] = f2_pow(f2(fp_one(), fp_one()), HP_PM1D6, 6);
+        for (int i = 2; i < 6; i++) g[i] = f2_mul(g[i - 1], g[1]);
+    }
+};
+static const FrobConsts& frob_consts() {
+    static const FrobConsts c;          // C++11 magic static: built once, thread-safe
+    return c;
+}
+static Fp12 f12_frob(const Fp12& x) {
+    const FrobConsts& k = frob_consts();
+    return Fp12{Fp6{f2_conj(x.c0.c0), f2_mul(f2_conj(x.c0.c1), k.g[2]), f2_mul(f2_conj(x.c0.c2), k.g[4])},
+                Fp6{f2_mul(f2_conj(x.c1.c0), k.g[1]), f2_mul(f2_conj(x.c1.c1), k.g[3]), f2_mul(f2_conj(x.c1.c2), k.g[5])}};
 }
 
 // ---- curve points (affine; inf flag)
@@ -212,6 +271,9 @@ template <> struct Ops<Fp> {
     static Fp add(const Fp& a, const Fp& b) { return fp_add(a, b); }
     static Fp sub(const Fp& a, const Fp& b) { return fp_sub(a, b); }
     static Fp mul(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+    static Fp sqr(const Fp& a) { return fp_sqr(a); }
+    static Fp zero() { return fp_zero(); }
+    static Fp one() { return fp_one(); }
     static Fp inv(const Fp& a) { return fp_inv(a); }
     static bool is_zero(const Fp& a) { return fp_is_zero(a); }
     static bool eq(const Fp& a, const Fp& b) { return fp_eq(a, b); }
@@ -220,6 +282,9 @@ template <> struct Ops<Fp2> {
     static Fp2 add(const Fp2& a, const Fp2& b) { return f2_add(a, b); }
     static Fp2 sub(const Fp2& a, const Fp2& b) { return f2_sub(a, b); }
     static Fp2 mul(const Fp2& a, const Fp2& b) { return f2_mul(a, b); }
+    static Fp2 sqr(const Fp2& a) { return f2_sqr(a); }
+    static Fp2 zero() { return f2_zero(); }
+    static Fp2 one() { return f2_one(); }
     static Fp2 inv(const Fp2& a) { return f2_inv(a); }
     static bool is_zero(const Fp2& a) { return f2_is_zero(a); }
     static bool eq(const Fp2& a, const Fp2& b) { return f2_eq(a, b); }
@@ -251,6 +316,63 @@ template <class PT, class F> static PT pt_mul(const PT& p, const uint64_t* k, in
     }
     return acc;
 }
+// [k] P in Jacobian coordinates (y^2 = x^3 + b: a = 0), no inversion on the way: the subgroup checks [r] P = O of every decoded point and the
+// verifiers' small products over the public inputs were 255 affine steps with a Fermat inversion each (15-20 ms per point: most of a verify).
+// Complete for what it is used on: the addition falls back to a doubling / the identity when the running point meets +-P (points of small order do).
+template <class F> struct Jac { F X, Y, Z; };          // Z = 0: the identity
+template <class F> static Jac<F> jac_dbl(const Jac<F>& t) {
+    typedef Ops<F> O;
+    if (O::is_zero(t.Z) || O::is_zero(t.Y)) return Jac<F>{O::one(), O::one(), O::zero()};
+    const F A = O::sqr(t.X), B = O::sqr(t.Y), C = O::sqr(B);
+    F D = O::sub(O::sub(O::sqr(O::add(t.X, B)), A), C);
+    D = O::add(D, D);
+    const F E = O::add(O::add(A, A), A), Fq = O::sqr(E);
+    Jac<F> r;
+    r.X = O::sub(Fq, O::add(D, D));
+    F C8 = O::add(C, C); C8 = O::add(C8, C8); C8 = O::add(C8, C8);
+    r.Y = O::sub(O::mul(E, O::sub(D, r.X)), C8);
+    const F YZ = O::mul(t.Y, t.Z);
+    r.Z = O::add(YZ, YZ);
+    return r;
+}
+template <class PT, class F> static Jac<F> jac_madd(const Jac<F>& t, const PT& p) {          // t + p, p affine and not the identity
+    typedef Ops<F> O;
+    if (O::is_zero(t.Z)) return Jac<F>{p.x, p.y, O::one()};
+    const F ZZ = O::sqr(t.Z), U2 = O::mul(p.x, ZZ), S2 = O::mul(p.y, O::mul(t.Z, ZZ));
+    const F H = O::sub(U2, t.X), R = O::sub(S2, t.Y);
+    if (O::is_zero(H)) {
+        if (O::is_zero(R)) return jac_dbl(t);
+        return Jac<F>{O::one(), O::one(), O::zero()};
+    }
+    const F HH = O::sqr(H), HHH = O::mul(H, HH), V = O::mul(t.X, HH);
+    Jac<F> r;
+    r.X = O::sub(O::sub(O::sqr(R), HHH), O::add(V, V));
+    r.Y = O::sub(O::mul(R, O::sub(V, r.X)), O::mul(t.Y, HHH));
+    r.Z = O::mul(t.Z, H);
+    return r;
+}
+template <class PT, class F> static Jac<F> jac_mul(const PT& p, const uint64_t* k, int nlimbs) {
+    typedef Ops<F> O;
+    Jac<F> acc{O::one(), O::one(), O::zero()};
+    if (p.inf) return acc;
+    for (int i = nlimbs * 64 - 1; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((k[i / 64] >> (i % 64)) & 1) acc = jac_madd<PT, F>(acc, p);
+    }
+    return acc;
+}
+template <class PT, class F> static PT jac_to_affine(const Jac<F>& t) {
+    typedef Ops<F> O;
+    PT r;
+    if (O::is_zero(t.Z)) { r.inf = true; r.x = O::zero(); r.y = O::zero(); return r; }
+    const F zi = O::inv(t.Z), zi2 = O::sqr(zi);
+    r.inf = false;
+    r.x = O::mul(t.X, zi2);
+    r.y = O::mul(t.Y, O::mul(zi2, zi));
+    return r;
+}
+template <class PT, class F> static bool in_subgroup(const PT& p) { return Ops<F>::is_zero(jac_mul<PT, F>(p, HP_R, 4).Z); }
+
 // ZCash uncompressed decoding + curve and subgroup membership; 0 ok, else a ZK_ERR code
 static int g1_decode(G1& out, const uint8_t* b) {
     if (b[0] & 0x80) return ZK_ERR_ARG;
@@ -259,7 +381,7 @@ static int g1_decode(G1& out, const uint8_t* b) {
     out.inf = false;
     const Fp rhs = fp_add(fp_mul(fp_sqr(out.x), out.x), fp_from_u64(4));
     if (!fp_eq(fp_sqr(out.y), rhs)) return ZK_ERR_NOT_ON_CURVE;
-    if (!pt_mul<G1, Fp>(out, HP_R, 4).inf) return ZK_ERR_NOT_ON_CURVE;
+    if (!in_subgroup<G1, Fp>(out)) return ZK_ERR_NOT_ON_CURVE;
     return ZK_OK;
 }
 static int g2_decode(G2& out, const uint8_t* b) {
@@ -270,7 +392,7 @@ static int g2_decode(G2& out, const uint8_t* b) {
     const Fp four = fp_from_u64(4);
     const Fp2 rhs = f2_add(f2_mul(f2_mul(out.x, out.x), out.x), f2(four, four));
     if (!f2_eq(f2_mul(out.y, out.y), rhs)) return ZK_ERR_NOT_ON_CURVE;
-    if (!pt_mul<G2, Fp2>(out, HP_R, 4).inf) return ZK_ERR_NOT_ON_CURVE;
+    if (!in_subgroup<G2, Fp2>(out)) return ZK_ERR_NOT_ON_CURVE;
     return ZK_OK;
 }
 
@@ -307,36 +429,84 @@ static bool fp_is_large(const Fp& a) {
     return false;
 }
 
-// Miller loop f_{|x|,Q}(P) over E(Fp12) with the untwisted Q, conjugated at the end (x < 0)
-static Fp12 miller_loop(const G1& p, const G2& q) {
-    if (p.inf || q.inf) return f12_one();
-    const Fp12 px = f12_from_fp(p.x), py = f12_from_fp(p.y);
-    const Fp12 w = Fp12{f6_zero(), f6_one()};
-    const Fp12 w2 = f12_mul(w, w), w3 = f12_mul(w2, w);
-    const Fp12 qx = f12_mul(f12_from_fp2(q.x), f12_inv(w2)), qy = f12_mul(f12_from_fp2(q.y), f12_inv(w3));
-    Fp12 tx = qx, ty = qy, f = f12_one();
-    const Fp12 two = f12_from_fp(fp_from_u64(2)), three = f12_from_fp(fp_from_u64(3));
+// prod_i f_{|x|,Q_i}(P_i) over E(Fp12) with the untwisted Q_i, conjugated at the end (x < 0) -- the header comment says how the values of the dense
+// formulation are kept.  Pairs with an identity point contribute 1 (and are skipped).
+static Fp12 miller_product(const std::vector<G1>& ps, const std::vector<G2>& qs) {
+    std::vector<size_t> live;
+    for (size_t i = 0; i < ps.size(); i++)
+        if (!ps[i].inf && !qs[i].inf) live.push_back(i);
+    Fp12 f = f12_one();
+    const size_t n = live.size();
+    if (!n) return f;
+    const Fp2 inv_xi = f2_inv(f2(fp_one(), fp_one()));
+    std::vector<G2> t(n);
+    std::vector<Fp2> den(n), pre(n), lam(n);
+    for (size_t k = 0; k < n; k++) t[k] = qs[live[k]];
+    // lam[k] = num[k] / den[k] for all pairs with ONE field inversion: prefix products, invert the total, walk back
+    auto batch_div = [&](const std::vector<Fp2>& num) {
+        Fp2 run = f2_one();
+        for (size_t k = 0; k < n; k++) { pre[k] = run; run = f2_mul(run, den[k]); }
+        Fp2 inv = f2_inv(run);
+        for (size_t k = n; k-- > 0;) {
+            lam[k] = f2_mul(num[k], f2_mul(inv, pre[k]));
+            inv = f2_mul(inv, den[k]);
+        }
+    };
+    // f <- f * l_k(P_k) for the lines of slope lam[k] through T_k, then T_k <- the third point of the line and `other`
+    auto lines_and_steps = [&](const std::vector<G2>* other) {
+        for (size_t k = 0; k < n; k++) {
+            const G1& P = ps[live[k]];
+            const Fp2 B = f2_mul(f2_sub(f2_mul(lam[k], t[k].x), t[k].y), inv_xi);          // (lam' x' - y') / xi   on v w   (= 1 / w^3)
+            const Fp2 C = f2_neg(f2_mul(f2_mul_fp(lam[k], P.x), inv_xi));                   // - lam' xP / xi        on v^2 w (= 1 / w)
+            f = f12_mul_line(f, P.y, B, C);
+            const Fp2& ox = other ? (*other)[k].x : t[k].x;
+            const Fp2 nx = f2_sub(f2_sub(f2_sqr(lam[k]), t[k].x), ox);
+            const Fp2 ny = f2_sub(f2_mul(lam[k], f2_sub(t[k].x, nx)), t[k].y);
+            t[k].x = nx; t[k].y = ny;
+        }
+    };
+    std::vector<G2> q0(n);
+    for (size_t k = 0; k < n; k++) q0[k] = qs[live[k]];
+    std::vector<Fp2> num(n);
     int top = 63;
     while (!((HP_BLS_X >> top) & 1)) top--;
     for (int i = top - 1; i >= 0; i--) {
-        Fp12 lam = f12_mul(f12_mul(three, f12_mul(tx, tx)), f12_inv(f12_mul(two, ty)));
-        Fp12 line = f12_sub(f12_sub(py, ty), f12_mul(lam, f12_sub(px, tx)));
-        f = f12_mul(f12_mul(f, f), line);
-        Fp12 nx = f12_sub(f12_sub(f12_mul(lam, lam), tx), tx);
-        Fp12 ny = f12_sub(f12_mul(lam, f12_sub(tx, nx)), ty);
-        tx = nx; ty = ny;
+        f = f12_sqr(f);
+        for (size_t k = 0; k < n; k++) {          // tangent: 3 x^2 / (2 y); points of odd prime order never have y = 0
+            const Fp2 xx = f2_sqr(t[k].x);
+            num[k] = f2_add(f2_add(xx, xx), xx);
+            den[k] = f2_add(t[k].y, t[k].y);
+        }
+        batch_div(num);
+        lines_and_steps(nullptr);
         if ((HP_BLS_X >> i) & 1) {
-            lam = f12_mul(f12_sub(qy, ty), f12_inv(f12_sub(qx, tx)));
-            line = f12_sub(f12_sub(py, ty), f12_mul(lam, f12_sub(px, tx)));
-            f = f12_mul(f, line);
-            nx = f12_sub(f12_sub(f12_mul(lam, lam), tx), qx);
-            ny = f12_sub(f12_mul(lam, f12_sub(tx, nx)), ty);
-            tx = nx; ty = ny;
+            for (size_t k = 0; k < n; k++) {      // chord through T and Q: T = [m] Q with 1 < m < r - 1 here, so the x-coordinates differ
+                num[k] = f2_sub(q0[k].y, t[k].y);
+                den[k] = f2_sub(q0[k].x, t[k].x);
+            }
+            batch_div(num);
+            lines_and_steps(&q0);
         }
     }
     return f12_conj(f);
 }
-static inline Fp12 final_exp(const Fp12& f) { return f12_pow(f, HP_FEXP, HP_FEXP_BITS); }
+// f^((p^12 - 1) / r) as ONE power: the definition (and round 1-4's implementation); kept for the tests
+static inline Fp12 final_exp_plain(const Fp12& f) { return f12_pow(f, HP_FEXP, HP_FEXP_BITS); }
+// m^|x| for the powers by the curve parameter
+static Fp12 f12_pow_x(const Fp12& m) {
+    const uint64_t e[1] = {HP_BLS_X};
+    return f12_pow(m, e, 64);
+}
+// the same power, factored (header comment).  After the easy part m lies in the cyclotomic subgroup, where the inverse is the conjugate: m^x = conj(m^|x|).
+static Fp12 final_exp(const Fp12& f) {
+    Fp12 m = f12_mul(f12_conj(f), f12_inv(f));                          // f^(p^6 - 1)
+    m = f12_mul(f12_frob(f12_frob(m)), m);                               // ^(p^2 + 1)
+    const Fp12 a = f12_pow(m, HP_E1, HP_E1_BITS);                        // ^e1
+    const Fp12 b = f12_mul(f12_conj(f12_pow_x(a)), f12_frob(a));         // ^(x + p)
+    const Fp12 bx2 = f12_pow_x(f12_pow_x(b));                            // b^(x^2): two conjugations cancel
+    const Fp12 c = f12_mul(f12_mul(bx2, f12_frob(f12_frob(b))), f12_conj(b));      // ^(x^2 + p^2 - 1)
+    return f12_mul(c, m);                                                // ... + 1
+}
 
 static void gt_to_bytes(uint8_t* out, const Fp12& g) {
     const Fp2* c[6] = {&g.c0.c0, &g.c0.c1, &g.c0.c2, &g.c1.c0, &g.c1.c1, &g.c1.c2};
@@ -368,7 +538,7 @@ template <class PT, class F> static int dot_host(PT& acc, const std::vector<PT>&
     for (size_t k = 0; k < pts.size(); k++) {
         uint64_t c[4];
         ZKCHK(fr_limbs(c, scalars + 32 * k));
-        acc = hp::pt_add<PT, F>(acc, hp::pt_mul<PT, F>(pts[k], c, 4));
+        acc = hp::pt_add<PT, F>(acc, hp::jac_to_affine<PT, F>(hp::jac_mul<PT, F>(pts[k], c, 4)));
     }
     return ZK_OK;
 }
@@ -379,16 +549,15 @@ extern "C" {
 
 int zk_pairing_product(const uint8_t* g1_points, const uint8_t* g2_points, size_t n, uint8_t gt_out[576]) {
     if ((n && (!g1_points || !g2_points)) || !gt_out) ZK_FAIL(ZK_ERR_ARG, "zk_pairing_product: null argument");
-    hp::Fp12 f = hp::f12_one();
+    std::vector<hp::G1> ps(n);
+    std::vector<hp::G2> qs(n);
     for (size_t i = 0; i < n; i++) {
-        hp::G1 p;
-        hp::G2 q;
-        int rc = hp::g1_decode(p, g1_points + 96 * i);
+        int rc = hp::g1_decode(ps[i], g1_points + 96 * i);
         if (rc) ZK_FAIL(rc, "zk_pairing_product: bad G1 point (encoding, curve or subgroup)");
-        rc = hp::g2_decode(q, g2_points + 192 * i);
+        rc = hp::g2_decode(qs[i], g2_points + 192 * i);
         if (rc) ZK_FAIL(rc, "zk_pairing_product: bad G2 point (encoding, curve or subgroup)");
-        f = hp::f12_mul(f, hp::miller_loop(p, q));
     }
+    const hp::Fp12 f = hp::miller_product(ps, qs);
     hp::gt_to_bytes(gt_out, hp::final_exp(f));
     return ZK_OK;
 }
@@ -415,7 +584,7 @@ int zk_g1_decompress(const uint8_t in[48], uint8_t out[96]) {
     if (!hp::fp_from_be(p.x, xb)) ZK_FAIL(ZK_ERR_ARG, "zk_g1_decompress: x >= p");
     if (!hp::fp_sqrt(p.y, hp::fp_add(hp::fp_mul(hp::fp_sqr(p.x), p.x), hp::fp_from_u64(4)))) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g1_decompress: x is not on the curve");
     if (hp::fp_is_large(p.y) != ((in[0] & 0x20) != 0)) p.y = hp::fp_neg(p.y);
-    if (!hp::pt_mul<hp::G1, hp::Fp>(p, HP_R, 4).inf) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g1_decompress: not in the prime-order subgroup");
+    if (!hp::in_subgroup<hp::G1, hp::Fp>(p)) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g1_decompress: not in the prime-order subgroup");
     hp::fp_to_be(out, p.x);
     hp::fp_to_be(out + 48, p.y);
     return ZK_OK;
@@ -435,7 +604,7 @@ int zk_g2_decompress(const uint8_t in[96], uint8_t out[192]) {
     if (!hp::f2_sqrt(p.y, hp::f2_add(hp::f2_mul(hp::f2_mul(p.x, p.x), p.x), hp::f2(four, four)))) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g2_decompress: x is not on the curve");
     const bool large = hp::fp_is_zero(p.y.b) ? hp::fp_is_large(p.y.a) : hp::fp_is_large(p.y.b);
     if (large != ((in[0] & 0x20) != 0)) p.y = hp::f2_neg(p.y);
-    if (!hp::pt_mul<hp::G2, hp::Fp2>(p, HP_R, 4).inf) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g2_decompress: not in the prime-order subgroup");
+    if (!hp::in_subgroup<hp::G2, hp::Fp2>(p)) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "zk_g2_decompress: not in the prime-order subgroup");
     hp::fp_to_be(out, p.x.b);
     hp::fp_to_be(out + 48, p.x.a);
     hp::fp_to_be(out + 96, p.y.b);
@@ -456,9 +625,7 @@ int zk_groth16_verify(const uint8_t ab[576], const uint8_t* ltgm_io, const uint8
     }
     hp::G1 acc;
     ZKCHK((dot_host<hp::G1, hp::Fp>(acc, pts, io_scalars)));
-    hp::Fp12 f = hp::miller_loop(A, B);
-    f = hp::f12_mul(f, hp::miller_loop(g1_neg(acc), GM));
-    f = hp::f12_mul(f, hp::miller_loop(g1_neg(Cc), D));
+    const hp::Fp12 f = hp::miller_product({A, g1_neg(acc), g1_neg(Cc)}, {B, GM, D});          // three pairs in lockstep
     uint8_t gt[576];
     hp::gt_to_bytes(gt, hp::final_exp(f));
     *ok = memcmp(gt, ab, 576) == 0 ? 1 : 0;
@@ -482,14 +649,13 @@ int zk_pinocchio_verify(const uint8_t* vk_g1, const uint8_t* vk_g2, const uint8_
     }
     HP_DECODE1(vv, proof) HP_DECODE2(ww, proof + 96) HP_DECODE1(yy, proof + 288) HP_DECODE1(h, proof + 384)
     HP_DECODE1(vavv, proof + 480) HP_DECODE2(waww, proof + 576) HP_DECODE1(yayy, proof + 768) HP_DECODE1(bvwy, proof + 864)
-    auto is_one = [](const hp::Fp12& f) { return hp::f12_eq(hp::final_exp(f), hp::f12_one()); };
-    using hp::f12_mul; using hp::miller_loop;
+    // every equation of Verify.f is one product of pairings = 1: its pairs walk the Miller loop in lockstep, one final exponentiation each
+    auto is_one = [](std::vector<hp::G1> ps, std::vector<hp::G2> qs) { return hp::f12_eq(hp::final_exp(hp::miller_product(ps, qs)), hp::f12_one()); };
     bool good = true;
-    good &= is_one(f12_mul(miller_loop(vv, av), miller_loop(g1_neg(vavv), one2)));                      // :285
-    good &= is_one(f12_mul(miller_loop(aw, ww), miller_loop(g1_neg(one), waww)));                       // :298
-    good &= is_one(f12_mul(miller_loop(yy, ay), miller_loop(g1_neg(yayy), one2)));                      // :311
-    good &= is_one(f12_mul(f12_mul(miller_loop(bvwy, gm2), miller_loop(g1_neg(vv), bgm2)),
-                           f12_mul(miller_loop(g1_neg(bgm), ww), miller_loop(g1_neg(yy), bgm2))));       // :361-366
+    good &= is_one({vv, g1_neg(vavv)}, {av, one2});                                                      // :285
+    good &= is_one({aw, g1_neg(one)}, {ww, waww});                                                       // :298
+    good &= is_one({yy, g1_neg(yayy)}, {ay, one2});                                                      // :311
+    good &= is_one({bvwy, g1_neg(vv), g1_neg(bgm), g1_neg(yy)}, {gm2, bgm2, ww, bgm2});                   // :361-366
     hp::G1 vio, yio;
     hp::G2 wio;
     ZKCHK((dot_host<hp::G1, hp::Fp>(vio, vv_io, io_scalars)));
@@ -497,7 +663,7 @@ int zk_pinocchio_verify(const uint8_t* vk_g1, const uint8_t* vk_g2, const uint8_
     ZKCHK((dot_host<hp::G2, hp::Fp2>(wio, ww_io, io_scalars)));
     const hp::G1 vsum = hp::pt_add<hp::G1, hp::Fp>(vio, vv), ysum = hp::pt_add<hp::G1, hp::Fp>(yio, yy);
     const hp::G2 wsum = hp::pt_add<hp::G2, hp::Fp2>(wio, ww);
-    good &= is_one(f12_mul(f12_mul(miller_loop(vsum, wsum), miller_loop(g1_neg(ysum), one2)), miller_loop(g1_neg(h), yt)));   // :418-420
+    good &= is_one({vsum, g1_neg(ysum), g1_neg(h)}, {wsum, one2, yt});                                   // :418-420
     *ok = good ? 1 : 0;
     return ZK_OK;
 }
