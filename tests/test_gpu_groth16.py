@@ -252,8 +252,7 @@ def test_lagrange_form_key_gives_the_same_proofs(maker):
     std.close(); lag.close()
 
 
-# 2^20 (42 s, 27 of them the derivation) runs with ZK_TEST_FULL=1; every driver run of bench.py derives the 2^20 and 2^22 keys and holds their proofs to the oracle
-@pytest.mark.parametrize("log_n", [16, 18, 20] if os.environ.get("ZK_TEST_FULL") else [16, 18])
+@pytest.mark.parametrize("log_n", [16, 18, 20])          # 2^20: 42 s, 27 of them the derivation -- every byte of the derived pools at BASELINE config 3's size
 def test_derived_key_at_the_config_sizes(log_n):
     """The path bench.py's headline runs: a key in the REFERENCE's format at BASELINE's sizes (2^16 = config 2, 2^18, 2^20 =
     config 3's size), its Lagrange form derived on the device (zk_groth16_pk_derive_lagrange, no tau), then proofs -- one at a time and pipelined
