@@ -16,7 +16,7 @@
 // NonZK.prove (Compute.f) is the same with dv = dw = dy = 0.
 //
 // The COMPACT h pool (round 5; default, ZK_PIN_COMPACT_H=0 / a key that fails the check below keeps the layout above).  v_all[k] = [v_k(s)] and
-// w_all[k] = [w_k(s)] are 2 m of the h product's n + 1 + 2 m points (4 n of 5 n in the iterated-cubic benchmark) and serve the blinding only:
+// w_all[k] = [w_k(s)] are 2 m of the h product's n + 1 + 2 m points (2 n + 4 of 3 n + 5 in the iterated-cubic benchmark) and serve the blinding only:
 //   sum_k (dw c_k) [v_k(s)] = dw [v(s)],   v = sum_k c_k v_k  -- the very polynomial QAP.eval builds,
 // so with the coefficients of v, w the prover already holds (the tau-power Fr stage) the two terms ride on si:
 //   h' = <si, h + dv dw Z - dy e_0 + dw v + dv w>                                    n + 1 points,
