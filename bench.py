@@ -274,6 +274,12 @@ def roofline_objects(fam_timed, n_timed, fam_alone, n_alone, pairs, world, windo
             o["achieved"], o["frac"], o["frac_is"] = o["one_proof_in_flight"]["achieved"], o["one_proof_in_flight"]["frac"], "un-overlapped launch (one proof in flight)"
         elif "timed_region" in o:
             o["achieved"], o["frac"], o["frac_is"] = o["timed_region"]["achieved"], o["timed_region"]["frac"], "launch inside the timed region (no un-overlapped pass at N > 1)"
+        # the rate the launch REALLY moves HBM bytes at: the PMC bytes per launch (profiles/) over this run's live launch time -- north_star's "rocprof-reported
+        # achieved HBM GB/s ... against gfx950 peak" (the algorithmic figure above counts what the problem needs, this one what the kernel fetched and wrote)
+        live = o.get("one_proof_in_flight") or o.get("timed_region")
+        if t and live and live.get("avg_launch_ms"):
+            o["traffic_gbs"] = t / (live["avg_launch_ms"] * live.get("launches_per_proof", 1.0) * 1e-3) / 1e9
+            o["traffic_frac"] = o["traffic_gbs"] / HBM_PEAK_GBS
         objs[key] = o
     return objs
 
@@ -683,7 +689,7 @@ def compact_line(full):
         t = roof.get("one_proof_in_flight") or roof.get("timed_region") or {}
         out["roofline"] = {"kernel": roof.get("kernel"), "bound": roof.get("bound"), "peak": roof.get("peak"), "unit": roof.get("unit"),
                            "algorithmic_bytes_per_launch": t.get("algorithmic_bytes_per_launch"), "avg_launch_ms": t.get("avg_launch_ms"),
-                           "achieved": roof.get("achieved"), "frac": roof.get("frac"), "traffic": roof.get("traffic"),
+                           "achieved": roof.get("achieved"), "frac": roof.get("frac"), "traffic": roof.get("traffic"), "traffic_gbs": roof.get("traffic_gbs"), "traffic_frac": roof.get("traffic_frac"),
                            "alu_frac": (t.get("alu") or {}).get("frac"), "alu_frac_hw": (t.get("alu") or {}).get("frac_hw"),
                            "alu_peak_hw": "%.1f G Fp products/s = 1024 SIMDs x 2.4 GHz / 5 cyc per v_mad_u64_u32 x 64 lanes / 392 mads" % ALU_PEAK_HW,
                            "measured": roof.get("frac_is")}
