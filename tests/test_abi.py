@@ -134,6 +134,6 @@ def test_set_option_accepts_the_public_knobs_and_nothing_else():
     L = _lib.lib()
     assert L.zk_set_option(b"no_such_knob", b"1") == -1 and L.zk_set_option(None, b"1") == -1 and L.zk_set_option(b"", b"1") == -1
     assert L.zk_set_option(b"test_forms", b"1") == -1                  # test-only switches stay environment-only
-    for name in (b"msm_window", b"ZK_MSM_WINDOW", b"Msm_Window", b"key_subgroup_check", b"slot_streams", b"graph", b"derive_side_by_side", b"pin_compact_h"):
+    for name in (b"msm_window", b"ZK_MSM_WINDOW", b"Msm_Window", b"key_subgroup_check", b"slot_streams", b"graph", b"derive_side_by_side", b"pin_compact_h", b"PIN_SHARED_SORT"):
         assert L.zk_set_option(name, b"16") == 0
         assert L.zk_set_option(name, None) == 0
