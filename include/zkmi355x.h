@@ -115,6 +115,13 @@ int zk_g1_compress(const uint8_t in[96], uint8_t out[48]);
 int zk_g1_decompress(const uint8_t in[48], uint8_t out[96]);
 int zk_g2_decompress(const uint8_t in[96], uint8_t out[192]);
 int zk_g2_compress(const uint8_t in[192], uint8_t out[96]);
+/* The same of_compressed_bytes_exn over a whole list ON THE GPU (round 5): the reference's JSON holds every key point compressed (groth16.ml:24-34,
+ * pinocchio.ml:37-60 through curve.ml:199-219), and a 2^20-constraint key is five million square roots and subgroup checks -- half an hour of one
+ * host core through the calls above, about a second here.  n points in, n uncompressed points out; ZK_ERR_ARG when some point's compression flag is
+ * missing or a coordinate is >= p, ZK_ERR_NOT_ON_CURVE when some abscissa is not on the curve or some point lies outside the prime-order subgroup
+ * (the verdicts of the one-point calls; with several bad points in a list, the encoding error is reported first). */
+int zk_g1_decompress_batch(const uint8_t* in /* n*48 */, size_t n, uint8_t* out /* n*96 */);
+int zk_g2_decompress_batch(const uint8_t* in /* n*96 */, size_t n, uint8_t* out /* n*192 */);
 
 /* ---- protocol seam: Groth16.Make(C).prove (src/groth16/groth16.ml:235-237) -------------------
  * The circuit enters as sparse R1CS rows instead of the dense QAP.t (which is 3*m*n field

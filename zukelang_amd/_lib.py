@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("ZK_LIBZKMI355X_PATH") or os.path.join(_HERE, "libzkmi
 EXPORTS = [
     "zk_strerror", "zk_last_error", "zk_device_count", "zk_init", "zk_shutdown", "zk_set_devices", "zk_set_device_list", "zk_get_device_list", "zk_set_option",
     "zk_fr_ntt", "zk_fr_poly_mul", "zk_fr_spmv", "zk_msm_g1", "zk_msm_g2", "zk_g1_of_fr", "zk_g2_of_fr",
-    "zk_g1_powers", "zk_g2_powers", "zk_g1_compress", "zk_g2_compress", "zk_g1_decompress", "zk_g2_decompress",
+    "zk_g1_powers", "zk_g2_powers", "zk_g1_compress", "zk_g2_compress", "zk_g1_decompress", "zk_g2_decompress", "zk_g1_decompress_batch", "zk_g2_decompress_batch",
     "zk_groth16_pk_upload", "zk_groth16_pk_upload_lagrange", "zk_groth16_pk_derive_lagrange", "zk_groth16_lagrange_pool_sizes", "zk_groth16_pk_derive_lagrange_sets", "zk_groth16_pk_install_lagrange", "zk_groth16_pk_shard", "zk_groth16_shard_range", "zk_groth16_pool_points", "zk_groth16_pk_free", "zk_groth16_prove", "zk_groth16_reserve_slots", "zk_groth16_prove_async", "zk_groth16_prove_wait", "zk_groth16_set_witness", "zk_groth16_qap_eval",
     "zk_groth16_pk_upload_sharded", "zk_groth16_prove_partial", "zk_groth16_prove_partial_async", "zk_groth16_prove_partial_wait", "zk_groth16_combine", "zk_groth16_prove_partial_wait_device", "zk_groth16_combine_device",
     "zk_groth16_pool_layout", "zk_groth16_scalars_async", "zk_groth16_scalars_wait", "zk_groth16_msm_partial_async",

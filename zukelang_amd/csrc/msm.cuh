@@ -128,6 +128,8 @@ int proof_points_to_bytes_dev(const void* d_g1, uint32_t n1, const uint32_t* off
 // bytes (device copy of host encoding) -> affine Montgomery; *d_flag |= 1 not on curve, |= 2 bad encoding
 int points_bytes_to_affine(Curve curve, void* d_affine, const void* d_bytes, uint64_t n, int* d_flag, hipStream_t s);
 int points_affine_to_bytes(Curve curve, void* d_bytes, const void* d_affine, uint64_t n, hipStream_t s);
+// n ZCash-COMPRESSED points (host, 48 / 96 B) -> uncompressed (host, 96 / 192 B): square roots, curve and subgroup checks on the device (msm_points.hip)
+int points_decompress(Curve curve, const uint8_t* in, uint64_t n, uint8_t* out, hipStream_t s);
 // out[i] = scalars[i] * G (affine Montgomery on device); scalars canonical on device
 int fixed_base_mul(Curve curve, void* d_affine_out, const void* d_scalars, uint64_t n, hipStream_t s);
 // acc[i] = sum_j parts[j*stride + i] over j < count   (XYZZ, tiny: cross-GPU partial reduction)

@@ -427,6 +427,13 @@ int zk_msm_g1(const uint8_t* bases, size_t nbases, const uint8_t* scalars, size_
 int zk_msm_g2(const uint8_t* bases, size_t nbases, const uint8_t* scalars, size_t nscalars, uint32_t window_bits, uint8_t out[192]) {
     return msm_api(CURVE_G2, bases, nbases, scalars, nscalars, window_bits, out);
 }
+static int decompress_api(Curve curve, const uint8_t* in, size_t n, uint8_t* out) {
+    if (n && (!in || !out)) ZK_FAIL(ZK_ERR_ARG, "decompress_batch: null");
+    ZKCHK(ensure_init());
+    return points_decompress(curve, in, n, out, ctx().stream);
+}
+int zk_g1_decompress_batch(const uint8_t* in, size_t n, uint8_t* out) { return decompress_api(CURVE_G1, in, n, out); }
+int zk_g2_decompress_batch(const uint8_t* in, size_t n, uint8_t* out) { return decompress_api(CURVE_G2, in, n, out); }
 int zk_g1_of_fr(const uint8_t* scalars, size_t n, uint8_t* out) { return of_fr_api(CURVE_G1, scalars, n, out); }
 int zk_g2_of_fr(const uint8_t* scalars, size_t n, uint8_t* out) { return of_fr_api(CURVE_G2, scalars, n, out); }
 int zk_g1_powers(uint32_t d, const uint8_t s[32], uint8_t* out) { return powers_api(CURVE_G1, d, s, out); }

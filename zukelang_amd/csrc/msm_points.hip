@@ -103,6 +103,109 @@ __global__ __launch_bounds__(64) void k_proof_to_bytes(const uint8_t* g1, uint32
     else aff_encode(out + off.g2[b - n1], xyzz_to_aff(xyzz_load<Fp2>(g2 + 384 * (size_t)(b - n1))));
 }
 
+// ------------------------------------------------------------------ of_compressed_bytes_exn over whole lists (curve.ml:199-212; round 5)
+// The reference's JSON holds every key point COMPRESSED (Bls12_381.G1/G2.to_compressed_bytes): a 2^20-constraint key is five million square roots and
+// subgroup checks on the way in -- half an hour of one host core through zk_g1/g2_decompress, a second here.  One lane per point: x from its 48 / 96
+// big-endian bytes, y = sqrt(x^3 + b) by the power (p + 1) / 4 (p = 3 mod 4; in Fp2 through the norm), the sign bit's choice of root, then the
+// subgroup check and the encoder above.  Same verdicts as the host functions: flag 2 = bad encoding (compression bit missing, coordinate >= p),
+// 1 = x is not the abscissa of a curve point.
+__device__ static const uint32_t FP_SQRT_EXP[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                                    0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};      // (p + 1) / 4, 379 bits
+__device__ static const uint32_t FP_HALF_PM1[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
+                                                    0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};      // (p - 1) / 2
+template <int A> FF_INLINE FpB<2> fp_red2(const FpB<A>& a) { return fe_mul(a, fp_one()); }          // the same value below 2 p
+__device__ __noinline__ FpB<2> fp_pow_sqrt(const FpB<2>& a) {          // a^((p + 1) / 4): the exponent is a constant, every lane takes the same branches
+    FpB<2> acc = fp_one();
+    for (int i = 378; i >= 0; i--) {
+        acc = fe_sqr(acc);
+        if ((FP_SQRT_EXP[i >> 5] >> (i & 31)) & 1u) acc = fe_mul(acc, a);
+    }
+    return acc;
+}
+FF_INLINE bool fp_sqrt_dev(FpB<2>& out, const FpB<2>& a) {
+    out = fp_pow_sqrt(a);
+    return fe_eq(fe_sqr(out), a);
+}
+template <int A> FF_INLINE bool fp_is_large(const FpB<A>& y) {          // canonical integer of y > (p - 1) / 2: the ZCash sign of a coordinate
+    const FpWords w = fp_from_mont(y);
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int k = 11; k >= 0; k--)
+        if (!decided && w.w[k] != FP_HALF_PM1[k]) { gt = w.w[k] > FP_HALF_PM1[k]; decided = true; }
+    return gt;
+}
+// a square root of a in Fp2 = Fp[u] / (u^2 + 1) (either one: the caller fixes the sign); false: a is not a square
+FF_INLINE bool fp2_sqrt_dev(Fp2B<2>& out, const Fp2B<2>& a) {
+    if (fe_is_zero(a.c1)) {
+        FpB<2> r;
+        if (fp_sqrt_dev(r, a.c0)) { out = {r, fp_zero()}; return true; }
+        if (fp_sqrt_dev(r, fp_red2(fe_neg(a.c0)))) { out = {fp_zero(), r}; return true; }          // (r u)^2 = -r^2
+        return false;
+    }
+    FpB<2> s;
+    if (!fp_sqrt_dev(s, fp_red2(fe_add(fe_sqr(a.c0), fe_sqr(a.c1))))) return false;                 // the norm of a square is a square
+    const FpB<2> half = fe_inv(fe_dbl(fp_one()));
+    FpB<2> x0;
+    if (!fp_sqrt_dev(x0, fe_mul(fe_add(a.c0, s), half)) && !fp_sqrt_dev(x0, fe_mul(fe_sub(a.c0, s), half))) return false;
+    const FpB<2> x1 = fe_mul(a.c1, fe_inv(fe_dbl(x0)));
+    out = {x0, x1};
+    const Fp2B<4> sq = fe_sqr(out);
+    return fe_eq(sq.c0, a.c0) && fe_eq(sq.c1, a.c1);
+}
+__global__ __launch_bounds__(128) void k_decompress_g1(uint8_t* __restrict__ dense, const uint8_t* __restrict__ in, uint64_t n, int* flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    alignas(16) uint8_t xb[48];
+    for (int k = 0; k < 48; k++) xb[k] = in[48 * i + k];
+    const uint8_t f0 = xb[0];
+    xb[0] &= 0x1f;
+    Aff<Fp> out = aff_inf<Fp>();
+    if (!(f0 & 0x80)) atomicOr(flag, 2);
+    else if (!(f0 & 0x40)) {
+        const FpWords xw = fpw_from_be(xb);
+        if (!fpw_canonical(xw)) atomicOr(flag, 2);
+        else {
+            const FpB<2> x = fp_to_mont(xw);
+            const FpB<2> rhs = fp_red2(fe_add(fe_mul(fe_sqr(x), x), FieldOps<Fp>::curve_b()));
+            FpB<2> y;
+            if (!fp_sqrt_dev(y, rhs)) atomicOr(flag, 1);
+            else {
+                if (fp_is_large(y) != ((f0 & 0x20) != 0)) y = fp_red2(fe_neg(y));
+                out = {x, y};
+            }
+        }
+    }
+    aff_store<Fp>(dense + 96 * i, out);
+}
+__global__ __launch_bounds__(128) void k_decompress_g2(uint8_t* __restrict__ dense, const uint8_t* __restrict__ in, uint64_t n, int* flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    alignas(16) uint8_t xb[96];          // x.c1 (with the flags) | x.c0
+    for (int k = 0; k < 96; k++) xb[k] = in[96 * i + k];
+    const uint8_t f0 = xb[0];
+    xb[0] &= 0x1f;
+    Aff<Fp2> out = aff_inf<Fp2>();
+    if (!(f0 & 0x80)) atomicOr(flag, 2);
+    else if (!(f0 & 0x40)) {
+        const FpWords x1w = fpw_from_be(xb), x0w = fpw_from_be(xb + 48);
+        if (!fpw_canonical(x1w) || !fpw_canonical(x0w)) atomicOr(flag, 2);
+        else {
+            const Fp2B<2> x = {fp_to_mont(x0w), fp_to_mont(x1w)};
+            const auto cube = fe_mul(fe_sqr(x), x);
+            const Fp2 b = FieldOps<Fp2>::curve_b();
+            const Fp2B<2> rhs = {fp_red2(fe_add(cube.c0, b.c0)), fp_red2(fe_add(cube.c1, b.c1))};
+            Fp2B<2> y;
+            if (!fp2_sqrt_dev(y, rhs)) atomicOr(flag, 1);
+            else {
+                const bool large = fe_is_zero(y.c1) ? fp_is_large(y.c0) : fp_is_large(y.c1);
+                if (large != ((f0 & 0x20) != 0)) y = {fp_red2(fe_neg(y.c0)), fp_red2(fe_neg(y.c1))};
+                out = {Fp2(x), Fp2(y)};
+            }
+        }
+    }
+    aff_store<Fp2>(dense + 192 * i, out);
+}
+
 // ------------------------------------------------------------------ prime-order subgroup check of uploaded KEY points: [r] P = O
 // The reference's points come from Bls12_381.G1/G2.of_bytes_exn / of_compressed_bytes_exn (curve.ml:199-212), which raise on a point of the curve
 // that lies outside the r-torsion; a key uploaded to the library as raw bytes gets the same treatment here.  Plain double-and-add over the bits of r
@@ -346,6 +449,36 @@ int fixed_base_mul(Curve curve, void* d_out, const void* d_scalars, uint64_t n, 
     HIPCHK(hipGetLastError());
     return ZK_OK;
 }
+// n compressed points (host) -> n uncompressed points (host), every one decoded, checked (curve, subgroup) and re-encoded on the device
+int points_decompress(Curve curve, const uint8_t* in, uint64_t n, uint8_t* out, hipStream_t s) {
+    if (!n) return ZK_OK;
+    const size_t cb = aff_bytes(curve) / 2, ub = aff_bytes(curve);
+    DevBuf din, dense, dout, flag;
+    ZKCHK(din.alloc(cb * n));
+    ZKCHK(dense.alloc(ub * n));
+    ZKCHK(dout.alloc(ub * n));
+    ZKCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
+    HIPCHK(hipMemcpyAsync(din.p, in, cb * n, hipMemcpyHostToDevice, s));
+    if (curve == CURVE_G1) {
+        hipLaunchKernelGGL(k_decompress_g1, grid_for(n, 128), dim3(128), 0, s, dense.as<uint8_t>(), (const uint8_t*)din.as<uint8_t>(), n, flag.as<int>());
+        hipLaunchKernelGGL(k_subgroup_check<Fp>, grid_for(n, 128), dim3(128), 0, s, (const uint8_t*)dense.as<uint8_t>(), n, flag.as<int>());
+    } else {
+        hipLaunchKernelGGL(k_decompress_g2, grid_for(n, 128), dim3(128), 0, s, dense.as<uint8_t>(), (const uint8_t*)din.as<uint8_t>(), n, flag.as<int>());
+        hipLaunchKernelGGL(k_subgroup_check<Fp2>, grid_for(n, 128), dim3(128), 0, s, (const uint8_t*)dense.as<uint8_t>(), n, flag.as<int>());
+    }
+    HIPCHK(hipGetLastError());
+    ZKCHK(points_affine_to_bytes(curve, dout.p, dense.p, n, s));
+    int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(out, dout.p, ub * n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h & 2) ZK_FAIL(ZK_ERR_ARG, "decompress: a point's compression flag is not set or a coordinate is >= p");
+    if (h & 1) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "decompress: an abscissa is not on the curve");
+    if (h & 4) ZK_FAIL(ZK_ERR_NOT_ON_CURVE, "decompress: a point is on the curve but outside the prime-order subgroup");
+    return ZK_OK;
+}
+
 // ---- may one product read another's sort?  (msm.cuh: msm_accumulate_sorted)
 __global__ void k_bytes_differ(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint64_t n, int* flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

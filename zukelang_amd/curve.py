@@ -124,15 +124,30 @@ class _Group:
         _lib.check(getattr(_lib.lib(), cls._compress)(_p(p), _p(out)))
         return bytes(out)
 
+    @classmethod
+    def of_compressed_bytes_many(cls, comp):
+        """of_compressed_bytes_exn (curve.ml:199-212) mapped over a list ON THE GPU (zk_g1/g2_decompress_batch): `comp` = the compressed points back
+        to back; returns the uncompressed points back to back.  Square roots, curve and subgroup checks per point, as the one-point host call."""
+        c = np.ascontiguousarray(np.frombuffer(bytes(comp), dtype=np.uint8))
+        n = len(c) // cls.COMPRESSED_BYTES
+        if len(c) != n * cls.COMPRESSED_BYTES:
+            raise AssertionError("compressed point list: length is not a multiple of the point size")
+        out = np.zeros(n * cls.POINT_BYTES, dtype=np.uint8)
+        if n:
+            _lib.check(getattr(_lib.lib(), cls._decompress_batch)(_p(c), C.c_size_t(n), _p(out)))
+        return bytes(out)
+
 
 class G1(_Group):
     POINT_BYTES, COMPRESSED_BYTES = 96, 48
     _msm, _of_fr, _powers, _compress = "zk_msm_g1", "zk_g1_of_fr", "zk_g1_powers", "zk_g1_compress"
+    _decompress_batch = "zk_g1_decompress_batch"
 
 
 class G2(_Group):
     POINT_BYTES, COMPRESSED_BYTES = 192, 96
     _msm, _of_fr, _powers, _compress = "zk_msm_g2", "zk_g2_of_fr", "zk_g2_powers", "zk_g2_compress"
+    _decompress_batch = "zk_g2_decompress_batch"
 
 
 class GT:

@@ -176,6 +176,26 @@ def g2_of_json(b):
     return _decompress(_lib.lib().zk_g2_decompress, b, 192)
 
 
+# A key is lists of thousands to millions of compressed points: from BATCH_MIN points up a list goes through the GPU in one call
+# (zk_g1/g2_decompress_batch: ~1 s for the five million points of a 2^20 key against half an hour of one host core), shorter ones -- proofs,
+# verification keys, the fixtures of the CPU tests -- through the one-point host calls.  Same checks, same bytes either way.
+BATCH_MIN = 256
+
+
+def g1s_of_json(bs):
+    if len(bs) < BATCH_MIN:
+        return b"".join(g1_of_json(b) for b in bs)
+    _need(all(len(b) == 48 for b in bs), "a compressed G1 point is 48 bytes")
+    return G1.of_compressed_bytes_many(b"".join(bs))
+
+
+def g2s_of_json(bs):
+    if len(bs) < BATCH_MIN:
+        return b"".join(g2_of_json(b) for b in bs)
+    _need(all(len(b) == 96 for b in bs), "a compressed G2 point is 96 bytes")
+    return G2.of_compressed_bytes_many(b"".join(bs))
+
+
 # ---- Groth16 (groth16.ml:110-114, 36-43, 24-34)
 def groth16_proof_to_json(proof):
     return dumps({"a": G1.to_compressed_bytes(proof.a), "b": G2.to_compressed_bytes(proof.b), "c": G1.to_compressed_bytes(proof.c)})
@@ -228,11 +248,10 @@ def groth16_pkey_of_json(data):
     from .groth16 import PKey
     import numpy as np
     d = loads(data)
-    g1 = [g1_of_json(d["a"]), g1_of_json(d["d1"]), g1_of_json(d["b1"])] + [g1_of_json(x) for x in d["ti1"]] + \
-         [g1_of_json(x) for x in d["tiztd"]] + [g1_of_json(b[1]) for b in d["ltd_mid"]]
-    g2 = [g2_of_json(d["b2"]), g2_of_json(d["d2"])] + [g2_of_json(x) for x in d["ti2"]]
+    g1 = g1s_of_json([d["a"], d["d1"], d["b1"]] + list(d["ti1"]) + list(d["tiztd"]) + [b[1] for b in d["ltd_mid"]])
+    g2 = g2s_of_json([d["b2"], d["d2"]] + list(d["ti2"]))
     mid_vars = [(b[0][0].decode("latin-1"), b[0][1]) for b in d["ltd_mid"]]
-    return PKey(np.frombuffer(b"".join(g1), dtype=np.uint8), np.frombuffer(b"".join(g2), dtype=np.uint8)), mid_vars
+    return PKey(np.frombuffer(g1, dtype=np.uint8), np.frombuffer(g2, dtype=np.uint8)), mid_vars
 
 
 # ---- Pinocchio proof (pinocchio.ml:195-208)
@@ -297,16 +316,16 @@ def pinocchio_pkey_of_json(data):
     import numpy as np
     d = loads(data)
     vars_of = lambda f: [(b[0][0].decode("latin-1"), b[0][1]) for b in d[f]]
-    m1 = lambda f: [g1_of_json(b[1]) for b in d[f]]
-    m2 = lambda f: [g2_of_json(b[1]) for b in d[f]]
+    m1 = lambda f: [b[1] for b in d[f]]
+    m2 = lambda f: [b[1] for b in d[f]]
     mid_vars, all_vars = vars_of("vv"), vars_of("v_all")
     for f in ("ww", "yy", "vav", "waw", "yay", "bvwy"):
         _need(vars_of(f) == mid_vars, "Pinocchio pkey: the I_mid maps must share one domain")
     _need(vars_of("w_all") == all_vars, "key / record lengths or variable domains do not match")
-    g1 = (m1("vv") + m1("yy") + m1("vav") + m1("yay") + m1("bvwy") + [g1_of_json(x) for x in d["si"]] + m1("v_all") + m1("w_all")
-          + [g1_of_json(d[f]) for f in ("vt", "yt", "vavt", "yayt", "vbt", "wbt", "ybt")])
-    g2 = m2("ww") + m2("waw") + [g2_of_json(x) for x in d["si2"]] + [g2_of_json(d["wt"]), g2_of_json(d["wawt"])]
-    return (PKey(np.frombuffer(b"".join(g1), dtype=np.uint8), np.frombuffer(b"".join(g2), dtype=np.uint8)), len(d["si"]) - 1, mid_vars, all_vars)
+    g1 = g1s_of_json(m1("vv") + m1("yy") + m1("vav") + m1("yay") + m1("bvwy") + list(d["si"]) + m1("v_all") + m1("w_all")
+                     + [d[f] for f in ("vt", "yt", "vavt", "yayt", "vbt", "wbt", "ybt")])
+    g2 = g2s_of_json(m2("ww") + m2("waw") + list(d["si2"]) + [d["wt"], d["wawt"]])
+    return (PKey(np.frombuffer(g1, dtype=np.uint8), np.frombuffer(g2, dtype=np.uint8)), len(d["si"]) - 1, mid_vars, all_vars)
 
 
 def pinocchio_vkey_to_json(vk, io_vars):
