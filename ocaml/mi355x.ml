@@ -112,6 +112,19 @@ let of_fr_many ~g2 (scalars : bytes) : bytes =
   if n > 0 then check ((if g2 then zk_g2_of_fr else zk_g1_of_fr) (bytes_start scalars) (sz n) (bytes_start out));
   Bytes.sub out 0 (psize * n)
 
+(* of_compressed_bytes_exn over a whole list on the GPU (a key read from the reference's JSON: every point is compressed there): the compressed points
+   back to back in, the uncompressed points back to back out; Not_on_curve / Invalid_argument as the one-point functions of Bls12_381 raise *)
+let zk_g1_decompress_batch = fn "zk_g1_decompress_batch" (ocaml_bytes @-> size_t @-> ocaml_bytes @-> returning int)
+let zk_g2_decompress_batch = fn "zk_g2_decompress_batch" (ocaml_bytes @-> size_t @-> ocaml_bytes @-> returning int)
+
+let decompress_many ~g2 (comp : bytes) : bytes =
+  let csize = if g2 then 96 else 48 in
+  let n = Bytes.length comp / csize in
+  if Bytes.length comp <> n * csize then invalid_arg "decompress_many";
+  let out = Bytes.create (max 1 (2 * csize * n)) in
+  if n > 0 then check ((if g2 then zk_g2_decompress_batch else zk_g1_decompress_batch) (bytes_start comp) (sz n) (bytes_start out));
+  Bytes.sub out 0 (2 * csize * n)
+
 let powers ~g2 d (s : bytes) : bytes =
   let psize = if g2 then 192 else 96 in
   let out = Bytes.create (psize * (d + 1)) in
