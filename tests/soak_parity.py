@@ -20,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 frb = P.fr_to_bytes
 t_end = time.time() + budget
-n_msm = n_g16 = n_pin = n_der = n_ba = n_multi = n_rns = n_sort = n_pin_multi = 0
+n_msm = n_g16 = n_pin = n_der = n_ba = n_multi = n_rns = n_sort = n_pin_multi = n_dec = 0
 _lib.check(_lib.lib().zk_init(0))
 while time.time() < t_end:
     # ---- MSM with duplicates, negations, identity, tiny / huge / zero scalars
@@ -188,7 +188,33 @@ while time.time() < t_end:
             _lib.set_device_list([0])
         os.environ.pop("ZK_FR_RNS", None)          # set for every fifth case from the upload to the last proof (the switch is read per call under ZK_TEST_FORMS)
         n_pin += 1
+    # ---- every eighth round: a list of compressed points (valid, the identity, sometimes one bad one) through the GPU decompression against the host function
+    if n_msm % 8 == 0:
+        Gd = rnd.choice([G1, G2])
+        cnt = rnd.choice([1, 3, 64, 257, 700])
+        ptsd = Gd.of_Fr(RC.fr_bytes([rnd.randrange(P.R) if rnd.random() > 0.05 else 0 for _ in range(cnt)]))
+        Bd, Cd = Gd.POINT_BYTES, Gd.COMPRESSED_BYTES
+        comps = [Gd.to_compressed_bytes(ptsd[Bd * i:Bd * (i + 1)]) for i in range(cnt)]
+        bad_at = rnd.randrange(cnt) if rnd.random() < 0.3 else None
+        if bad_at is not None:
+            comps[bad_at] = rnd.choice([bytes([comps[bad_at][0] & 0x7F]) + comps[bad_at][1:], bytes([0x9F]) + bytes([0xFF]) * (Cd - 1),
+                                        bytes([0x80]) + rnd.randrange(1, 1 << 64).to_bytes(Cd - 1, "big")])
+        import ctypes as _C
+        outd = np.zeros(cnt * Bd, dtype=np.uint8)
+        bufd = np.frombuffer(b"".join(comps), dtype=np.uint8)
+        rcd = getattr(_lib.lib(), "zk_g1_decompress_batch" if Gd is G1 else "zk_g2_decompress_batch")(bufd.ctypes.data_as(_C.c_void_p), _C.c_size_t(cnt), outd.ctypes.data_as(_C.c_void_p))
+        one = getattr(_lib.lib(), "zk_g1_decompress" if Gd is G1 else "zk_g2_decompress")
+        refs, rcs = [], []
+        for cpt in comps:
+            o1 = _C.create_string_buffer(Bd)
+            rcs.append(one(bytes(cpt), o1))
+            refs.append(o1.raw)
+        if all(r == 0 for r in rcs):
+            assert rcd == 0 and bytes(outd) == b"".join(refs), ("batched decompression differs from the host function", Gd.__name__, cnt)
+        else:
+            assert rcd != 0 and rcd in rcs, ("batched decompression accepted a list the host function rejects", Gd.__name__, cnt, rcd, rcs[bad_at])
+        n_dec += 1
     if (n_msm % 10) == 0:
         print("soak: %d MSM cases, %d Groth16 cases (%d multi-device, %d RNS), %d Pinocchio cases ok" % (n_msm, n_g16, n_multi, n_rns, n_pin), flush=True)
-print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds, %d behind a multi-device handle, %d through the residue number system, %d through the forced two-level sort in its plain / staged forms) pinocchio=%d (%d of them behind a device list)"
-      % (n_msm, n_g16, n_der, n_ba, n_multi, n_rns, n_sort, n_pin, n_pin_multi))
+print("SOAK-OK msm=%d groth16=%d (of them %d with the derived Lagrange form, %d with batch-affine rounds, %d behind a multi-device handle, %d through the residue number system, %d through the forced two-level sort in its plain / staged forms) pinocchio=%d (%d of them behind a device list) decompressed_lists=%d"
+      % (n_msm, n_g16, n_der, n_ba, n_multi, n_rns, n_sort, n_pin, n_pin_multi, n_dec))
