@@ -125,3 +125,29 @@ def test_writer_reproduces_the_golden_json_bytes():
     assert mids2 == mids and bytes(pk2.g1) == bytes(pk.g1) and bytes(pk2.g2) == bytes(pk.g2)
     back = wire.groth16_proof_of_json(proof_js)
     assert (back.a, back.b, back.c) == (proof.a, proof.b, proof.c)
+
+
+def test_vectorised_compression_is_the_per_point_function():
+    """curve.G1/G2.to_compressed_bytes_many (numpy byte logic over a whole key, used by the *_pkey_to_json writers) == zk_g1/g2_compress per point:
+    both signs of y, the identity, and for G2 a y with zero imaginary part (the sign then comes from the real part)."""
+    import oracle_lib as O
+    from oracle import pyref as P
+    from zukelang_amd.curve import G1, G2
+    st = P.fr_stream(0x5EEDC0DE)
+    ks = [1, 2, 3, P.R - 1, P.R - 2] + [next(st) for _ in range(40)]
+    for grp, gen, mul in ((G1, O.g1_generator, O.g1_mul), (G2, O.g2_generator, O.g2_mul)):
+        B = grp.POINT_BYTES
+        pts = [mul(gen(), P.fr_to_bytes(k)) for k in ks] + [bytes([0x40]) + bytes(B - 1)]
+        if grp is G2:          # a synthetic encoding with y1 = 0: only the byte logic is under test here
+            y0_large = bytes(96) + bytes(48) + bytes([0x19]) + bytes(47)
+            y0_small = bytes(96) + bytes(48) + bytes([0x01]) + bytes(47)
+            pts += [y0_large, y0_small]
+        many = grp.to_compressed_bytes_many(b"".join(pts))
+        Cb = grp.COMPRESSED_BYTES
+        assert len(many) == Cb * len(pts)
+        signs = set()
+        for i, pt in enumerate(pts):
+            one = grp.to_compressed_bytes(pt)
+            assert many[Cb * i:Cb * (i + 1)] == one, (grp.__name__, i)
+            signs.add(one[0] & 0x20)
+        assert signs == {0, 0x20}

@@ -124,6 +124,33 @@ class _Group:
         _lib.check(getattr(_lib.lib(), cls._compress)(_p(p), _p(out)))
         return bytes(out)
 
+    _HALF = np.frombuffer(bytes.fromhex("0d0088f51cbff34d258dd3db21a5d66bb23ba5c279c2895fb39869507b587b120f55ffff58a9ffffdcff7fffffffd555"), dtype=np.uint8)   # (p - 1) / 2
+
+    @classmethod
+    def to_compressed_bytes_many(cls, pts):
+        """to_compressed_bytes (curve.ml:199,208) over a list: pure byte logic (x with the flag bits; the sign bit = the lexicographically leading
+        coordinate of y above (p - 1) / 2), vectorised -- what zk_g1/g2_compress do per point.  Uncompressed points back to back in, compressed out."""
+        a = np.ascontiguousarray(np.frombuffer(bytes(pts), dtype=np.uint8)).reshape(-1, cls.POINT_BYTES)
+        cb = cls.COMPRESSED_BYTES
+        out = a[:, :cb].copy()
+        inf = (a[:, 0] & 0x40) != 0
+
+        def above_half(y):          # y: (n, 48) big-endian
+            diff = y != cls._HALF
+            first = diff.argmax(axis=1)
+            rows = np.arange(len(y))
+            return diff.any(axis=1) & (y[rows, first] > cls._HALF[first])
+        if cb == 48:
+            large = above_half(a[:, 48:96])
+        else:
+            y1, y0 = a[:, 96:144], a[:, 144:192]
+            large = np.where((y1 != 0).any(axis=1), above_half(y1), above_half(y0))
+        out[:, 0] |= 0x80
+        out[large, 0] |= 0x20
+        out[inf] = 0
+        out[inf, 0] = 0xC0
+        return out.tobytes()
+
     @classmethod
     def of_compressed_bytes_many(cls, comp):
         """of_compressed_bytes_exn (curve.ml:199-212) mapped over a list ON THE GPU (zk_g1/g2_decompress_batch): `comp` = the compressed points back

@@ -232,8 +232,9 @@ def groth16_vkey_of_json(data):
 def groth16_pkey_to_json(pk, n, mid_vars):
     """Record fields in the reference's declaration order (groth16.ml:24-34): a, d1, ti1, ltd_mid, tiztd, b1, b2, d2, ti2."""
     g1, g2 = bytes(pk.g1), bytes(pk.g2)
-    p1 = lambda i: G1.to_compressed_bytes(g1[96 * i:96 * i + 96])
-    p2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
+    c1, c2 = G1.to_compressed_bytes_many(g1), G2.to_compressed_bytes_many(g2)          # every point of the key in two vectorised passes
+    p1 = lambda i: c1[48 * i:48 * i + 48]
+    p2 = lambda i: c2[96 * i:96 * i + 96]
     o_ti, o_tz = 3, 3 + (n + 2)
     o_lt = o_tz + (n - 1)
     _need(len(g1) == 96 * (o_lt + len(mid_vars)) and len(g2) == 192 * (2 + n + 2), "key / record lengths or variable domains do not match")
@@ -291,8 +292,9 @@ def pinocchio_pkey_to_json(pk, n, mid_vars, all_vars):
     g1, g2 = bytes(pk.g1), bytes(pk.g2)
     k, m = len(mid_vars), len(all_vars)
     _need(len(g1) == 96 * (5 * k + (n + 1) + 2 * m + 7) and len(g2) == 192 * (2 * k + (n + 1) + 2), "key / record lengths or variable domains do not match")
-    c1 = lambda i: G1.to_compressed_bytes(g1[96 * i:96 * i + 96])
-    c2 = lambda i: G2.to_compressed_bytes(g2[192 * i:192 * i + 192])
+    cc1, cc2 = G1.to_compressed_bytes_many(g1), G2.to_compressed_bytes_many(g2)          # every point of the key in two vectorised passes
+    c1 = lambda i: cc1[48 * i:48 * i + 48]
+    c2 = lambda i: cc2[96 * i:96 * i + 96]
     r1 = lambda o, cnt: [c1(o + i) for i in range(cnt)]
     r2 = lambda o, cnt: [c2(o + i) for i in range(cnt)]
     o_si, o_va = 5 * k, 5 * k + n + 1
